@@ -1,0 +1,64 @@
+"""Shared parity criteria (used by the CPU oracle-vs-reference tests and the GPU HIP-vs-oracle tests).
+
+Float tolerances follow BASELINE.json's north_star: frame counts bit-exact, log-mel and logits
+within 1e-4 (float32).  Two facts measured against the reference itself (tools/make_goldens.py,
+see DESIGN.md "Conditioning") shape how 1e-4 is applied to the frontend:
+
+ * The reference evaluates each 400-tap DFT sum in float32, so every mel bin of a frame carries
+   an ABSOLUTE error of ~1.5e-6 x that frame's peak mel power (reference vs float64 evaluation
+   of the same graph).  Bins more than ~40 dB below the frame peak (tonal inputs, silence
+   between words) are therefore rounding noise in the reference: it sits up to 0.57 dB from
+   exact arithmetic there, and no implementation can agree with it to 1e-4 dB on those bins.
+ * On bins within 40 dB of their frame's peak, two correct float32 implementations agree to
+   ~3e-5 dB.
+
+So: (A) |d dB| <= 1e-4 on bins >= 1e-4 x frame peak; (B) |d mel| <= 3e-6 x frame peak on ALL bins;
+and for PCM->logit, |d logit| <= 1e-4 on every broadband, silent and real-speech clip (observed
+<= 2e-5); the three synthetic tonal clips (sine x2, chirp), whose logits the reference itself
+only determines to ~1e-3, get 1e-4 + 4 x the measured float32 noise scale (logit_bounds).
+"""
+import numpy as np
+
+DB_ATOL = 1e-4
+MEL_FRAME_REL = 3e-6
+COND_REL_FLOOR = 1e-4
+LOGIT_ATOL = 1e-4
+
+
+def frontend_errors(mel, db, mel_ref, db_ref):
+    """mel/db [B, n_mels, T]. Returns (max dB error on well-conditioned bins, max |dmel|/frame peak,
+    fraction of bins that are well-conditioned)."""
+    fpk = mel_ref.max(axis=1, keepdims=True)
+    ok = (mel_ref >= COND_REL_FLOOR * fpk) & (mel_ref > 1e-10)
+    e_db = float(np.abs(db - db_ref)[ok].max()) if ok.any() else 0.0
+    e_mel = float((np.abs(mel - mel_ref) / np.maximum(fpk, 1e-30)).max())
+    return e_db, e_mel, float(ok.mean())
+
+
+def assert_frontend_close(mel, db, mel_ref, db_ref, what=""):
+    assert mel.shape == mel_ref.shape and db.shape == db_ref.shape, (mel.shape, mel_ref.shape)
+    e_db, e_mel, frac = frontend_errors(mel, db, mel_ref, db_ref)
+    assert e_db <= DB_ATOL, f"{what}: log-mel differs by {e_db:.3e} dB on well-conditioned bins"
+    assert e_mel <= MEL_FRAME_REL, f"{what}: mel power differs by {e_mel:.3e} x frame peak"
+    # silent frames must land exactly on the clamp floor in both
+    silent = mel_ref.max(axis=1) == 0
+    if silent.any():
+        assert np.abs(db.transpose(0, 2, 1)[silent] + 100.0).max() <= 1e-5, f"{what}: silent frames not at -100 dB"
+    return e_db, e_mel, frac
+
+
+def is_tonal(names):
+    """Synthetic pure-tone / chirp clips: >50% of their mel bins sit below the float32 noise
+    floor of the frame, so the reference's own logits move by 1e-3 under re-association."""
+    return np.array([str(n).startswith(("sine", "chirp")) for n in names])
+
+
+def logit_bounds(names, logits_ref, logits_f32_other, logits_exact_frontend):
+    """Per-clip |d logit| bound: 1e-4 everywhere (north_star); tonal clips add 4x the float32
+    noise scale, estimated from two independent float32 evaluations (the reference and the
+    oracle) against the exact-arithmetic (float64) frontend feeding the same head."""
+    noise = np.maximum(np.abs(logits_ref - logits_exact_frontend), np.abs(logits_f32_other - logits_exact_frontend))
+    b = np.full(logits_ref.shape, LOGIT_ATOL, np.float64)
+    t = is_tonal(names)
+    b[t] += 4.0 * noise[t]
+    return b

@@ -1,0 +1,111 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz,
+produced by tools/make_goldens.py importing /root/reference).  CPU-only."""
+import numpy as np
+import pytest
+
+import oracle
+from nanowakeword_amd.config import HeadConfig, param_spec
+from nanowakeword_amd.synth import synth_features, synth_state_dict, state_dict_checksum
+from conftest import head_case_names
+from parity import assert_frontend_close, logit_bounds, DB_ATOL
+
+LOGIT_ATOL = 2e-5   # oracle vs reference on identical float32 features
+
+
+def test_tables_match_torchaudio_semantics(golden_frontend):
+    g = golden_frontend
+    w, fb64 = oracle.default_tables(n_mels=64)
+    _, fb40 = oracle.default_tables(n_mels=40)
+    assert np.abs(w - g["window"]).max() <= 3e-7   # torch builds it in float32 (0.5-0.5cos cancels near the ends)
+    assert np.abs(fb64 - g["fb64"]).max() <= 1e-5
+    assert np.abs(fb40 - g["fb40"]).max() <= 1e-5
+    assert ((fb64 > 0) == (g["fb64"] > 0)).mean() > 0.999
+    re, im = oracle.dft_bases(g["window"])
+    assert np.abs(re[1] - g["real_basis_row1"]).max() <= 1e-7
+    assert np.abs(im[1] - g["imag_basis_row1"]).max() <= 1e-7
+
+
+def test_frame_law_bit_exact(golden_frontend):
+    g = golden_frontend
+    for n, fc, fn in zip(g["edge_n"], g["edge_frames_center"], g["edge_frames_nocenter"]):
+        assert oracle.frame_count(int(n), center=True) == int(fc)
+        assert oracle.frame_count(int(n), center=False) == int(fn)
+    assert oracle.frame_count(16000, center=True) == 101
+    assert oracle.frame_count(16000, center=False) == 98
+
+
+@pytest.mark.parametrize("variant", ["64c", "40n"])
+def test_frontend_against_reference(golden_frontend, variant):
+    g = golden_frontend
+    if variant == "64c":
+        fb, center, mel_ref, db_ref = g["fb64"], True, g["mel64"], g["db64"]
+    else:
+        fb, center, mel_ref, db_ref = g["fb40"], False, g["mel40"], g["db40"]
+    mel = oracle.mel_power(g["pcm"], g["window"], fb, center=center)
+    assert mel.dtype == np.float32
+    db = oracle.logmel_db(mel)
+    e_db, e_mel, frac = assert_frontend_close(mel, db, mel_ref, db_ref, variant)
+    assert frac > 0.6
+    zi = list(g["names"]).index("zeros0")
+    assert np.all(db_ref[zi] == -100.0) and np.abs(db[zi] + 100.0).max() <= 1e-5
+
+
+def test_frontend_short_clip(golden_frontend):
+    g = golden_frontend
+    db = oracle.frontend_logmel(g["short_pcm"], g["window"], g["fb64"])
+    assert db.shape == g["short_db64"].shape == (2, 64, 7)
+    assert np.abs(db - g["short_db64"]).max() <= DB_ATOL
+
+
+def test_synth_weights_are_pinned(golden_heads):
+    d, meta = golden_heads
+    for name, c in meta.items():
+        cfg = HeadConfig(**c)
+        assert state_dict_checksum(synth_state_dict(cfg)) == str(d[f"{name}/sd_checksum"]), name
+    import os
+    from conftest import GOLDEN
+    small = np.load(os.path.join(GOLDEN, "sd_dnn_small.npz"))
+    sd = synth_state_dict(HeadConfig("dnn", (16, 96), layer_dim=16, embedding_dim=8))
+    assert set(small.files) == set(sd)
+    for k in sd:
+        assert np.array_equal(small[k], sd[k]), k
+
+
+@pytest.mark.parametrize("name", head_case_names())
+def test_head_against_reference(golden_heads, golden_frontend, name):
+    d, meta = golden_heads
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    feats = synth_features(4, cfg.input_shape)
+    logits = oracle.model_forward(feats, sd, cfg)
+    ref = d[f"{name}/logits_feat"]
+    assert logits.shape == ref.shape
+    assert np.abs(logits - ref).max() <= LOGIT_ATOL, np.abs(logits - ref).max()
+    if f"{name}/emb_feat" in d:
+        emb = oracle.head_forward(feats, sd, cfg)
+        e_ref = d[f"{name}/emb_feat"]
+        assert np.abs(emb - e_ref).max() <= 2e-5 * max(1.0, np.abs(e_ref).max())
+    if f"{name}/logits_pcm" in d:
+        g = golden_frontend
+        if cfg.model_type == "e2e_dnn":
+            lm = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"])
+        elif cfg.input_shape == (101, 64):
+            lm = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"]).transpose(0, 2, 1)
+        else:
+            lm = oracle.frontend_logmel(g["pcm"], g["window"], g["fb40"], center=False).transpose(0, 2, 1)
+        lp = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg)
+        rp = d[f"{name}/logits_pcm"]
+        # conditioning of each clip: the reference's own distance from an exact-arithmetic frontend
+        n_mels = 40 if cfg.input_shape == (98, 40) else 64
+        fbx = g["fb40"] if n_mels == 40 else g["fb64"]
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], fbx, center=(n_mels == 64), dtype=np.float64)
+        lm64 = lm64 if cfg.model_type == "e2e_dnn" else lm64.transpose(0, 2, 1)
+        lx = oracle.model_forward(np.ascontiguousarray(lm64, dtype=np.float32), sd, cfg)
+        bound = logit_bounds(g["names"], rp, lp, lx)
+        assert np.all(np.abs(lp - rp) <= bound), (np.abs(lp - rp).ravel(), bound.ravel())
+        if cfg.model_type == "e2e_dnn":
+            pe = d[f"{name}/probs_pcm_export"]
+            assert pe.shape == (16, 1, 1)
+            assert np.all(np.abs(oracle.sigmoid(lp).reshape(-1, 1, 1) - pe) <= bound.reshape(-1, 1, 1))
+            # export pool patch == adaptive pool at this shape
+            assert np.abs(rp - d[f"{name}/logits_pcm_adaptivepool"]).max() <= 1e-6

@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (read-only import).
+
+Runs only in the build container, where /root/reference exists.  Nothing here
+travels to the GPU box except the emitted fixtures (data: inputs + expected
+outputs).  The reference's absent third-party deps are stubbed:
+  * torchaudio.transforms.MelSpectrogram / AmplitudeToDB -> attribute-carrying
+    shims restating torchaudio's published defaults (window = torch.hann_window,
+    fb = melscale_fbanks formula in torch float32 like torchaudio evaluates it);
+    the mel module is then swapped for the reference's own ONNXSafeMelSpectrogram
+    by the reference's own replace_mel_spectrogram(), which is the form its CPU
+    interpreter executes (nanowakeword/_export/onnx.py:27-93).
+  * torchinfo -> empty stub (only used by Model.summary()).
+  * onnxruntime -> scripted fake session, used only to capture predict()
+    state-machine traces of NanoInterpreter (nanointerpreter.py:606-833).
+
+usage: python tools/make_goldens.py [--out tests/golden]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import types
+import wave
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------ third-party shims
+class _Spec(torch.nn.Module):
+    def __init__(self, n_fft, win_length, hop_length):
+        super().__init__()
+        self.n_fft, self.win_length, self.hop_length = n_fft, win_length, hop_length
+        self.center, self.pad_mode, self.power = True, "reflect", 2.0
+        self.register_buffer("window", torch.hann_window(win_length))   # periodic=True default
+
+
+class _MelScale(torch.nn.Module):
+    def __init__(self, n_mels, sample_rate, n_stft, f_min=0.0, f_max=None):
+        super().__init__()
+        f_max = float(sample_rate // 2) if f_max is None else f_max
+        # torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk"), torch float32 ops
+        all_freqs = torch.linspace(0, sample_rate // 2, n_stft)
+        m_min = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+        m_max = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+        m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+        f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+        f_diff = f_pts[1:] - f_pts[:-1]
+        slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+        down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+        up = slopes[:, 2:] / f_diff[1:]
+        self.register_buffer("fb", torch.max(torch.zeros(1), torch.min(down, up)))
+
+
+class MelSpectrogramShim(torch.nn.Module):
+    def __init__(self, sample_rate=16000, n_fft=400, win_length=None, hop_length=None, n_mels=128,
+                 f_min=0.0, f_max=None, center=True):
+        super().__init__()
+        win_length = win_length or n_fft
+        hop_length = hop_length or win_length // 2
+        self.spectrogram = _Spec(n_fft, win_length, hop_length)
+        self.spectrogram.center = center
+        self.mel_scale = _MelScale(n_mels, sample_rate, n_fft // 2 + 1, f_min, f_max)
+
+    def forward(self, x):
+        raise RuntimeError("shim: must be replaced by ONNXSafeMelSpectrogram")
+
+
+class AmplitudeToDBShim(torch.nn.Module):
+    """torchaudio.transforms.AmplitudeToDB(stype='power', top_db=None): 10*log10(clamp(x,1e-10)) - 10*log10(max(1e-10,1))."""
+    def forward(self, x):
+        x_db = 10.0 * torch.log10(torch.clamp(x, min=1e-10))
+        return x_db - 10.0 * math.log10(max(1e-10, 1.0))
+
+
+def install_stubs(scripted_session_factory=None):
+    ta = types.ModuleType("torchaudio")
+    tat = types.ModuleType("torchaudio.transforms")
+    tat.MelSpectrogram = MelSpectrogramShim
+    tat.AmplitudeToDB = AmplitudeToDBShim
+    ta.transforms = tat
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tat
+    ti = types.ModuleType("torchinfo")
+    ti.summary = lambda *a, **k: None
+    sys.modules["torchinfo"] = ti
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def ref_frontend(n_mels, center):
+    from nanowakeword._export.onnx import ONNXSafeMelSpectrogram
+    shim = MelSpectrogramShim(16000, n_fft=400, win_length=400, hop_length=160, n_mels=n_mels, center=center)
+    return ONNXSafeMelSpectrogram(shim).eval(), shim
+
+
+def load_wavs():
+    out = {}
+    base = os.path.join(REF, "examples", "training_data")
+    for sub in sorted(os.listdir(base)):
+        d = os.path.join(base, sub)
+        if not os.path.isdir(d):
+            continue
+        for fn in sorted(os.listdir(d)):
+            if fn.endswith(".wav"):
+                with wave.open(os.path.join(d, fn), "rb") as f:
+                    assert f.getframerate() == 16000 and f.getsampwidth() == 2 and f.getnchannels() == 1
+                    out[f"{sub}/{fn}"] = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16).copy()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    install_stubs()
+    torch.set_num_threads(1)
+
+    from nanowakeword.modules.model import Model                      # reseeds torch/np (SEED=10)
+    from nanowakeword._export import onnx as ref_onnx
+    from nanowakeword_amd.config import HeadConfig, param_spec
+    from nanowakeword_amd.synth import synth_pcm, synth_features, synth_state_dict, state_dict_checksum
+
+    # ---------------------------------------------------------------- frontend goldens
+    wavs = load_wavs()
+    wav_names = sorted(wavs)
+    wav_pcm = np.stack([wavs[k][:16000] for k in wav_names])
+    assert wav_pcm.shape == (len(wav_names), 16000), wav_pcm.shape
+    pcm_set = {
+        "noise": synth_pcm("noise", 4), "loud": synth_pcm("loud", 1), "zeros": synth_pcm("zeros", 1),
+        "sine": synth_pcm("sine", 2), "chirp": synth_pcm("chirp", 1), "square": synth_pcm("square", 1),
+        "speechlike": synth_pcm("speechlike", 2), "wav": wav_pcm,
+    }
+    names, clips = [], []
+    for k, v in pcm_set.items():
+        for i in range(v.shape[0]):
+            names.append(f"{k}{i}")
+            clips.append(v[i])
+    pcm = np.stack(clips)                                            # [16, 16000] int16
+    fe64, shim64 = ref_frontend(64, True)
+    fe40, shim40 = ref_frontend(40, False)
+    with torch.no_grad():
+        x = torch.from_numpy(pcm.astype(np.float32) / 32768.0)       # nanointerpreter.py:750
+        mel64 = fe64(x)                                              # [B,64,101]
+        db64 = AmplitudeToDBShim()(mel64)
+        mel40 = fe40(x)                                              # [B,40,98]
+        db40 = AmplitudeToDBShim()(mel40)
+    assert mel64.shape[1:] == (64, 101) and mel40.shape[1:] == (40, 98)
+    fr = dict(pcm=pcm, names=np.array(names), wav_names=np.array(wav_names),
+              window=shim64.spectrogram.window.numpy(), fb64=shim64.mel_scale.fb.numpy(),
+              fb40=shim40.mel_scale.fb.numpy(),
+              real_basis_row1=fe64.real_basis[1, 0].numpy(), imag_basis_row1=fe64.imag_basis[1, 0].numpy(),
+              mel64=mel64.numpy(), db64=db64.numpy(), mel40=mel40.numpy(), db40=db40.numpy())
+    # frame-law edge cases (bit-exact frame counts)
+    edge = {}
+    for n in (400, 401, 559, 560, 15999, 16000, 16001, 32000):
+        xe = torch.from_numpy(synth_pcm("noise", 1, n, seed=77).astype(np.float32) / 32768.0)
+        with torch.no_grad():
+            edge[n] = (int(fe64(xe).shape[-1]), int(fe40(xe).shape[-1]))
+    fr["edge_n"] = np.array(sorted(edge))
+    fr["edge_frames_center"] = np.array([edge[n][0] for n in sorted(edge)])
+    fr["edge_frames_nocenter"] = np.array([edge[n][1] for n in sorted(edge)])
+    # one short ragged clip with full outputs (N=1000) to pin reflect padding on tiny inputs
+    xs = synth_pcm("noise", 2, 1000, seed=78)
+    with torch.no_grad():
+        fr["short_pcm"] = xs
+        fr["short_db64"] = AmplitudeToDBShim()(fe64(torch.from_numpy(xs.astype(np.float32) / 32768.0))).numpy()
+    np.savez_compressed(os.path.join(args.out, "frontend.npz"), **fr)
+    print("frontend.npz:", {k: getattr(v, "shape", None) for k, v in fr.items()})
+
+    # ---------------------------------------------------------------- head goldens
+    def ref_model(cfg: HeadConfig, sd_np):
+        conf = {"activation_function": cfg.activation, "embedding_dim": cfg.embedding_dim,
+                "crnn_cnn_channels": list(cfg.crnn_cnn_channels), "crnn_rnn_type": cfg.crnn_rnn_type,
+                "conformer_d_model": cfg.conformer_d_model, "conformer_n_head": cfg.conformer_n_head}
+        if cfg.model_type == "e2e_dnn":
+            m = Model(conf, "g", input_shape=(16000,), model_type="e2e_dnn", mode="e2e")
+        else:
+            m = Model(conf, "g", input_shape=cfg.input_shape, model_type=cfg.model_type,
+                      layer_dim=cfg.layer_dim, n_blocks=cfg.n_blocks)
+        ref_sd = m.state_dict()
+        ref_keys = {k: tuple(v.shape) for k, v in ref_sd.items()
+                    if not k.endswith("num_batches_tracked") and not k.startswith("model.mel_spec")}
+        spec = dict(param_spec(cfg))
+        assert ref_keys == spec, (set(ref_keys) ^ set(spec),
+                                  {k: (ref_keys.get(k), spec.get(k)) for k in set(ref_keys) & set(spec)
+                                   if ref_keys[k] != spec[k]})
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+        assert not unexpected, unexpected
+        assert all(k.endswith("num_batches_tracked") or k.startswith("model.mel_spec") for k in missing), missing
+        return m.eval()
+
+    head_cases = [
+        ("dnn_16x96", HeadConfig("dnn", (16, 96))),
+        ("dnn_98x40", HeadConfig("dnn", (98, 40))),
+        ("dnn_101x64", HeadConfig("dnn", (101, 64))),
+        ("dnn_16x96_b2_gelu", HeadConfig("dnn", (16, 96), layer_dim=64, n_blocks=2, activation="gelu")),
+        ("cnn_16x96", HeadConfig("cnn", (16, 96))),
+        ("cnn_98x40", HeadConfig("cnn", (98, 40))),
+        ("cnn_101x64", HeadConfig("cnn", (101, 64))),
+        ("cnn_16x96_silu", HeadConfig("cnn", (16, 96), activation="silu")),
+        ("crnn_16x96", HeadConfig("crnn", (16, 96))),
+        ("crnn_101x64", HeadConfig("crnn", (101, 64))),
+        ("crnn_98x40", HeadConfig("crnn", (98, 40))),
+        ("crnn_16x96_b2_silu", HeadConfig("crnn", (16, 96), layer_dim=32, n_blocks=2, activation="silu")),
+        ("gru_16x96", HeadConfig("gru", (16, 96))),
+        ("gru_101x64", HeadConfig("gru", (101, 64))),
+        ("gru_16x96_b2", HeadConfig("gru", (16, 96), layer_dim=48, n_blocks=2)),
+        ("bcresnet_16x96", HeadConfig("bcresnet", (16, 96))),
+        ("bcresnet_98x40", HeadConfig("bcresnet", (98, 40))),
+        ("bcresnet_101x64", HeadConfig("bcresnet", (101, 64))),
+        ("bcresnet_16x96_gelu", HeadConfig("bcresnet", (16, 96), activation="gelu")),
+        ("conformer_16x96", HeadConfig("conformer", (16, 96))),
+        ("conformer_101x64", HeadConfig("conformer", (101, 64))),
+        ("conformer_16x96_b2", HeadConfig("conformer", (16, 96), n_blocks=2, embedding_dim=32)),
+        ("e2e_dnn_64x101", HeadConfig("e2e_dnn", (64, 101))),
+    ]
+    db64_np = db64.numpy()
+    db40_np = db40.numpy()
+    heads = {}
+    meta = {}
+    for name, cfg in head_cases:
+        sd = synth_state_dict(cfg)
+        m = ref_model(cfg, sd)
+        T, F = cfg.input_shape
+        out = {}
+        # (i) synthetic N(0,1) features
+        feats = synth_features(4, (T, F))
+        body = m.model if cfg.model_type != "e2e_dnn" else None
+        with torch.no_grad():
+            if cfg.model_type == "e2e_dnn":
+                # run the conv body + classifier on given log-mel: emulate forward after the dB stage
+                def body_fwd(lm):
+                    mm = m.model
+                    h = mm.conv_block(lm.unsqueeze(1))
+                    h = mm.flatten(h)
+                    h = mm.act1(mm.bn1(mm.fc1(h)))
+                    return m.classifier(mm.out(h))
+                out["logits_feat"] = body_fwd(torch.from_numpy(feats)).numpy()
+            else:
+                out["logits_feat"] = m(torch.from_numpy(feats)).numpy()
+                out["emb_feat"] = body(torch.from_numpy(feats)).numpy()
+            # (ii) composite: reference frontend log-mel -> head
+            if (T, F) == (101, 64):
+                lm = np.ascontiguousarray(db64_np.transpose(0, 2, 1))
+                out["logits_pcm"] = m(torch.from_numpy(lm)).numpy()
+            elif (T, F) == (98, 40):
+                lm = np.ascontiguousarray(db40_np.transpose(0, 2, 1))
+                out["logits_pcm"] = m(torch.from_numpy(lm)).numpy()
+            elif cfg.model_type == "e2e_dnn":
+                # the native composite: the reference's own E2E model, export-patched, fed float PCM
+                ref_onnx.replace_mel_spectrogram(m)
+                xin = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+                logits_torchpool = m(xin).numpy()
+
+                class W(torch.nn.Module):
+                    def __init__(s, mm):
+                        super().__init__(); s.trained_model = mm
+                    def forward(s, x):
+                        return torch.sigmoid(s.trained_model(x)).view(-1, 1, 1)
+                w = W(m).eval()
+                ref_onnx.make_onnx_safe_adaptive_pool(w, xin[:1].unsqueeze(1))
+                out["probs_pcm_export"] = w(xin.unsqueeze(1)).numpy()        # (B,1,1) as the ONNX output
+                out["logits_pcm"] = m(xin).numpy()                            # after pool patch
+                out["logits_pcm_adaptivepool"] = logits_torchpool
+        out["sd_checksum"] = np.array(state_dict_checksum(sd))
+        meta[name] = cfg.to_dict()
+        for k, v in out.items():
+            heads[f"{name}/{k}"] = v
+        print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()},
+              "logit range", float(out["logits_feat"].min()), float(out["logits_feat"].max()))
+    heads["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(args.out, "heads.npz"), **heads)
+
+    # a small full state_dict, to detect RNG drift of synth_state_dict independently of checksums
+    cfg_small = HeadConfig("dnn", (16, 96), layer_dim=16, embedding_dim=8)
+    np.savez_compressed(os.path.join(args.out, "sd_dnn_small.npz"), **synth_state_dict(cfg_small))
+
+    # ---------------------------------------------------------------- predict() state-machine traces
+    make_predict_traces(os.path.join(args.out, "predict_trace.json"))
+    print("done ->", args.out)
+
+
+def make_predict_traces(path):
+    """Capture NanoInterpreter e2e-mode predict()/predict_clip() behaviour with a scripted session."""
+    ort = types.ModuleType("onnxruntime")
+
+    class SessionOptions:
+        inter_op_num_threads = 0
+        intra_op_num_threads = 0
+
+    class _Inp:
+        def __init__(self, name, shape):
+            self.name, self.shape = name, shape
+
+    class InferenceSession:
+        def __init__(self, path, sess_options=None, providers=None):
+            self._model_filename = path
+            self.clip_samples = 16000
+            self.calls = []
+
+        def get_inputs(self):
+            return [_Inp("input", [None, 1, self.clip_samples])]
+
+        def run(self, output_names, feed):
+            x = feed["input"]
+            assert x.shape == (1, 1, self.clip_samples) and x.dtype == np.float32
+            self.calls.append(x.copy())
+            s = float(np.clip(np.abs(x).mean() * 4.0, 0.0, 1.0))
+            return [np.array([[[s]]], dtype=np.float32)]
+
+    ort.SessionOptions = SessionOptions
+    ort.InferenceSession = InferenceSession
+    sys.modules["onnxruntime"] = ort
+    import tempfile
+    from nanowakeword.interpreter.nanointerpreter import NanoInterpreter
+    from nanowakeword_amd.synth import synth_pcm
+    tmp = tempfile.mkdtemp()
+    mp = os.path.join(tmp, "wake.onnx")
+    open(mp, "wb").close()
+    traces = {}
+    stream = np.concatenate([synth_pcm("noise", 1, 16000 * 3, seed=5)[0],
+                             synth_pcm("loud", 1, 16000, seed=6)[0]])
+
+    def run_trace(chunk, **kw):
+        it = NanoInterpreter.load_model(mp)
+        assert it.preprocessor is None
+        rows = []
+        for i in range(0, len(stream) - chunk + 1, chunk):
+            r = it.predict(stream[i:i + chunk], **kw)
+            rows.append([float(it.raw_scores["wake"]), float(r.score), bool(r.detected) if kw.get("threshold") else False])
+        sess = it.models["wake"]
+        first_clip_sum = float(np.abs(sess.calls[0]).sum()) if sess.calls else 0.0
+        return {"chunk": chunk, "kw": {k: v for k, v in kw.items()}, "rows": rows, "n_calls": len(sess.calls),
+                "first_clip_abs_sum": first_clip_sum}
+
+    traces["chunk1280"] = run_trace(1280)
+    traces["chunk4000"] = run_trace(4000)
+    traces["chunk16000"] = run_trace(16000)
+    traces["patience3"] = run_trace(1280, patience={"wake": 3}, threshold={"wake": 0.5})
+    traces["debounce"] = run_trace(1280, debounce_time=0.5, threshold={"wake": 0.5})
+    it = NanoInterpreter.load_model(mp)
+    res = it.predict_clip(stream[:20000])
+    traces["predict_clip_len"] = len(res)
+    traces["predict_clip_score"] = float(res[0].score)
+    traces["predict_clip_raw"] = float(it.raw_scores["wake"])
+    it.reset()
+    traces["after_reset_buffer"] = int(it.e2e_buffer_samples["wake"])
+    traces["stream_spec"] = {"parts": [["noise", 48000, 5], ["loud", 16000, 6]]}
+    with open(path, "w") as f:
+        json.dump(traces, f, indent=1)
+    print("predict_trace.json rows:", {k: (len(v["rows"]) if isinstance(v, dict) and "rows" in v else v)
+                                       for k, v in traces.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * nww.h - C-ABI of libnwwhip.so: the MI355X (gfx950) implementation of nanowakeword's
+ * batched keyword-spotting hot path  int16 PCM -> STFT -> mel -> dB -> classifier head -> logit.
+ *
+ * The reference (arcosoph/nanowakeword v3.0.0) is pure Python and has no FFI of its own; its
+ * hot path sits behind a duck-typed onnxruntime.InferenceSession:
+ *     session.get_inputs()[0].{name,shape}        nanointerpreter.py:165-167,177-178
+ *     session.run(None, {"input": x}) -> [probs(B,1,1)]   nanointerpreter.py:677,681,783
+ * with `_RemoteSession` (remote_verifier.py:490-648) as the in-tree precedent of a non-ORT
+ * backend.  This header is what a ctypes binding of such a backend binds;
+ * nanowakeword_amd/session.py is that binding.
+ *
+ * Conventions: extern "C", opaque handle, int return codes (0 = ok), no exceptions or C++ types
+ * across the boundary.  Buffers are caller-owned.  `*_host` entry points take host pointers and
+ * synchronise before returning; `*_dev` entry points take device pointers, enqueue on the given
+ * hipStream_t (NULL = the handle's own stream) and do NOT synchronise.  A handle is bound to one
+ * GPU and is not re-entrant (the reference interpreter is single-threaded too:
+ * nanointerpreter.py:955-959); use one handle per GPU / per thread.
+ */
+#ifndef NWW_H
+#define NWW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NWW_OK 0
+#define NWW_ERR_INVALID 1      /* bad argument (ValueError in the reference's terms)          */
+#define NWW_ERR_MISSING 2      /* finalize(): a state_dict tensor was never loaded            */
+#define NWW_ERR_SHAPE 3        /* load_tensor(): shape differs from Model.state_dict()        */
+#define NWW_ERR_HIP 4          /* a HIP runtime call failed; see nww_last_error               */
+#define NWW_ERR_STATE 5        /* call order: run before finalize, load after finalize        */
+#define NWW_ERR_UNSUPPORTED 6
+
+/* head_type: which nanowakeword/modules/architectures.py class the handle evaluates */
+#define NWW_HEAD_DNN 0         /* Net                     architectures.py:102-126 */
+#define NWW_HEAD_CNN 1         /* CNNModel                architectures.py:51-80   */
+#define NWW_HEAD_CRNN 2        /* CRNNModel (rnn=gru)     architectures.py:209-287 */
+#define NWW_HEAD_GRU 3         /* GRUModel                architectures.py:129-145 */
+#define NWW_HEAD_BCRESNET 4    /* BcResNetModel           architectures.py:620-687 */
+#define NWW_HEAD_CONFORMER 5   /* ConformerModel          architectures.py:441-543 */
+#define NWW_HEAD_E2E_DNN 6     /* E2E_MelSpectrogram_CNN  architectures.py:820-889 */
+
+#define NWW_ACT_RELU 0         /* model.py:81-87 activation_function */
+#define NWW_ACT_GELU 1
+#define NWW_ACT_SILU 2
+
+#define NWW_DTYPE_F32 0
+
+typedef struct nww_handle nww_handle;
+
+typedef struct nww_config {
+    int32_t device;            /* HIP device ordinal                                          */
+    /* frontend: T.MelSpectrogram(...) + T.AmplitudeToDB() of architectures.py:830-837,
+       evaluated as the exported ONNXSafeMelSpectrogram (_export/onnx.py:27-83)               */
+    int32_t sample_rate;       /* 16000                                                       */
+    int32_t n_fft;             /* 400 (only 400 = 8*25*2 is implemented)                      */
+    int32_t win_length;        /* 400                                                         */
+    int32_t hop_length;        /* 160                                                         */
+    int32_t n_mels;            /* <= 128                                                      */
+    int32_t center;            /* 1: reflect-pad n_fft/2 (reference e2e), 0: no padding       */
+    float f_min, f_max;        /* 0, sample_rate/2                                            */
+    float amin;                /* 1e-10 clamp floor (-100 dB)                                 */
+    float db_multiplier;       /* 10 (power spectrogram)                                      */
+    /* head: kwargs/config keys of Model() (model.py:67-296)                                  */
+    int32_t head_type;         /* NWW_HEAD_*                                                  */
+    int32_t in_rows, in_cols;  /* Model(input_shape=(in_rows, in_cols))                       */
+    int32_t layer_dim, n_blocks, embedding_dim, activation;
+    int32_t n_crnn_channels;   /* crnn_cnn_channels (<= 4 stages)                             */
+    int32_t crnn_channels[4];
+    int32_t conformer_d_model, conformer_n_head;
+    /* how nww_forward_pcm feeds the head: 0 = log-mel transposed to (frames, n_mels) =
+       Model(input_shape=(frames, n_mels)); 1 = (n_mels, frames) as E2E_MelSpectrogram_CNN.   */
+    int32_t mel_major_features;
+    int32_t reserved[7];
+} nww_config;
+
+/* Fill *cfg with the reference defaults (16 kHz, 400/400/160, 64 mel, center, DNN (16,96)). */
+void nww_default_config(nww_config* cfg);
+
+int nww_create(const nww_config* cfg, nww_handle** out);
+int nww_destroy(nww_handle* h);
+const char* nww_last_error(const nww_handle* h);   /* h may be NULL: last create() error      */
+
+/* Weights. `key` is exactly a Model.state_dict() key ("model.conv1.weight", "classifier.0.bias",
+ * BatchNorm "running_mean"/"running_var"; "num_batches_tracked" is accepted and ignored).
+ * Optional frontend tables taken from an exported model instead of the built-in torchaudio
+ * formulas: "frontend.window" [win_length] and "frontend.mel_fb" [n_fft/2+1, n_mels]
+ * (ONNXSafeMelSpectrogram buffers real_basis[0,0,:] and mel_fb, _export/onnx.py:62-64).     */
+int nww_load_tensor(nww_handle* h, const char* key, const void* host_data,
+                    const int64_t* shape, int32_t ndim, int32_t dtype);
+/* Number of tensors finalize() requires, and the i-th key/shape (for loaders/validators).    */
+int nww_num_tensors(const nww_handle* h);
+int nww_tensor_info(const nww_handle* h, int32_t i, const char** key, int64_t* shape4, int32_t* ndim);
+/* Check completeness, fold BatchNorm (alpha = w/sqrt(var+eps), beta = b - mean*alpha, as
+ * PyTorch's eval kernel), build FFT/mel tables, upload.                                      */
+int nww_finalize(nww_handle* h);
+
+/* Frame law (bit-exact): center ? 1 + N/hop : 1 + (N - n_fft)/hop ; <0 if N is too short.    */
+int32_t nww_num_frames(const nww_handle* h, int32_t n_samples);
+
+/* ---- host-pointer entry points (synchronous) --------------------------------------------- */
+/* pcm [B,N] int16 -> logmel [B, n_mels, frames] float32 dB (the mel module's own layout).    */
+int nww_frontend(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N,
+                 float* logmel_out, int32_t* frames_out);
+/* same, additionally returning the mel power spectrogram [B, n_mels, frames] (may be NULL).  */
+int nww_frontend_ex(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N,
+                    float* logmel_out, float* melpower_out, int32_t* frames_out);
+/* pcm [B,N] -> logits [B] (Model.forward) and/or probs [B] (InferenceWrapper sigmoid,
+ * _export/onnx.py:164-172).  Either output may be NULL.                                      */
+int nww_forward_pcm(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N,
+                    float* logits, float* probs);
+/* feats [B, in_rows, in_cols] float32 -> logits/probs; embedding [B, embedding_dim] optional. */
+int nww_forward_features(nww_handle* h, const float* feats, int32_t B,
+                         float* logits, float* probs);
+int nww_forward_features_ex(nww_handle* h, const float* feats, int32_t B,
+                            float* logits, float* probs, float* embedding);
+
+/* ---- device-pointer entry points (asynchronous on `stream`, a hipStream_t) ----------------- */
+int nww_frontend_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N,
+                     float* d_logmel, int32_t frames_major, void* stream);
+int nww_forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N,
+                        float* d_logits, float* d_probs, void* stream);
+int nww_forward_features_dev(nww_handle* h, const float* d_feats, int32_t B,
+                             float* d_logits, float* d_probs, void* stream);
+/* Pre-size the workspace for batches up to B clips of N samples (otherwise grown on demand,
+ * which synchronises the device).                                                           */
+int nww_reserve(nww_handle* h, int32_t B, int32_t N);
+
+/* Per-stage timing of the last *_dev/_host call is not kept; instead, profile hooks:        */
+/* names of the kernels a forward_pcm launches, in order (for rocprof correlation).           */
+int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen);
+
+const char* nww_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NWW_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libnwwhip.so (include/nww.h).  No CPU fallback: if the HIP library is absent
+or cannot be loaded, importing callers get an ImportError that says how to build it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .config import FrontendConfig, HeadConfig, HEAD_CODE, ACT_CODE
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnwwhip.so")
+
+NWW_OK = 0
+ERR_NAMES = {1: "INVALID", 2: "MISSING", 3: "SHAPE", 4: "HIP", 5: "STATE", 6: "UNSUPPORTED"}
+
+
+class NwwConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32), ("hop_length", C.c_int32),
+        ("n_mels", C.c_int32), ("center", C.c_int32),
+        ("f_min", C.c_float), ("f_max", C.c_float), ("amin", C.c_float), ("db_multiplier", C.c_float),
+        ("head_type", C.c_int32), ("in_rows", C.c_int32), ("in_cols", C.c_int32),
+        ("layer_dim", C.c_int32), ("n_blocks", C.c_int32), ("embedding_dim", C.c_int32), ("activation", C.c_int32),
+        ("n_crnn_channels", C.c_int32), ("crnn_channels", C.c_int32 * 4),
+        ("conformer_d_model", C.c_int32), ("conformer_n_head", C.c_int32),
+        ("mel_major_features", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+_lib = None
+
+# every symbol include/nww.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "nww_default_config", "nww_create", "nww_destroy", "nww_last_error", "nww_load_tensor", "nww_num_tensors",
+    "nww_tensor_info", "nww_finalize", "nww_num_frames", "nww_frontend", "nww_frontend_ex", "nww_forward_pcm",
+    "nww_forward_features", "nww_forward_features_ex", "nww_frontend_dev", "nww_forward_pcm_dev",
+    "nww_forward_features_dev", "nww_reserve", "nww_describe_plan", "nww_version",
+]
+
+
+def load_library():
+    """Load libnwwhip.so once. Raises ImportError (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m nanowakeword_amd.build` "
+            "(or __graft_entry__.build()). nanowakeword_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, f32p, i16p = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int16)
+    lib.nww_default_config.argtypes = [C.POINTER(NwwConfig)]; lib.nww_default_config.restype = None
+    lib.nww_create.argtypes = [C.POINTER(NwwConfig), C.POINTER(vp)]; lib.nww_create.restype = C.c_int
+    lib.nww_destroy.argtypes = [vp]; lib.nww_destroy.restype = C.c_int
+    lib.nww_last_error.argtypes = [vp]; lib.nww_last_error.restype = C.c_char_p
+    lib.nww_load_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32, i32]; lib.nww_load_tensor.restype = C.c_int
+    lib.nww_num_tensors.argtypes = [vp]; lib.nww_num_tensors.restype = C.c_int
+    lib.nww_tensor_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(i32)]
+    lib.nww_tensor_info.restype = C.c_int
+    lib.nww_finalize.argtypes = [vp]; lib.nww_finalize.restype = C.c_int
+    lib.nww_num_frames.argtypes = [vp, i32]; lib.nww_num_frames.restype = i32
+    lib.nww_frontend.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]; lib.nww_frontend.restype = C.c_int
+    lib.nww_frontend_ex.argtypes = [vp, vp, i32, i32, vp, vp, C.POINTER(i32)]; lib.nww_frontend_ex.restype = C.c_int
+    lib.nww_forward_pcm.argtypes = [vp, vp, i32, i32, vp, vp]; lib.nww_forward_pcm.restype = C.c_int
+    lib.nww_forward_features.argtypes = [vp, vp, i32, vp, vp]; lib.nww_forward_features.restype = C.c_int
+    lib.nww_forward_features_ex.argtypes = [vp, vp, i32, vp, vp, vp]; lib.nww_forward_features_ex.restype = C.c_int
+    lib.nww_frontend_dev.argtypes = [vp, vp, i32, i32, vp, i32, vp]; lib.nww_frontend_dev.restype = C.c_int
+    lib.nww_forward_pcm_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp]; lib.nww_forward_pcm_dev.restype = C.c_int
+    lib.nww_forward_features_dev.argtypes = [vp, vp, i32, vp, vp, vp]; lib.nww_forward_features_dev.restype = C.c_int
+    lib.nww_reserve.argtypes = [vp, i32, i32]; lib.nww_reserve.restype = C.c_int
+    lib.nww_describe_plan.argtypes = [vp, C.c_char_p, i32]; lib.nww_describe_plan.restype = C.c_int
+    lib.nww_version.argtypes = []; lib.nww_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major_features: bool | None = None) -> NwwConfig:
+    lib = load_library()
+    c = NwwConfig()
+    lib.nww_default_config(C.byref(c))
+    c.device = device
+    c.sample_rate, c.n_fft, c.win_length, c.hop_length = fe.sample_rate, fe.n_fft, fe.win_length, fe.hop_length
+    c.n_mels, c.center = fe.n_mels, int(bool(fe.center))
+    c.f_min, c.f_max, c.amin, c.db_multiplier = fe.f_min, fe.f_max, fe.amin, fe.db_multiplier
+    c.head_type = HEAD_CODE[head.model_type]
+    c.in_rows, c.in_cols = head.input_shape
+    c.layer_dim, c.n_blocks, c.embedding_dim = head.layer_dim, head.n_blocks, head.embedding_dim
+    c.activation = ACT_CODE[head.activation]
+    ch = list(head.crnn_cnn_channels)
+    if len(ch) > 4:
+        raise ValueError("crnn_cnn_channels supports at most 4 stages")
+    c.n_crnn_channels = len(ch)
+    for i, v in enumerate(ch):
+        c.crnn_channels[i] = int(v)
+    c.conformer_d_model, c.conformer_n_head = head.conformer_d_model, head.conformer_n_head
+    if mel_major_features is None:
+        mel_major_features = head.model_type == "e2e_dnn"
+    c.mel_major_features = int(bool(mel_major_features))
+    return c

@@ -1,0 +1,10 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fe_tables.h"
+
+int fe_lds_bytes(int fc, int hop);
+void fe_plan(int T, int fc_max, int* fc, int* nchunks);
+// d_db / d_mel: [B][n_mels][T] (frames_major = 0) or [B][T][n_mels] (frames_major = 1); either may be null.
+hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
+                     float* d_db, float* d_mel, int frames_major, int fc_max, int block, int max_grid,
+                     hipStream_t stream);

@@ -1,0 +1,73 @@
+// layers.h - launchers of the classifier-head kernels (layers.hip).  All tensors float32, row-major,
+// activations NCHW per clip like the reference's torch modules so flatten orders match the weights.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum NwwAct { ACT_RELU = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_NONE = 3, ACT_SIGMOID = 4, ACT_SWISH = 2 };
+
+// C[M,N] = post( A[M,K] * W[N,K]^T ) with
+//   v = acc + bias[n] (bias may be null); v = v*alpha[n] + beta[n] (alpha may be null: folded BatchNorm1d);
+//   v = act(v); v = res[m*ldres+n] + rscale*v (res may be null).
+// lda/ldc/ldres are row strides in floats (lda % 4 == 0 and A, W 16-byte aligned).
+struct GemmArgs {
+    const float* A; int lda;
+    const float* W;            // [N][K], row stride K
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias; const float* alpha; const float* beta;
+    int act;
+    const float* res; int ldres; float rscale;
+};
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
+
+// 3x3 conv, stride 1, pad 1 on NCHW + bias + (alpha,beta) + act, optionally followed by MaxPool2d(2) (floor).
+// in [B][Cin][H][W] -> out [B][Cout][Ho][Wo], Ho = pool ? H/2 : H.
+struct Conv3Args {
+    const float* in; const float* w; const float* bias; const float* alpha; const float* beta;
+    float* out; int B, Cin, Cout, H, W; int act; int pool;
+};
+hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
+
+// depthwise 3x3, pad 1, stride (sh, sw), no bias: in [B][C][H][W] -> out [B][C][Ho][Wo]
+hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, int C, int H, int W, int sh, int sw,
+                            hipStream_t s);
+// pointwise 1x1 conv with input stride (sh, sw) on NCHW + (alpha,beta) + act + residual add:
+// out[b][co][y][x] = res + act( (sum_ci w[co][ci] in[b][ci][y*sh][x*sw]) * alpha[co] + beta[co] )
+struct PwArgs {
+    const float* in; const float* w; const float* alpha; const float* beta; const float* res; float* out;
+    int B, Cin, Cout, Hin, Win, sh, sw; int act;
+};
+hipError_t launch_pwconv(const PwArgs& a, hipStream_t s);
+
+// rows [R][D]: y = act(LayerNorm(x)*w + b), eps 1e-5, biased variance; in place allowed (y == x)
+hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
+                            hipStream_t s);
+// mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s);
+// mean over the last axis: in [R][L] -> out [R]
+hipError_t launch_mean_last(const float* in, float* out, int R, int L, hipStream_t s);
+// AvgPool2d(kernel (kh,kw), stride (sh,sw)) on [B*C][H][W] -> [B*C][oh][ow]  (export form of AdaptiveAvgPool2d)
+hipError_t launch_avgpool(const float* in, float* out, int BC, int H, int W, int kh, int kw, int sh, int sw, int oh,
+                          int ow, hipStream_t s);
+// y = act(x) elementwise (sigmoid for probabilities)
+hipError_t launch_unary(const float* x, float* y, size_t n, int act, hipStream_t s);
+// GLU over the last axis: in [R][2D] -> out [R][D] = in[:, :D] * sigmoid(in[:, D:])
+hipError_t launch_glu(const float* in, float* out, int R, int D, hipStream_t s);
+// depthwise conv1d over time, 'same' padding, + bias, folded BN (alpha,beta), Swish: x [B][T][D] -> y [B][T][D]
+hipError_t launch_dwconv1d_bn_swish(const float* x, const float* w /*[D][K]*/, const float* bias, const float* alpha,
+                                    const float* beta, float* y, int B, int T, int D, int K, hipStream_t s);
+// multi-head self-attention core: qkv [B][T][3D] (q|k|v) -> out [B][T][D]; softmax(q k^T / sqrt(dh)) v per head
+hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s);
+// [B][C][H][W] -> [B][W][C*H]  (CRNN: sequence over W, features C*H; architectures.py:272-276)
+hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
+// GRU recurrence for one direction. xg [B][T][3H] = x W_ih^T + b_ih (precomputed by GEMM).
+// reverse=0: t = 0..T-1; reverse=1: t = T-1..0.  steps = number of steps to run (T, or 1 for the
+// "last step of a reverse direction" shortcut).  seq_out (may be null) [B][T][ld_seq] receives h at
+// column offset col_off for every visited t; last_out (may be null) [B][ld_last] at col_off gets the
+// h after the final visited step... see layers.hip.
+struct GruArgs {
+    const float* xg; const float* w_hh; const float* b_hh;
+    float* seq_out; int ld_seq; float* last_out; int ld_last; int col_off;
+    int B, T, H, reverse, steps;
+};
+hipError_t launch_gru(const GruArgs& a, hipStream_t s);

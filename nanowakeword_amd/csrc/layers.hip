@@ -1,0 +1,595 @@
+// layers.hip - gfx950 kernels of the classifier heads (float32 end to end, MFMA f32 for dense contractions).
+//
+// Dense contractions (Linear layers, GRU gate GEMMs) run on v_mfma_f32_32x32x2_f32: exact float32
+// products/accumulation (an fmaf chain per output), 157 TF peak.  Operand fragments are fetched as
+// 16-byte loads along K straight from global/L2 (each lane owns one row): lane l = (i = l&31, h = l>>5)
+// holds A[m0+i][k0+4h .. +3]; MFMA step s of a group of four consumes element s, i.e. k = k0 + 4h + s -
+// the k <-> (step, half-wave) assignment is a bijection shared by both operands, which is all the
+// contraction needs.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+//
+// Convolutions are register-blocked direct convs on the VALU: one lane = one output position x COB
+// output channels, weights wave-uniform (scalar loads), so the FMA:load ratio is 36:1 (pooled 3x3).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "layers.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+// block = 256 threads = 4 waves as 2(M) x 2(N), each wave one 32x32 tile -> 64x64 per block.
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 64 + (wave >> 1) * 32;
+    const int n0 = blockIdx.y * 64 + (wave & 1) * 32;
+    if (m0 >= g.M || n0 >= g.N) return;                    // wave-uniform
+    const int i = lane & 31, h = lane >> 5;
+    const int arow = min(m0 + i, g.M - 1), wrow = min(n0 + i, g.N - 1);
+    const float* ap = g.A + (size_t)arow * g.lda + 4 * h;
+    const float* wp = g.W + (size_t)wrow * g.K + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int K = g.K;
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(ap + k + 8 * u);
+            b[u] = *reinterpret_cast<const float4*>(wp + k + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+    }
+    for (; k < K; k += 8) {                                  // K % 4 == 0: the last group may be half
+        float4 a = make_float4(0, 0, 0, 0), b = a;
+        if (k + 4 * h + 4 <= K) {
+            a = *reinterpret_cast<const float4*>(ap + k);
+            b = *reinterpret_cast<const float4*>(wp + k);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    const int n = n0 + i;
+    if (n >= g.N) return;
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+    const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+            float v = acc[r] + bias;
+            if (g.alpha) v = v * al + be;
+            v = act_apply(v, g.act);
+            if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+            g.C[(size_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
+// generic (unaligned / K % 4 != 0) fallback on the VALU: one thread per output, same epilogue.
+__global__ void __launch_bounds__(256) gemm_valu_kernel(GemmArgs g) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)g.M * g.N) return;
+    const int m = (int)(idx / g.N), n = (int)(idx - (size_t)m * g.N);
+    const float* a = g.A + (size_t)m * g.lda;
+    const float* w = g.W + (size_t)n * g.K;
+    float acc = 0.0f;
+    for (int k = 0; k < g.K; ++k) acc = fmaf(a[k], w[k], acc);
+    float v = acc + (g.bias ? g.bias[n] : 0.0f);
+    if (g.alpha) v = v * g.alpha[n] + g.beta[n];
+    v = act_apply(v, g.act);
+    if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+    g.C[(size_t)m * g.ldc + n] = v;
+}
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    if (aligned) {
+        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64);
+        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, g);
+    } else {
+        const size_t total = (size_t)g.M * g.N;
+        hipLaunchKernelGGL(gemm_valu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ conv 3x3
+template <int COB, bool POOL>
+__global__ void __launch_bounds__(256) conv3x3_kernel(Conv3Args a) {
+    constexpr int PS = POOL ? 4 : 3;       // input patch edge
+    constexpr int NP = POOL ? 4 : 1;       // conv outputs per lane (2x2 quad when pooling)
+    const int Ho = POOL ? a.H / 2 : a.H, Wo = POOL ? a.W / 2 : a.W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < Ho * Wo;
+    const int pc = valid ? p : 0;
+    const int oy = pc / Wo, ox = pc - oy * Wo;
+    const int co0 = blockIdx.y * COB, b = blockIdx.z;
+    const int y0 = (POOL ? 2 * oy : oy) - 1, x0 = (POOL ? 2 * ox : ox) - 1;
+    int off[PS][PS];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int r = 0; r < PS; ++r)
+#pragma unroll
+        for (int c = 0; c < PS; ++c) {
+            const int yy = y0 + r, xx = x0 + c;
+            const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            off[r][c] = ok ? yy * a.W + xx : 0;
+            okmask |= (ok ? 1u : 0u) << (r * PS + c);
+        }
+    float acc[NP][COB];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int co = 0; co < COB; ++co) acc[q][co] = 0.0f;
+    const size_t plane = (size_t)a.H * a.W;
+    const float* inb = a.in + (size_t)b * a.Cin * plane;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float* inc = inb + (size_t)ci * plane;
+        float patch[PS][PS];
+#pragma unroll
+        for (int r = 0; r < PS; ++r)
+#pragma unroll
+            for (int c = 0; c < PS; ++c) {
+                const float v = inc[off[r][c]];
+                patch[r][c] = ((okmask >> (r * PS + c)) & 1u) ? v : 0.0f;
+            }
+        const float* wci = a.w + ((size_t)co0 * a.Cin + ci) * 9;      // wave-uniform -> scalar loads
+#pragma unroll
+        for (int co = 0; co < COB; ++co) {
+            const float* wc = wci + (size_t)co * a.Cin * 9;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float wv = wc[dy * 3 + dx];
+                    if (POOL) {
+                        acc[0][co] = fmaf(patch[dy][dx], wv, acc[0][co]);
+                        acc[1][co] = fmaf(patch[dy][dx + 1], wv, acc[1][co]);
+                        acc[2][co] = fmaf(patch[dy + 1][dx], wv, acc[2][co]);
+                        acc[3][co] = fmaf(patch[dy + 1][dx + 1], wv, acc[3][co]);
+                    } else {
+                        acc[0][co] = fmaf(patch[dy][dx], wv, acc[0][co]);
+                    }
+                }
+        }
+    }
+    if (!valid) return;
+    float* ob = a.out + ((size_t)b * a.Cout + co0) * Ho * Wo + p;
+#pragma unroll
+    for (int co = 0; co < COB; ++co) {
+        const float bias = a.bias ? a.bias[co0 + co] : 0.0f;
+        const float al = a.alpha ? a.alpha[co0 + co] : 1.0f, be = a.alpha ? a.beta[co0 + co] : 0.0f;
+        float best = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            float v = acc[q][co] + bias;
+            if (a.alpha) v = v * al + be;
+            v = act_apply(v, a.act);
+            best = (q == 0) ? v : fmaxf(best, v);
+        }
+        ob[(size_t)co * Ho * Wo] = best;
+    }
+}
+
+template <int COB>
+static hipError_t launch_conv3x3_cob(const Conv3Args& a, hipStream_t s) {
+    const int Ho = a.pool ? a.H / 2 : a.H, Wo = a.pool ? a.W / 2 : a.W;
+    if (Ho <= 0 || Wo <= 0) return hipErrorInvalidValue;
+    dim3 grid((Ho * Wo + 255) / 256, a.Cout / COB, a.B);
+    if (a.pool) hipLaunchKernelGGL((conv3x3_kernel<COB, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<COB, false>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s) {
+    if (a.Cout % 16 == 0) return launch_conv3x3_cob<16>(a, s);
+    if (a.Cout % 8 == 0) return launch_conv3x3_cob<8>(a, s);
+    if (a.Cout % 4 == 0) return launch_conv3x3_cob<4>(a, s);
+    return launch_conv3x3_cob<1>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------ depthwise 3x3
+__global__ void __launch_bounds__(256)
+dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out, int C, int H,
+                 int W, int Ho, int Wo, int sh, int sw, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % Wo);
+    size_t t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;                                           // t = b*C + c
+    const int c = (int)(t % C);
+    const float* ip = in + t * (size_t)H * W;
+    const float* wc = w + (size_t)c * 9;
+    float acc = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy * sh - 1 + dy;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = ox * sw - 1 + dx;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float v = ok ? ip[yy * W + xx] : 0.0f;
+            acc = fmaf(v, wc[dy * 3 + dx], acc);
+        }
+    }
+    out[idx] = acc;
+}
+
+hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, int C, int H, int W, int sh, int sw,
+                            hipStream_t s) {
+    const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+    const size_t total = (size_t)B * C * Ho * Wo;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, w, out, C, H, W,
+                       Ho, Wo, sh, sw, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ pointwise 1x1
+template <int COB>
+__global__ void __launch_bounds__(256) pwconv_kernel(PwArgs a) {
+    const int Ho = (a.Hin - 1) / a.sh + 1, Wo = (a.Win - 1) / a.sw + 1;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < Ho * Wo;
+    const int pc = valid ? p : 0;
+    const int oy = pc / Wo, ox = pc - oy * Wo;
+    const int co0 = blockIdx.y * COB, b = blockIdx.z;
+    const size_t plane = (size_t)a.Hin * a.Win;
+    const float* ip = a.in + (size_t)b * a.Cin * plane + (size_t)(oy * a.sh) * a.Win + ox * a.sw;
+    float acc[COB];
+#pragma unroll
+    for (int co = 0; co < COB; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float v = ip[(size_t)ci * plane];
+        const float* wc = a.w + (size_t)co0 * a.Cin + ci;              // wave-uniform
+#pragma unroll
+        for (int co = 0; co < COB; ++co) acc[co] = fmaf(v, wc[(size_t)co * a.Cin], acc[co]);
+    }
+    if (!valid) return;
+    const size_t o0 = ((size_t)b * a.Cout + co0) * Ho * Wo + p;
+#pragma unroll
+    for (int co = 0; co < COB; ++co) {
+        float v = acc[co];
+        if (a.alpha) v = v * a.alpha[co0 + co] + a.beta[co0 + co];
+        v = act_apply(v, a.act);
+        const size_t o = o0 + (size_t)co * Ho * Wo;
+        if (a.res) v += a.res[o];
+        a.out[o] = v;
+    }
+}
+
+hipError_t launch_pwconv(const PwArgs& a, hipStream_t s) {
+    const int Ho = (a.Hin - 1) / a.sh + 1, Wo = (a.Win - 1) / a.sw + 1;
+    if (a.Cout % 16 == 0) {
+        dim3 grid((Ho * Wo + 255) / 256, a.Cout / 16, a.B);
+        hipLaunchKernelGGL((pwconv_kernel<16>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((Ho * Wo + 255) / 256, a.Cout, a.B);
+        hipLaunchKernelGGL((pwconv_kernel<1>), grid, dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm rows
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                 const float* __restrict__ b, int R, int D, int act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.0f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.0f;
+    for (int i = lane; i < D; i += 64) { const float d = xr[i] - mu; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    float* yr = y + (size_t)row * D;
+    for (int i = lane; i < D; i += 64) yr[i] = act_apply((xr[i] - mu) * rstd * w[i] + b[i], act);
+}
+
+hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
+                            hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, y, w, b, R, D, act);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ reductions / pools
+__global__ void __launch_bounds__(256)
+mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*D + d
+    if (idx >= total) return;
+    const size_t b = idx / D, d = idx - b * D;
+    const float* p = in + b * (size_t)L * D + d;
+    float s = 0.0f;
+    for (int l = 0; l < L; ++l) s += p[(size_t)l * D];
+    out[idx] = s / (float)L;
+}
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s) {
+    const size_t total = (size_t)B * D;
+    hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) mean_last_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int L) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* p = in + (size_t)row * L;
+    float s = 0.0f;
+    for (int i = lane; i < L; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s / (float)L;
+}
+hipError_t launch_mean_last(const float* in, float* out, int R, int L, hipStream_t s) {
+    hipLaunchKernelGGL(mean_last_kernel, dim3((R + 3) / 4), dim3(256), 0, s, in, out, R, L);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int kh, int kw, int sh, int sw,
+               int oh, int ow, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx % ow);
+    size_t t = idx / ow;
+    const int i = (int)(t % oh);
+    t /= oh;
+    const float* p = in + t * (size_t)H * W + (size_t)(i * sh) * W + j * sw;
+    float s = 0.0f;
+    for (int y = 0; y < kh; ++y)
+        for (int x = 0; x < kw; ++x) s += p[y * W + x];
+    out[idx] = s / (float)(kh * kw);
+}
+hipError_t launch_avgpool(const float* in, float* out, int BC, int H, int W, int kh, int kw, int sh, int sw, int oh,
+                          int ow, hipStream_t s) {
+    const size_t total = (size_t)BC * oh * ow;
+    hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, H, W, kh, kw,
+                       sh, sw, oh, ow, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) unary_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) y[idx] = act_apply(x[idx], act);
+}
+hipError_t launch_unary(const float* x, float* y, size_t n, int act, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(unary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, act);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ in, float* __restrict__ out, int D, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t r = idx / D, d = idx - r * D;
+    const float a = in[r * 2 * D + d], g = in[r * 2 * D + D + d];
+    out[idx] = a * (1.0f / (1.0f + expf(-g)));
+}
+hipError_t launch_glu(const float* in, float* out, int R, int D, hipStream_t s) {
+    const size_t total = (size_t)R * D;
+    hipLaunchKernelGGL(glu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, D, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ y, int T, int D,
+                int K, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = (b*T + t)*D + d
+    if (idx >= total) return;
+    const int d = (int)(idx % D);
+    const size_t bt = idx / D;
+    const int t = (int)(bt % T);
+    const size_t b = bt / T;
+    const int left = K / 2;                                          // padding='same', odd K: K/2 each side
+    const float* xb = x + b * (size_t)T * D + d;
+    const float* wd = w + (size_t)d * K;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int tt = t - left + k;
+        if (tt >= 0 && tt < T) acc = fmaf(xb[(size_t)tt * D], wd[k], acc);
+    }
+    float v = (acc + bias[d]) * alpha[d] + beta[d];
+    y[idx] = v / (1.0f + expf(-v));
+}
+hipError_t launch_dwconv1d_bn_swish(const float* x, const float* w, const float* bias, const float* alpha,
+                                    const float* beta, float* y, int B, int T, int D, int K, hipStream_t s) {
+    const size_t total = (size_t)B * T * D;
+    hipLaunchKernelGGL(dwconv1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha,
+                       beta, y, T, D, K, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+crnn_seq_kernel(const float* __restrict__ in, float* __restrict__ out, int CH, int W, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // out index: (b*W + w)*CH + ch
+    if (idx >= total) return;
+    const int ch = (int)(idx % CH);
+    const size_t bw = idx / CH;
+    const int w = (int)(bw % W);
+    const size_t b = bw / W;
+    out[idx] = in[(b * CH + ch) * (size_t)W + w];
+}
+hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(crnn_seq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, C * H, W, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ attention core
+// One workgroup per (clip, head).  K and V of the head live in LDS; lane t owns query row t and walks the
+// keys with an online softmax (running max / sum), every lane reading the same K/V element (LDS broadcast).
+template <int DH>
+__global__ void __launch_bounds__(128)
+mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int D, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    float* Vs = Ks + (size_t)T * DH;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const float* base = qkv + (size_t)b * T * 3 * D;
+    for (int i = threadIdx.x; i < T * DH; i += blockDim.x) {
+        const int t = i / DH, c = i - t * DH;
+        Ks[i] = base[(size_t)t * 3 * D + D + head * DH + c];
+        Vs[i] = base[(size_t)t * 3 * D + 2 * D + head * DH + c];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float q[DH], o[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { q[c] = base[(size_t)t * 3 * D + head * DH + c] * scale; o[c] = 0.0f; }
+        float mx = -INFINITY, den = 0.0f;
+        for (int j = 0; j < T; ++j) {
+            const float* kj = Ks + (size_t)j * DH;
+            float sc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) sc = fmaf(q[c], kj[c], sc);
+            const float nm = fmaxf(mx, sc);
+            const float corr = expf(mx - nm), pj = expf(sc - nm);
+            den = den * corr + pj;
+            const float* vj = Vs + (size_t)j * DH;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) o[c] = fmaf(pj, vj[c], o[c] * corr);
+            mx = nm;
+        }
+        const float inv = 1.0f / den;
+        float* op = out + ((size_t)b * T + t) * D + head * DH;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) op[c] = o[c] * inv;
+    }
+}
+
+hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s) {
+    const int dh = D / n_head;
+    const size_t lds = (size_t)2 * T * dh * sizeof(float);
+    if (lds > 150 * 1024 || dh * n_head != D) return hipErrorInvalidValue;
+    const float scale = 1.0f / sqrtf((float)dh);
+    dim3 grid(n_head, B);
+#define MHA_CASE(DHV)                                                                                              \
+    case DHV: {                                                                                                    \
+        if (lds > 64 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_kernel<DHV>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipLaunchKernelGGL((mha_core_kernel<DHV>), grid, dim3(128), lds, s, qkv, out, T, D, scale);                \
+        break;                                                                                                     \
+    }
+    switch (dh) {
+        MHA_CASE(16) MHA_CASE(18) MHA_CASE(24) MHA_CASE(32) MHA_CASE(36) MHA_CASE(48) MHA_CASE(64) MHA_CASE(72)
+        default: return hipErrorInvalidValue;
+    }
+#undef MHA_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ GRU recurrence
+// One workgroup = 32 clips x all H hidden units; wave w owns hidden units [32w, 32w+32) and computes, per
+// step, the three 32x32 gate tiles (r, z, n columns j, H+j, 2H+j) of  hg = h W_hh^T  on MFMA f32, with h as the
+// A operand read from LDS ([32][H+4] floats) and W_hh rows streamed from L2.  Gate math runs in the MFMA C
+// layout (lane = hidden unit j, 16 clips per lane), so xg loads and h stores are coalesced along j, and
+// h_prev stays in registers across steps.  PyTorch semantics: r,z = sigmoid(xg + hg + b_hh);
+// n = tanh(xg_n + r*(hg_n + b_hn)); h' = (1-z) n + z h.
+__global__ void __launch_bounds__(512) gru_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hs = reinterpret_cast<float*>(smem_raw);           // [32][H+4]
+    const int H = a.H, ldh = H + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b0 = blockIdx.x * 32;
+    const int j = wave * 32 + i;                              // hidden unit of this lane (C-layout column)
+    const bool jok = j < H;
+    const int jc = jok ? j : H - 1;
+    for (int idx = threadIdx.x; idx < 32 * ldh; idx += blockDim.x) hs[idx] = 0.0f;
+    float hprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hprev[r] = 0.0f;
+    const float bhr = a.b_hh[jc], bhz = a.b_hh[H + jc], bhn = a.b_hh[2 * H + jc];
+    const float* wr = a.w_hh + (size_t)jc * H + 4 * hh;       // B operand rows (col = lane&31 -> same jc)
+    const float* wz = a.w_hh + (size_t)(H + jc) * H + 4 * hh;
+    const float* wn = a.w_hh + (size_t)(2 * H + jc) * H + 4 * hh;
+    const float* arow = hs + (size_t)i * ldh + 4 * hh;        // A operand row (clip i)
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        f32x16 ar, az, an;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ar[r] = 0.0f; az[r] = 0.0f; an[r] = 0.0f; }
+        if (step > 0) {                                       // h == 0 on the first step
+            for (int k = 0; k < H; k += 8) {
+                float4 av = make_float4(0, 0, 0, 0), br = av, bz = av, bn = av;
+                if (k + 4 * hh + 4 <= H) {
+                    av = *reinterpret_cast<const float4*>(arow + k);
+                    br = *reinterpret_cast<const float4*>(wr + k);
+                    bz = *reinterpret_cast<const float4*>(wz + k);
+                    bn = *reinterpret_cast<const float4*>(wn + k);
+                }
+                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, br.x, ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bz.x, az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bn.x, an, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, br.y, ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bz.y, az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bn.y, an, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, br.z, ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bz.z, az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bn.z, an, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, br.w, ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bz.w, az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bn.w, an, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                      // every wave has finished reading hs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;    // clip row within the block
+            const int b = b0 + c;
+            float hn = 0.0f;
+            if (b < a.B && jok) {
+                const float* xg = a.xg + ((size_t)b * a.T + t) * 3 * H;
+                const float rg = 1.0f / (1.0f + expf(-(xg[j] + ar[r] + bhr)));
+                const float zg = 1.0f / (1.0f + expf(-(xg[H + j] + az[r] + bhz)));
+                const float ng = tanhf(xg[2 * H + j] + rg * (an[r] + bhn));
+                hn = (1.0f - zg) * ng + zg * hprev[r];
+                if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+            }
+            hprev[r] = hn;
+            if (jok) hs[(size_t)c * ldh + j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
+    if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
+    const int waves = (a.H + 31) / 32;
+    const size_t lds = (size_t)32 * (a.H + 4) * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gru_kernel, dim3((a.B + 31) / 32), dim3(waves * 64), lds, s, a);
+    return hipGetLastError();
+}

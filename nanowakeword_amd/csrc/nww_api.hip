@@ -1,0 +1,792 @@
+// nww_api.hip - the C-ABI of include/nww.h: handle, weights, plans (sequence of kernel launches per head).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nww.h"
+#include "fe_tables.h"
+#include "frontend.h"
+#include "layers.h"
+
+namespace {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+    size_t dev_off = 0;     // float offset in the weight arena
+};
+
+struct Step {
+    std::string name;
+    std::function<hipError_t(struct Run&)> fn;
+};
+
+struct Run {
+    int B = 0;
+    hipStream_t stream = nullptr;
+    const float* x = nullptr;   // head input [B][in_rows*in_cols]
+    float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* emb = nullptr;       // [B][E]
+    float* hid = nullptr;       // [B][E/2]
+    float* logits = nullptr;    // [B]
+};
+
+}  // namespace
+
+struct nww_handle {
+    nww_config cfg;
+    FeParams fe;
+    std::string err;
+    std::vector<std::string> keys;                 // required state_dict keys, in order
+    std::map<std::string, HostTensor> tensors;     // required + optional + derived
+    bool finalized = false;
+    float* d_weights = nullptr;
+    FeTables* d_tables = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::vector<Step> plan;
+    size_t buf_per_clip[6] = {0, 0, 0, 0, 0, 0};   // floats per clip of each workspace buffer
+    // workspace (grown on demand)
+    int cap_B = 0, cap_N = 0;
+    float* d_ws = nullptr;
+    int16_t* d_pcm = nullptr;
+    float* d_logmel = nullptr;     // [B][n_mels*frames]
+    float* d_feats = nullptr;      // staging for host feature input
+    float* d_emb = nullptr;
+    float* d_hid = nullptr;
+    float* d_logits = nullptr;
+    float* d_probs = nullptr;
+    int cu_count = 256;
+};
+
+static std::string g_create_err;
+
+static int fail(nww_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                             \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(h, NWW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ spec
+namespace {
+using Shape = std::vector<int64_t>;
+struct SpecBuilder {
+    std::vector<std::string>& keys;
+    std::map<std::string, HostTensor>& t;
+    void add(const std::string& k, Shape s) { keys.push_back(k); t[k].shape = std::move(s); }
+    void lin(const std::string& p, int out, int in) { add(p + ".weight", {out, in}); add(p + ".bias", {out}); }
+    void ln(const std::string& p, int d) { add(p + ".weight", {d}); add(p + ".bias", {d}); }
+    void bn(const std::string& p, int c) {
+        add(p + ".weight", {c}); add(p + ".bias", {c}); add(p + ".running_mean", {c}); add(p + ".running_var", {c});
+    }
+    void gru(const std::string& p, int in, int H, int layers) {
+        for (int l = 0; l < layers; ++l) {
+            const int isz = l == 0 ? in : 2 * H;
+            for (const char* sfx : {"", "_reverse"}) {
+                const std::string s = "_l" + std::to_string(l) + sfx;
+                add(p + ".weight_ih" + s, {3 * H, isz}); add(p + ".weight_hh" + s, {3 * H, H});
+                add(p + ".bias_ih" + s, {3 * H}); add(p + ".bias_hh" + s, {3 * H});
+            }
+        }
+    }
+};
+
+void crnn_out(const nww_config& c, int* C, int* H, int* W) {
+    int h = c.in_rows, w = c.in_cols;
+    for (int i = 0; i < c.n_crnn_channels; ++i) { h /= 2; w /= 2; }
+    *C = c.crnn_channels[c.n_crnn_channels - 1]; *H = h; *W = w;
+}
+
+// Mirrors nanowakeword_amd/config.py:param_spec == Model.state_dict() of the reference (model.py:67-296).
+void build_spec(nww_handle* h) {
+    const nww_config& c = h->cfg;
+    SpecBuilder s{h->keys, h->tensors};
+    const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks;
+    switch (c.head_type) {
+        case NWW_HEAD_DNN:
+            s.lin("model.layer1", L, T * F); s.ln("model.layernorm1", L);
+            for (int i = 0; i < nb; ++i) {
+                const std::string p = "model.blocks." + std::to_string(i);
+                s.lin(p + ".fcn_layer", L, L); s.ln(p + ".layer_norm", L);
+            }
+            s.lin("model.last_layer", E, L);
+            break;
+        case NWW_HEAD_CNN:
+            s.add("model.conv1.weight", {16, 1, 3, 3}); s.add("model.conv1.bias", {16});
+            s.add("model.conv2.weight", {32, 16, 3, 3}); s.add("model.conv2.bias", {32});
+            s.lin("model.fc1", 128, 32 * (T / 4) * (F / 4)); s.lin("model.fc2", E, 128);
+            break;
+        case NWW_HEAD_CRNN: {
+            int cin = 1;
+            for (int i = 0; i < c.n_crnn_channels; ++i) {
+                const int co = c.crnn_channels[i];
+                const std::string p = "model.cnn." + std::to_string(4 * i);
+                s.add(p + ".weight", {co, cin, 3, 3}); s.add(p + ".bias", {co});
+                s.bn("model.cnn." + std::to_string(4 * i + 1), co);
+                cin = co;
+            }
+            int C, H, W; crnn_out(c, &C, &H, &W);
+            s.gru("model.rnn", C * H, L, nb); s.lin("model.fc", E, 2 * L);
+            break;
+        }
+        case NWW_HEAD_GRU:
+            s.gru("model.gru", F, L, nb); s.lin("model.fc", E, 2 * L);
+            break;
+        case NWW_HEAD_BCRESNET: {
+            s.add("model.init_conv.0.weight", {32, 1, 3, 3}); s.bn("model.init_conv.1", 32);
+            const int ch[4] = {32, 64, 128, 256};
+            for (int i = 1; i <= 3; ++i) {
+                const std::string p = "model.block" + std::to_string(i);
+                s.add(p + ".depthwise.weight", {ch[i - 1], 1, 3, 3});
+                s.add(p + ".pointwise.weight", {ch[i], ch[i - 1], 1, 1}); s.bn(p + ".bn1", ch[i]);
+                s.add(p + ".shortcut.0.weight", {ch[i], ch[i - 1], 1, 1}); s.bn(p + ".shortcut.1", ch[i]);
+            }
+            s.lin("model.fc", E, 256);
+            break;
+        }
+        case NWW_HEAD_CONFORMER: {
+            const int D = c.conformer_d_model;
+            s.lin("model.input_proj", D, F);
+            for (int i = 0; i < nb; ++i) {
+                const std::string p = "model.conformer_blocks." + std::to_string(i);
+                for (const char* ff : {".ff1", ".ff2"}) {
+                    s.ln(p + ff + ".layer_norm", D); s.lin(p + ff + ".linear1", 4 * D, D); s.lin(p + ff + ".linear2", D, 4 * D);
+                }
+                s.add(p + ".attention.in_proj_weight", {3 * D, D}); s.add(p + ".attention.in_proj_bias", {3 * D});
+                s.lin(p + ".attention.out_proj", D, D);
+                s.ln(p + ".conv_module.layer_norm", D);
+                s.add(p + ".conv_module.conv1.weight", {2 * D, D, 1}); s.add(p + ".conv_module.conv1.bias", {2 * D});
+                s.add(p + ".conv_module.depthwise_conv.weight", {D, 1, 31}); s.add(p + ".conv_module.depthwise_conv.bias", {D});
+                s.bn(p + ".conv_module.batch_norm", D);
+                s.add(p + ".conv_module.conv2.weight", {D, D, 1}); s.add(p + ".conv_module.conv2.bias", {D});
+                s.ln(p + ".layer_norm", D);
+            }
+            s.lin("model.output_proj", E, D);
+            break;
+        }
+        case NWW_HEAD_E2E_DNN: {
+            int cin = 1;
+            const int ch[3] = {16, 32, 64};
+            for (int i = 0; i < 3; ++i) {
+                const std::string p = "model.conv_block." + std::to_string(4 * i);
+                s.add(p + ".weight", {ch[i], cin, 3, 3}); s.add(p + ".bias", {ch[i]});
+                s.bn("model.conv_block." + std::to_string(4 * i + 1), ch[i]);
+                cin = ch[i];
+            }
+            s.lin("model.fc1", 128, 256); s.bn("model.bn1", 128); s.lin("model.out", E, 128);
+            break;
+        }
+    }
+    s.lin("classifier.0", E / 2, E);
+    s.lin("classifier.3", 1, E / 2);
+}
+
+size_t numel(const Shape& s) { size_t n = 1; for (auto v : s) n *= (size_t)v; return n; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ create / load
+extern "C" void nww_default_config(nww_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->sample_rate = 16000; c->n_fft = 400; c->win_length = 400; c->hop_length = 160; c->n_mels = 64; c->center = 1;
+    c->f_min = 0.f; c->f_max = 8000.f; c->amin = 1e-10f; c->db_multiplier = 10.f;
+    c->head_type = NWW_HEAD_DNN; c->in_rows = 16; c->in_cols = 96; c->layer_dim = 128; c->n_blocks = 1;
+    c->embedding_dim = 64; c->activation = NWW_ACT_RELU;
+    c->n_crnn_channels = 3; c->crnn_channels[0] = 16; c->crnn_channels[1] = 32; c->crnn_channels[2] = 32;
+    c->conformer_d_model = 144; c->conformer_n_head = 4; c->mel_major_features = 0;
+}
+
+extern "C" const char* nww_version(void) { return "nwwhip 0.1.0 (gfx950)"; }
+
+extern "C" const char* nww_last_error(const nww_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
+    if (!cfg || !out) return fail(nullptr, NWW_ERR_INVALID, "nww_create: null argument");
+    *out = nullptr;
+    const nww_config& c = *cfg;
+    if (c.head_type < 0 || c.head_type > NWW_HEAD_E2E_DNN) return fail(nullptr, NWW_ERR_INVALID, "Unsupported model_type code %d", c.head_type);
+    if (c.activation < 0 || c.activation > 2) return fail(nullptr, NWW_ERR_INVALID, "bad activation code %d", c.activation);
+    if (c.in_rows <= 0 || c.in_cols <= 0 || c.embedding_dim < 2 || c.layer_dim <= 0 || c.n_blocks < 0)
+        return fail(nullptr, NWW_ERR_INVALID, "bad head dimensions");
+    if (c.n_fft != 400) return fail(nullptr, NWW_ERR_UNSUPPORTED, "only n_fft=400 is implemented (got %d)", c.n_fft);
+    if (c.win_length <= 0 || c.win_length > c.n_fft) return fail(nullptr, NWW_ERR_INVALID, "win_length must be in 1..n_fft");
+    if (c.hop_length <= 0 || (c.hop_length & 1)) return fail(nullptr, NWW_ERR_UNSUPPORTED, "hop_length must be positive and even");
+    if (c.n_mels <= 0 || c.n_mels > FE_MAX_MELS) return fail(nullptr, NWW_ERR_INVALID, "n_mels must be in 1..%d", FE_MAX_MELS);
+    if (c.head_type == NWW_HEAD_CRNN && (c.n_crnn_channels < 1 || c.n_crnn_channels > 4))
+        return fail(nullptr, NWW_ERR_INVALID, "crnn_cnn_channels must have 1..4 stages");
+    if ((c.head_type == NWW_HEAD_CRNN || c.head_type == NWW_HEAD_GRU) && (c.layer_dim % 4 != 0 || c.layer_dim > 256))
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "GRU hidden size must be a multiple of 4 and <= 256");
+    if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
+        return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NWW_ERR_HIP, "no HIP device available (%s): libnwwhip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (c.device < 0 || c.device >= ndev) return fail(nullptr, NWW_ERR_INVALID, "device %d out of range (0..%d)", c.device, ndev - 1);
+    nww_handle* h = new nww_handle();
+    h->cfg = c;
+    h->fe.sample_rate = c.sample_rate; h->fe.n_fft = c.n_fft; h->fe.win_length = c.win_length; h->fe.hop = c.hop_length;
+    h->fe.n_mels = c.n_mels; h->fe.center = c.center; h->fe.f_min = c.f_min; h->fe.f_max = c.f_max;
+    h->fe.amin = c.amin; h->fe.db_mult = c.db_multiplier;
+    build_spec(h);
+    if (hipSetDevice(c.device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_err = "hipSetDevice/hipStreamCreate failed";
+        delete h;
+        return NWW_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
+    *out = h;
+    return NWW_OK;
+}
+
+static void free_ws(nww_handle* h) {
+    for (void* p : {(void*)h->d_ws, (void*)h->d_pcm, (void*)h->d_logmel, (void*)h->d_feats, (void*)h->d_emb,
+                    (void*)h->d_hid, (void*)h->d_logits, (void*)h->d_probs})
+        if (p) (void)hipFree(p);
+    h->d_ws = nullptr; h->d_pcm = nullptr; h->d_logmel = nullptr; h->d_feats = nullptr; h->d_emb = nullptr;
+    h->d_hid = nullptr; h->d_logits = nullptr; h->d_probs = nullptr; h->cap_B = 0; h->cap_N = 0;
+}
+
+extern "C" int nww_destroy(nww_handle* h) {
+    if (!h) return NWW_OK;
+    (void)hipSetDevice(h->cfg.device);
+    free_ws(h);
+    if (h->d_weights) (void)hipFree(h->d_weights);
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return NWW_OK;
+}
+
+extern "C" int nww_num_tensors(const nww_handle* h) { return h ? (int)h->keys.size() : 0; }
+
+extern "C" int nww_tensor_info(const nww_handle* h, int32_t i, const char** key, int64_t* shape4, int32_t* ndim) {
+    if (!h || i < 0 || i >= (int)h->keys.size()) return NWW_ERR_INVALID;
+    const std::string& k = h->keys[i];
+    const HostTensor& t = h->tensors.at(k);
+    if (key) *key = k.c_str();
+    if (ndim) *ndim = (int)t.shape.size();
+    if (shape4) for (size_t d = 0; d < 4; ++d) shape4[d] = d < t.shape.size() ? t.shape[d] : 1;
+    return NWW_OK;
+}
+
+extern "C" int nww_load_tensor(nww_handle* h, const char* key, const void* host, const int64_t* shape, int32_t ndim,
+                               int32_t dtype) {
+    if (!h || !key || !host || !shape || ndim < 0) return fail(h, NWW_ERR_INVALID, "nww_load_tensor: null argument");
+    if (h->finalized) return fail(h, NWW_ERR_STATE, "nww_load_tensor('%s') after nww_finalize", key);
+    if (dtype != NWW_DTYPE_F32) return fail(h, NWW_ERR_UNSUPPORTED, "only float32 tensors are accepted");
+    std::string k(key);
+    const size_t nbt = std::strlen("num_batches_tracked");
+    if (k.size() >= nbt && k.compare(k.size() - nbt, nbt, "num_batches_tracked") == 0) return NWW_OK;
+    Shape s(shape, shape + ndim);
+    if (k == "frontend.window") {
+        if (ndim != 1 || s[0] != h->cfg.win_length) return fail(h, NWW_ERR_SHAPE, "frontend.window must be [%d]", h->cfg.win_length);
+    } else if (k == "frontend.mel_fb") {
+        if (ndim != 2 || s[0] != h->cfg.n_fft / 2 + 1 || s[1] != h->cfg.n_mels)
+            return fail(h, NWW_ERR_SHAPE, "frontend.mel_fb must be [%d,%d]", h->cfg.n_fft / 2 + 1, h->cfg.n_mels);
+        h->tensors[k].shape = s;
+    } else {
+        auto it = h->tensors.find(k);
+        if (it == h->tensors.end()) return fail(h, NWW_ERR_INVALID, "unexpected state_dict key '%s' for this head", key);
+        if (it->second.shape != s) {
+            std::string want, got;
+            for (auto v : it->second.shape) want += std::to_string(v) + ",";
+            for (auto v : s) got += std::to_string(v) + ",";
+            return fail(h, NWW_ERR_SHAPE, "size mismatch for %s: expected [%s] got [%s]", key, want.c_str(), got.c_str());
+        }
+    }
+    HostTensor& t = h->tensors[k];
+    t.shape = s;
+    t.data.assign(static_cast<const float*>(host), static_cast<const float*>(host) + numel(s));
+    t.loaded = true;
+    return NWW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ plan helpers
+namespace {
+
+struct PlanCtx {
+    nww_handle* h;
+    const float* W(const std::string& k) const {
+        auto it = h->tensors.find(k);
+        return it == h->tensors.end() || !it->second.loaded ? nullptr : h->d_weights + it->second.dev_off;
+    }
+    void need(int buf, size_t floats_per_clip) {
+        if (h->buf_per_clip[buf] < floats_per_clip) h->buf_per_clip[buf] = floats_per_clip;
+    }
+    void add(const std::string& name, std::function<hipError_t(Run&)> fn) { h->plan.push_back({name, std::move(fn)}); }
+};
+
+// source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
+inline const float* src(Run& r, int id) { return id == -1 ? r.x : id == -2 ? r.emb : id == -3 ? r.hid : r.buf[id]; }
+inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid : id == -4 ? r.logits : r.buf[id]; }
+
+// rows_per_clip: M = B*rows_per_clip
+void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
+              const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
+              int res_id = 99, float rscale = 1.f) {
+    if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
+    p.add("gemm:" + name, [=](Run& r) {
+        GemmArgs g;
+        g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;
+        g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
+        g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
+        return launch_gemm(g, r.stream);
+    });
+}
+
+void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
+              const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool) {
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    p.need(out_id, (size_t)Cout * Ho * Wo);
+    p.add("conv3x3:" + name, [=](Run& r) {
+        Conv3Args a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, Cin, Cout, H, W, act, pool};
+        return launch_conv3x3(a, r.stream);
+    });
+}
+
+// nn.GRU(bidirectional) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers xg_id, seqA, seqB.
+void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int I, int H, int layers, int xg_id,
+                    int seqA, int seqB, int last_id) {
+    p.need(xg_id, (size_t)T * 3 * H);
+    p.need(last_id, (size_t)2 * H);
+    int cur_in = in_id, cur_I = I;
+    for (int l = 0; l < layers; ++l) {
+        const bool last = l == layers - 1;
+        const int seq_out = (l % 2 == 0) ? seqA : seqB;
+        if (!last) p.need(seq_out, (size_t)T * 2 * H);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
+            const float* wih = p.W(prefix + ".weight_ih" + sfx);
+            const float* whh = p.W(prefix + ".weight_hh" + sfx);
+            const float* bih = p.W(prefix + ".bias_ih" + sfx);
+            const float* bhh = p.W(prefix + ".bias_hh" + sfx);
+            add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, 3 * H, cur_I, wih, bih, ACT_NONE);
+            const int in_T = T;
+            p.add("gru:" + prefix + sfx, [=](Run& r) {
+                GruArgs a;
+                a.xg = r.buf[xg_id]; a.w_hh = whh; a.b_hh = bhh;
+                a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
+                a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H; a.col_off = dir ? H : 0;
+                a.B = r.B; a.T = in_T; a.H = H; a.reverse = dir;
+                a.steps = (last && dir) ? 1 : in_T;          // reverse half of rnn_out[:, -1] is its first step
+                return launch_gru(a, r.stream);
+            });
+        }
+        cur_in = seq_out; cur_I = 2 * H;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ finalize
+extern "C" int nww_finalize(nww_handle* h) {
+    if (!h) return NWW_ERR_INVALID;
+    if (h->finalized) return NWW_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const nww_config& c = h->cfg;
+    for (const auto& k : h->keys)
+        if (!h->tensors[k].loaded) return fail(h, NWW_ERR_MISSING, "Missing key(s) in state_dict: '%s'", k.c_str());
+    // ---- fold every BatchNorm (eval): alpha = w/sqrt(var+eps), beta = b - mean*alpha (PyTorch CPU kernel form)
+    std::vector<std::string> bn_prefixes;
+    for (const auto& k : h->keys) {
+        const std::string sfx = ".running_var";
+        if (k.size() > sfx.size() && k.compare(k.size() - sfx.size(), sfx.size(), sfx) == 0)
+            bn_prefixes.push_back(k.substr(0, k.size() - sfx.size()));
+    }
+    for (const auto& p : bn_prefixes) {
+        const HostTensor &w = h->tensors[p + ".weight"], &b = h->tensors[p + ".bias"], &m = h->tensors[p + ".running_mean"],
+                         &v = h->tensors[p + ".running_var"];
+        HostTensor al, be;
+        al.shape = be.shape = w.shape;
+        al.data.resize(w.data.size()); be.data.resize(w.data.size());
+        for (size_t i = 0; i < w.data.size(); ++i) {
+            const float invstd = 1.0f / std::sqrt(v.data[i] + 1e-5f);
+            al.data[i] = w.data[i] * invstd;
+            be.data[i] = b.data[i] - m.data[i] * al.data[i];
+        }
+        al.loaded = be.loaded = true;
+        h->tensors[p + ".alpha"] = al;
+        h->tensors[p + ".beta"] = be;
+    }
+    // ---- weight arena (each tensor 16-byte aligned)
+    size_t total = 0;
+    for (auto& kv : h->tensors) {
+        if (!kv.second.loaded || kv.first.rfind("frontend.", 0) == 0) continue;
+        kv.second.dev_off = total;
+        total += (kv.second.data.size() + 3) & ~(size_t)3;
+    }
+    HIP_TRY(h, hipMalloc(&h->d_weights, (total + 4) * sizeof(float)));
+    for (auto& kv : h->tensors) {
+        if (!kv.second.loaded || kv.first.rfind("frontend.", 0) == 0) continue;
+        HIP_TRY(h, hipMemcpy(h->d_weights + kv.second.dev_off, kv.second.data.data(), kv.second.data.size() * sizeof(float),
+                             hipMemcpyHostToDevice));
+    }
+    // ---- frontend tables
+    {
+        std::vector<float> win, fb;
+        auto wi = h->tensors.find("frontend.window");
+        if (wi != h->tensors.end() && wi->second.loaded) win = wi->second.data; else fe_default_window(h->fe.win_length, win);
+        auto fi = h->tensors.find("frontend.mel_fb");
+        if (fi != h->tensors.end() && fi->second.loaded) fb = fi->second.data; else fe_default_melfb(h->fe, fb);
+        FeTables tb;
+        const std::string e = fe_build_tables(h->fe, win.data(), fb.data(), &tb);
+        if (!e.empty()) return fail(h, NWW_ERR_INVALID, "frontend tables: %s", e.c_str());
+        const size_t tbytes = (sizeof(FeTables) + 15) & ~(size_t)15;
+        HIP_TRY(h, hipMalloc(&h->d_tables, tbytes));
+        HIP_TRY(h, hipMemset(h->d_tables, 0, tbytes));
+        HIP_TRY(h, hipMemcpy(h->d_tables, &tb, sizeof(FeTables), hipMemcpyHostToDevice));
+    }
+    // ---- plan
+    PlanCtx p{h};
+    const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks, act = c.activation;
+    switch (c.head_type) {
+        case NWW_HEAD_DNN: {                      // Net: architectures.py:110-126
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE);
+            p.add("layernorm:layernorm1", [=](Run& r) {
+                return launch_layernorm(r.buf[0], r.buf[0], p.W("model.layernorm1.weight"), p.W("model.layernorm1.bias"), r.B, L, act, r.stream);
+            });
+            int cur = 0;
+            for (int i = 0; i < nb; ++i) {
+                const std::string q = "model.blocks." + std::to_string(i);
+                const int nxt = cur ^ 1;
+                add_gemm(p, q + ".fcn_layer", cur, nxt, 1, L, L, p.W(q + ".fcn_layer.weight"), p.W(q + ".fcn_layer.bias"), ACT_NONE);
+                const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
+                p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[nxt], r.buf[nxt], lw, lb, r.B, L, act, r.stream); });
+                cur = nxt;
+            }
+            add_gemm(p, "last_layer", cur, -2, 1, E, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
+            add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
+            add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
+            add_gemm(p, "fc1", 1, 0, 1, 128, 32 * (T / 4) * (F / 4), p.W("model.fc1.weight"), p.W("model.fc1.bias"), act);
+            add_gemm(p, "fc2", 0, -2, 1, E, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_E2E_DNN: {                  // E2E_MelSpectrogram_CNN body: architectures.py:840-865,877-889
+            const int Hh = T, Ww = F;             // (n_mels, frames)
+            const int ch[3] = {16, 32, 64};
+            int cin = 1, hh = Hh, ww = Ww, cur = -1;
+            for (int i = 0; i < 3; ++i) {
+                const std::string cw = "model.conv_block." + std::to_string(4 * i), bnp = "model.conv_block." + std::to_string(4 * i + 1);
+                const int out = (i % 2 == 0) ? 0 : 1;
+                add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
+                if (i < 2) { hh /= 2; ww /= 2; }
+                cin = ch[i]; cur = out;
+            }
+            if (hh < 1 || ww < 4) return fail(h, NWW_ERR_INVALID, "e2e_dnn input too small for AdaptiveAvgPool2d((1,4))");
+            // AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form (_export/onnx.py:146-152)
+            const int sh = hh / 1, kh = hh, sw = ww / 4, kw = ww - 3 * sw;
+            p.need(1, 256);
+            p.add("avgpool:export(1,4)", [=](Run& r) { return launch_avgpool(r.buf[0], r.buf[1], r.B * 64, hh, ww, kh, kw, sh, sw, 1, 4, r.stream); });
+            add_gemm(p, "fc1+bn1", 1, 0, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
+            add_gemm(p, "out", 0, -2, 1, E, 128, p.W("model.out.weight"), p.W("model.out.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287
+            int cin = 1, hh = T, ww = F, cur = -1;
+            for (int i = 0; i < c.n_crnn_channels; ++i) {
+                const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
+                const int out = (i % 2 == 0) ? 0 : 1;
+                add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
+                hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
+            }
+            if (hh < 1 || ww < 1) return fail(h, NWW_ERR_INVALID, "crnn input too small for the conv stack");
+            const int seq = cur ^ 1, C = cin, Hc = hh, Wc = ww;
+            p.need(seq, (size_t)C * Hc * Wc);
+            p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
+            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, cur, 3, 4);
+            add_gemm(p, "fc", 4, -2, 1, E, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_GRU: {                      // GRUModel: architectures.py:129-145
+            add_bigru_last(p, "model.gru", -1, T, F, L, nb, 2, 0, 1, 4);
+            add_gemm(p, "fc", 4, -2, 1, E, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_BCRESNET: {                 // BcResNetModel: architectures.py:620-687
+            add_conv(p, "init_conv", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1);
+            int hh = T / 2, ww = F / 2, cur = 0;
+            const int ch[4] = {32, 64, 128, 256};
+            const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};
+            for (int i = 1; i <= 3; ++i) {
+                const std::string q = "model.block" + std::to_string(i);
+                const int ci = ch[i - 1], co = ch[i], sh = st[i - 1][0], sw = st[i - 1][1];
+                const int ho = (hh - 1) / sh + 1, wo = (ww - 1) / sw + 1;
+                const int resb = 2, dwb = 3, outb = cur ^ 1;
+                p.need(resb, (size_t)co * ho * wo); p.need(dwb, (size_t)ci * ho * wo); p.need(outb, (size_t)co * ho * wo);
+                const float *scw = p.W(q + ".shortcut.0.weight"), *sca = p.W(q + ".shortcut.1.alpha"), *scb = p.W(q + ".shortcut.1.beta");
+                const float *dww = p.W(q + ".depthwise.weight"), *pww = p.W(q + ".pointwise.weight");
+                const float *ba = p.W(q + ".bn1.alpha"), *bb = p.W(q + ".bn1.beta");
+                const int hin = hh, win = ww;
+                p.add("pwconv:" + q + ".shortcut", [=](Run& r) {
+                    PwArgs a{r.buf[cur], scw, sca, scb, nullptr, r.buf[resb], r.B, ci, co, hin, win, sh, sw, ACT_NONE};
+                    return launch_pwconv(a, r.stream);
+                });
+                p.add("dwconv3x3:" + q, [=](Run& r) { return launch_dwconv3x3(r.buf[cur], dww, r.buf[dwb], r.B, ci, hin, win, sh, sw, r.stream); });
+                p.add("pwconv:" + q + ".pointwise+bn+act+res", [=](Run& r) {
+                    PwArgs a{r.buf[dwb], pww, ba, bb, r.buf[resb], r.buf[outb], r.B, ci, co, ho, wo, 1, 1, act};
+                    return launch_pwconv(a, r.stream);
+                });
+                hh = ho; ww = wo; cur = outb;
+            }
+            const int hw = hh * ww;
+            p.need(2, 256);
+            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_last(r.buf[cur], r.buf[2], r.B * 256, hw, r.stream); });
+            add_gemm(p, "fc", 2, -2, 1, E, 256, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            break;
+        }
+        case NWW_HEAD_CONFORMER: {                // ConformerModel: architectures.py:441-543
+            const int D = c.conformer_d_model, NH = c.conformer_n_head;
+            const int hb = 0, t1 = 1, t3 = 2, big = 3;      // h, LN/glu/attn scratch, dwconv scratch, wide scratch
+            p.need(t1, (size_t)T * D); p.need(t3, (size_t)T * D);
+            add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
+            for (int i = 0; i < nb; ++i) {
+                const std::string q = "model.conformer_blocks." + std::to_string(i);
+                auto ffn = [&](const std::string& ff) {
+                    const float *lw = p.W(q + ff + ".layer_norm.weight"), *lb = p.W(q + ff + ".layer_norm.bias");
+                    p.add("layernorm:" + q + ff, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                    add_gemm(p, q + ff + ".linear1+swish", t1, big, T, 4 * D, D, p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"), ACT_SILU);
+                    add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
+                };
+                ffn(".ff1");
+                add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
+                p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
+                add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                {
+                    const std::string m = q + ".conv_module";
+                    const float *lw = p.W(m + ".layer_norm.weight"), *lb = p.W(m + ".layer_norm.bias");
+                    p.add("layernorm:" + m, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                    add_gemm(p, m + ".conv1(pw)", t1, big, T, 2 * D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), ACT_NONE);
+                    p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
+                    const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
+                    const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
+                    p.add("dwconv1d+bn+swish:" + m, [=](Run& r) { return launch_dwconv1d_bn_swish(r.buf[t1], dw, db, ba, bb, r.buf[t3], r.B, T, D, 31, r.stream); });
+                    add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                }
+                ffn(".ff2");
+                const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
+                p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[hb], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+            }
+            p.add("mean:time", [=](Run& r) { return launch_mean_mid(r.buf[hb], r.buf[t1], r.B, T, D, r.stream); });
+            add_gemm(p, "output_proj", t1, -2, 1, E, D, p.W("model.output_proj.weight"), p.W("model.output_proj.bias"), ACT_NONE);
+            break;
+        }
+    }
+    // Model.classifier (model.py:291-296) -> logits [B]
+    add_gemm(p, "classifier.0", -2, -3, 1, E / 2, E, p.W("classifier.0.weight"), p.W("classifier.0.bias"), act);
+    add_gemm(p, "classifier.3", -3, -4, 1, 1, E / 2, p.W("classifier.3.weight"), p.W("classifier.3.bias"), ACT_NONE);
+    h->finalized = true;
+    return NWW_OK;
+}
+
+extern "C" int32_t nww_num_frames(const nww_handle* h, int32_t n) { return h ? fe_num_frames(h->fe, n) : -1; }
+
+extern "C" int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen) {
+    if (!h || !buf || buflen <= 0) return NWW_ERR_INVALID;
+    std::string s = "frontend:fe_stft_mel_db_kernel\n";
+    for (const auto& st : h->plan) s += st.name + "\n";
+    s += "unary:sigmoid\n";
+    std::snprintf(buf, (size_t)buflen, "%s", s.c_str());
+    return NWW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ workspace / run
+static int ensure_ws(nww_handle* h, int B, int N) {
+    if (B <= h->cap_B && N <= h->cap_N) return NWW_OK;
+    const int nB = B > h->cap_B ? B : h->cap_B, nN = N > h->cap_N ? N : h->cap_N;
+    HIP_TRY(h, hipDeviceSynchronize());
+    free_ws(h);
+    const nww_config& c = h->cfg;
+    size_t per = 0;
+    for (int i = 0; i < 6; ++i) per += (h->buf_per_clip[i] + 3) & ~(size_t)3;
+    HIP_TRY(h, hipMalloc(&h->d_ws, (per * nB + 4) * sizeof(float)));
+    const int T = nN > 0 ? fe_num_frames(h->fe, nN) : 0;
+    if (nN > 0) {
+        HIP_TRY(h, hipMalloc(&h->d_pcm, (size_t)nB * nN * sizeof(int16_t) + 16));
+        if (T > 0) HIP_TRY(h, hipMalloc(&h->d_logmel, (size_t)nB * T * c.n_mels * sizeof(float) + 16));
+    }
+    HIP_TRY(h, hipMalloc(&h->d_feats, (size_t)nB * c.in_rows * c.in_cols * sizeof(float) + 16));
+    HIP_TRY(h, hipMalloc(&h->d_emb, (size_t)nB * c.embedding_dim * sizeof(float) + 16));
+    HIP_TRY(h, hipMalloc(&h->d_hid, (size_t)nB * (c.embedding_dim / 2) * sizeof(float) + 16));
+    HIP_TRY(h, hipMalloc(&h->d_logits, (size_t)nB * sizeof(float) + 16));
+    HIP_TRY(h, hipMalloc(&h->d_probs, (size_t)nB * sizeof(float) + 16));
+    h->cap_B = nB; h->cap_N = nN;
+    return NWW_OK;
+}
+
+extern "C" int nww_reserve(nww_handle* h, int32_t B, int32_t N) {
+    if (!h || B <= 0 || N < 0) return fail(h, NWW_ERR_INVALID, "nww_reserve: bad arguments");
+    if (!h->finalized) return fail(h, NWW_ERR_STATE, "nww_reserve before nww_finalize");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return ensure_ws(h, B, N);
+}
+
+static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s) {
+    Run r;
+    r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
+    size_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+        r.buf[i] = h->d_ws + off;
+        off += ((h->buf_per_clip[i] + 3) & ~(size_t)3) * (size_t)h->cap_B;
+    }
+    for (auto& st : h->plan) {
+        hipError_t e = st.fn(r);
+        if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch '%s' failed: %s", st.name.c_str(), hipGetErrorString(e));
+    }
+    if (d_probs) {
+        hipError_t e = launch_unary(r.logits, d_probs, (size_t)B, ACT_SIGMOID, s);
+        if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch 'sigmoid' failed: %s", hipGetErrorString(e));
+    }
+    return NWW_OK;
+}
+
+static int check_run(nww_handle* h, int B) {
+    if (!h) return NWW_ERR_INVALID;
+    if (!h->finalized) return fail(h, NWW_ERR_STATE, "model not finalized: call nww_finalize after loading the state_dict");
+    if (B <= 0) return fail(h, NWW_ERR_INVALID, "batch must be positive (got %d)", B);
+    return NWW_OK;
+}
+
+static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_db, float* d_mel, int frames_major,
+                        hipStream_t s, int* frames_out) {
+    const int T = fe_num_frames(h->fe, N);
+    if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
+    if (frames_out) *frames_out = T;
+    hipError_t e = fe_launch(d_pcm, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, 16, 256, h->cu_count * 3, s);
+    if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
+    return NWW_OK;
+}
+
+extern "C" int nww_frontend_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_logmel,
+                                int32_t frames_major, void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_pcm || !d_logmel) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return frontend_dev(h, d_pcm, B, N, d_logmel, nullptr, frames_major, stream ? (hipStream_t)stream : h->own_stream, nullptr);
+}
+
+static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s) {
+    const nww_config& c = h->cfg;
+    const int T = fe_num_frames(h->fe, N);
+    if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
+    const int rows = c.mel_major_features ? c.n_mels : T, cols = c.mel_major_features ? T : c.n_mels;
+    if (rows != c.in_rows || cols != c.in_cols)
+        return fail(h, NWW_ERR_SHAPE, "frontend yields (%d,%d) features for %d samples but the head was built for input_shape=(%d,%d)",
+                    rows, cols, N, c.in_rows, c.in_cols);
+    int rc = ensure_ws(h, B, N);
+    if (rc) return rc;
+    rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr);
+    if (rc) return rc;
+    return run_head(h, h->d_logmel, B, d_logits, d_probs, s);
+}
+
+extern "C" int nww_forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_logits,
+                                   float* d_probs, void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_pcm) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return forward_pcm_dev(h, d_pcm, B, N, d_logits, d_probs, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+extern "C" int nww_forward_features_dev(nww_handle* h, const float* d_feats, int32_t B, float* d_logits, float* d_probs,
+                                        void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_feats) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    rc = ensure_ws(h, B, 0);
+    if (rc) return rc;
+    return run_head(h, d_feats, B, d_logits, d_probs, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+// ---- host-pointer entry points
+extern "C" int nww_frontend_ex(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N, float* logmel_out,
+                               float* melpower_out, int32_t* frames_out) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!pcm) return fail(h, NWW_ERR_INVALID, "Input audio must be a non-null int16 array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int T = fe_num_frames(h->fe, N);
+    if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
+    rc = ensure_ws(h, B, N);
+    if (rc) return rc;
+    hipStream_t s = h->own_stream;
+    const size_t n_out = (size_t)B * T * h->cfg.n_mels;
+    float* d_mel = nullptr;
+    if (melpower_out) HIP_TRY(h, hipMalloc(&d_mel, n_out * sizeof(float)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    rc = frontend_dev(h, h->d_pcm, B, N, h->d_logmel, d_mel, 0, s, frames_out);
+    if (rc) { if (d_mel) (void)hipFree(d_mel); return rc; }
+    if (logmel_out) HIP_TRY(h, hipMemcpyAsync(logmel_out, h->d_logmel, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (melpower_out) HIP_TRY(h, hipMemcpyAsync(melpower_out, d_mel, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (d_mel) (void)hipFree(d_mel);
+    return NWW_OK;
+}
+
+extern "C" int nww_frontend(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N, float* logmel_out, int32_t* frames_out) {
+    return nww_frontend_ex(h, pcm, B, N, logmel_out, nullptr, frames_out);
+}
+
+static int copy_out(nww_handle* h, int B, float* logits, float* probs, float* emb, hipStream_t s) {
+    if (logits) HIP_TRY(h, hipMemcpyAsync(logits, h->d_logits, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (probs) HIP_TRY(h, hipMemcpyAsync(probs, h->d_probs, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (emb) HIP_TRY(h, hipMemcpyAsync(emb, h->d_emb, (size_t)B * h->cfg.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return NWW_OK;
+}
+
+extern "C" int nww_forward_pcm(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N, float* logits, float* probs) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!pcm) return fail(h, NWW_ERR_INVALID, "Input audio must be a non-null int16 array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    rc = ensure_ws(h, B, N);
+    if (rc) return rc;
+    hipStream_t s = h->own_stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    rc = forward_pcm_dev(h, h->d_pcm, B, N, h->d_logits, h->d_probs, s);
+    if (rc) return rc;
+    return copy_out(h, B, logits, probs, nullptr, s);
+}
+
+extern "C" int nww_forward_features_ex(nww_handle* h, const float* feats, int32_t B, float* logits, float* probs, float* emb) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!feats) return fail(h, NWW_ERR_INVALID, "null feature pointer");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    rc = ensure_ws(h, B, 0);
+    if (rc) return rc;
+    hipStream_t s = h->own_stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_feats, feats, (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = run_head(h, h->d_feats, B, h->d_logits, h->d_probs, s);
+    if (rc) return rc;
+    return copy_out(h, B, logits, probs, emb, s);
+}
+
+extern "C" int nww_forward_features(nww_handle* h, const float* feats, int32_t B, float* logits, float* probs) {
+    return nww_forward_features_ex(h, feats, B, logits, probs, nullptr);
+}

@@ -1,0 +1,185 @@
+"""HIP path vs the oracle and the reference-generated goldens, through the C-ABI (run with -m gpu)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import head_case_names
+from nanowakeword_amd.config import FrontendConfig, HeadConfig
+from nanowakeword_amd.synth import synth_features, synth_pcm, synth_state_dict
+from parity import assert_frontend_close, frontend_errors, logit_bounds
+
+pytestmark = pytest.mark.gpu
+
+FEAT_LOGIT_ATOL = 1e-4        # north_star: logits within 1e-4 (float32)
+FEAT_EMB_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nanowakeword_amd.session import HipModel, HipSession
+    return HipModel, HipSession
+
+
+def _fe_cfg(n_mels, center):
+    return FrontendConfig(n_mels=n_mels, center=center)
+
+
+def _model(hip, cfg, fe, g, n_mels):
+    HipModel, _ = hip
+    fb = g["fb64"] if n_mels == 64 else g["fb40"]
+    return HipModel(cfg, fe, state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=fb)
+
+
+@pytest.mark.parametrize("variant", ["64c", "40n"])
+def test_frontend_vs_reference_golden(hip, golden_frontend, variant):
+    g = golden_frontend
+    n_mels, center = (64, True) if variant == "64c" else (40, False)
+    cfg = HeadConfig("dnn", (101, 64) if center else (98, 40))
+    m = _model(hip, cfg, _fe_cfg(n_mels, center), g, n_mels)
+    db, mel = m.frontend(g["pcm"], return_power=True)
+    mel_ref, db_ref = (g["mel64"], g["db64"]) if center else (g["mel40"], g["db40"])
+    assert db.shape == db_ref.shape                      # frame count bit-exact
+    e_db, e_mel, frac = assert_frontend_close(mel, db, mel_ref, db_ref, variant)
+    print(f"frontend {variant}: max dB err {e_db:.2e} (well-conditioned {frac:.0%} of bins), mel err {e_mel:.2e} x frame peak")
+    # and against the oracle (same tables)
+    mo = oracle.mel_power(g["pcm"], g["window"], g["fb64"] if center else g["fb40"], center=center)
+    assert_frontend_close(mel, db, mo, oracle.logmel_db(mo), variant + "/oracle")
+    m.close()
+
+
+def test_frame_law_and_edges(hip, golden_frontend):
+    g = golden_frontend
+    mc = _model(hip, HeadConfig("dnn", (101, 64)), _fe_cfg(64, True), g, 64)
+    mn = _model(hip, HeadConfig("dnn", (98, 40)), _fe_cfg(40, False), g, 40)
+    for n, fc, fn in zip(g["edge_n"], g["edge_frames_center"], g["edge_frames_nocenter"]):
+        assert mc.num_frames(int(n)) == int(fc) and mn.num_frames(int(n)) == int(fn)
+        x = synth_pcm("noise", 2, int(n), seed=77)
+        assert mc.frontend(x).shape == (2, 64, int(fc))
+        assert mn.frontend(x).shape == (2, 40, int(fn))
+    db = mc.frontend(g["short_pcm"])
+    assert np.abs(db - g["short_db64"]).max() <= 1e-4
+    with pytest.raises(ValueError):
+        mn.frontend(np.zeros((1, 399), np.int16))       # shorter than n_fft
+    with pytest.raises(ValueError):
+        mc.frontend(np.zeros((1, 200), np.int16))       # reflect pad needs N > n_fft/2
+    with pytest.raises(ValueError):
+        mc.frontend([1, 2, 3])                          # non-ndarray (nanointerpreter.py:628-629)
+    # odd length / misaligned clips take the 2-byte staging path: compare with oracle
+    x = synth_pcm("noise", 3, 16001, seed=3)
+    db, mel = mc.frontend(x, return_power=True)
+    mo = oracle.mel_power(x, g["window"], g["fb64"])
+    assert_frontend_close(mel, db, mo, oracle.logmel_db(mo), "odd-length")
+    mc.close(); mn.close()
+
+
+def test_frontend_linearity_and_builtin_tables(hip):
+    """Size-independent properties at full batch: |X|^2 scales with gain^2 (6.0206 dB per doubling),
+    and the library's built-in double-precision tables stay within their documented 1e-3 dB of
+    the torchaudio-float32 tables."""
+    HipModel, _ = hip
+    cfg = HeadConfig("dnn", (101, 64))
+    m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
+    x = synth_pcm("noise", 256, 16000, seed=11) // 4
+    a = m.frontend(x)
+    b = m.frontend((x * 2).astype(np.int16))
+    assert np.abs((b - a) - 20 * np.log10(2.0)).max() <= 2e-4
+    m2 = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg), tables="builtin")
+    c = m2.frontend(x)
+    assert np.abs(c - a).max() <= 2e-3
+    m.close(); m2.close()
+
+
+@pytest.mark.parametrize("name", head_case_names())
+def test_head_vs_oracle_and_golden(hip, golden_heads, golden_frontend, name):
+    d, meta = golden_heads
+    g = golden_frontend
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    n_mels = 40 if cfg.input_shape == (98, 40) else 64
+    center = n_mels == 64
+    m = _model(hip, cfg, _fe_cfg(n_mels, center), g, n_mels)
+    # (i) features -> logits / embedding, vs reference golden and oracle
+    feats = synth_features(4, cfg.input_shape)
+    logits, probs, emb = m.forward_features(feats, return_embedding=True)
+    ref = d[f"{name}/logits_feat"].ravel()
+    assert np.abs(logits - ref).max() <= FEAT_LOGIT_ATOL, (name, np.abs(logits - ref).max())
+    assert np.abs(probs - oracle.sigmoid(ref)).max() <= 1e-5
+    e_or = oracle.head_forward(feats, sd, cfg)
+    assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max()), np.abs(emb - e_or).max()
+    # ragged batch sizes (tile edges of the MFMA kernels): 1, 33, 70 clips
+    for B in (1, 33, 70):
+        fx = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(fx)
+        lo = oracle.model_forward(fx, sd, cfg).ravel()
+        assert np.abs(lg - lo).max() <= FEAT_LOGIT_ATOL, (name, B, np.abs(lg - lo).max())
+    # (ii) PCM -> logits through the fused frontend, vs the reference composite
+    if f"{name}/logits_pcm" in d:
+        rp = d[f"{name}/logits_pcm"].ravel()
+        lp, pp = m.forward_pcm(g["pcm"])
+        fb = g["fb64"] if n_mels == 64 else g["fb40"]
+        lm32 = oracle.frontend_logmel(g["pcm"], g["window"], fb, center=center)
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], fb, center=center, dtype=np.float64).astype(np.float32)
+        if cfg.model_type != "e2e_dnn":
+            lm32, lm64 = lm32.transpose(0, 2, 1), lm64.transpose(0, 2, 1)
+        l32 = oracle.model_forward(np.ascontiguousarray(lm32), sd, cfg).ravel()
+        lx = oracle.model_forward(np.ascontiguousarray(lm64), sd, cfg).ravel()
+        bound = logit_bounds(g["names"], rp, l32, lx)
+        err = np.abs(lp - rp)
+        assert np.all(err <= bound), (name, err, bound)
+        print(f"{name}: max |dlogit| vs reference = {err.max():.2e} (broadband/speech clips: "
+              f"{err[[i for i, n in enumerate(g['names']) if not str(n).startswith(('sine', 'chirp'))]].max():.2e})")
+        assert np.abs(pp - oracle.sigmoid(lp)).max() <= 1e-6
+    m.close()
+
+
+def test_session_protocol_and_errors(hip, golden_frontend):
+    HipModel, HipSession = hip
+    g = golden_frontend
+    cfg = HeadConfig("e2e_dnn", (64, 101))
+    m = _model(hip, cfg, _fe_cfg(64, True), g, 64)
+    s = HipSession(m, mode="e2e", clip_samples=16000, input_ndim=3)
+    inp = s.get_inputs()[0]
+    assert inp.name == "input" and inp.shape == [None, 1, 16000]
+    clip = (g["pcm"][:3].astype(np.float32) / 32768.0).reshape(3, 1, -1)       # nanointerpreter.py:750,773
+    out = s.run(None, {"input": clip})
+    assert isinstance(out, list) and out[0].shape == (3, 1, 1) and out[0].dtype == np.float32
+    lg, pr = m.forward_pcm(g["pcm"][:3])
+    assert np.array_equal(out[0].ravel(), pr)                                  # float and int16 inputs agree bit-for-bit
+    assert float(out[0][0].item()) == float(pr[0])                             # .item() as the interpreter calls it (:784)
+    with pytest.raises(ValueError):
+        s.run(None, {"input": clip * 0.3333})                                  # not int16-representable
+    with pytest.raises(ValueError):
+        m.forward_features(np.zeros((2, 5, 5), np.float32))
+    # state errors
+    m2 = HipModel(cfg, _fe_cfg(64, True))
+    with pytest.raises(KeyError):
+        m2.finalize()                                                          # missing state_dict keys
+    with pytest.raises(ValueError):
+        m2._load("model.fc1.weight", np.zeros((3, 3), np.float32))             # size mismatch
+    with pytest.raises(KeyError):
+        m2.load_state_dict({"bogus.weight": np.zeros(3, np.float32)})
+    m.close(); m2.close()
+    with pytest.raises(ValueError):
+        HipModel(HeadConfig("dnn", (16, 96)), FrontendConfig(n_mels=500))
+
+
+def test_batch_invariance_full_size(hip, golden_frontend):
+    """At BASELINE size (B=4096) the oracle is too slow to run everywhere; use properties instead:
+    per-clip results do not depend on batch size or position in the batch (bit-exact), and the
+    first clips equal the small-batch run that IS checked against the oracle."""
+    g = golden_frontend
+    cfg = HeadConfig("cnn", (101, 64))
+    m = _model(hip, cfg, _fe_cfg(64, True), g, 64)
+    x = synth_pcm("noise", 4096, 16000)
+    lg, pr = m.forward_pcm(x)
+    assert np.isfinite(lg).all()
+    l16, _ = m.forward_pcm(x[:16])
+    assert np.array_equal(lg[:16], l16)
+    perm = np.random.default_rng(0).permutation(4096)
+    lp, _ = m.forward_pcm(np.ascontiguousarray(x[perm]))
+    assert np.array_equal(lp, lg[perm])
+    sd = synth_state_dict(cfg)
+    lm = oracle.frontend_logmel(x[:8], g["window"], g["fb64"]).transpose(0, 2, 1)
+    lo = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+    assert np.abs(lg[:8] - lo).max() <= 1e-4
+    m.close()

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py - headline metric of BASELINE.json on MI355X: clips/s, 1 s @ 16 kHz int16 PCM -> logit.
+
+Workload (configs[1]): CNN head (CNNModel on (101,64) log-mel), batch 4096 clips per GPU, fused
+STFT+mel HIP frontend, float32.  A "step" = one pass of the hot path over one resident batch:
+frontend kernel -> conv1 -> conv2 -> fc1 -> fc2 -> classifier -> logits (+ for N>1 one RCCL
+all-gather of the per-clip logits, the path's only exchange).  Weak scaling: every rank holds its
+own 4096 clips.  PCM is resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract fields + "roofline" for the dominant kernel, measured
+with HIP events on the launch stream inside the timed region, + "cpu_baseline": the numpy oracle
+of the same workload timed on the host cores; kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+PEAK_F32_TFLOPS = 157.3        # dense f32 peak, MFMA f32 == vector rate (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
+    ap.add_argument("--head", default="cnn")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, window, fb, seconds):
+    """The oracle (numpy/BLAS restatement of the reference path) on the host cores: PCM -> logits.
+    Timed twice: all-core BLAS (capped at 32 threads; the reference's batch path uses 0.6 x cores,
+    transform_clips.py:441) -> "value"; and 1 thread (the reference interpreter's setting,
+    nanointerpreter.py:955-959) -> "value_1thread"."""
+    import oracle                                  # checker/baseline only, never on the product path
+    from threadpoolctl import threadpool_limits
+    from nanowakeword_amd.synth import synth_pcm
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(32, ncpu))
+    chunk = 64
+    pcm = synth_pcm("noise", chunk, 16000, seed=123)
+
+    def one():
+        lm = oracle.frontend_logmel(pcm, window, fb).transpose(0, 2, 1)
+        return oracle.model_forward(np.ascontiguousarray(lm), sd, cfg)
+
+    def timed(nthreads, budget):
+        with threadpool_limits(limits=nthreads):
+            one()                                  # warm-up (BLAS threads, page-in)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                one()
+                n += chunk
+                dt = time.perf_counter() - t0
+                if dt >= budget:
+                    return n, dt
+    n, dt = timed(threads, seconds * 0.6)
+    n1, dt1 = timed(1, seconds * 0.4)
+    return {"value": round(n / dt, 1), "unit": "clips/s", "cores": int(threads), "kind": "port",
+            "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu),
+            "sample": f"{n} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
+                      f"dense-DFT frontend + {cfg.model_type} head) in {dt:.1f} s on {threads} BLAS threads; "
+                      f"{n1} clips in {dt1:.1f} s on 1 thread"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from nanowakeword_amd.config import FrontendConfig, HeadConfig, head_macs
+    from nanowakeword_amd.session import HipModel, torchaudio_tables
+    from nanowakeword_amd.synth import synth_pcm, synth_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    fe = FrontendConfig()                                  # 16 kHz, 400/400/160, 64 mel, center
+    shape = (64, 101) if a.head == "e2e_dnn" else (101, 64)
+    cfg = HeadConfig(a.head, shape)
+    sd = synth_state_dict(cfg)
+    window, fb = torchaudio_tables(fe)
+    model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb)
+    B, N = a.batch, 16000
+    pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
+    pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
+    logits = torch.empty(B, dtype=torch.float32, device=dev)
+    gathered = torch.empty(B * world, dtype=torch.float32, device=dev) if world > 1 else None
+    model.reserve(B, N)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        model.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, logits)   # RCCL over xGMI: 4 B per clip
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    model.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = model.get_profile()
+    model.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- correctness guard on the timed buffers (cheap): finite, and first clips == small-batch run
+    lg = logits.cpu().numpy()
+    assert np.isfinite(lg).all()
+    l8, _ = model.forward_pcm(pcm_host[:8])
+    assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = B * world * a.steps / dt
+        # ---- roofline of the dominant kernel (largest share of device time in the timed region)
+        per = [(n, ms / max(c, 1), c, ms) for (n, ms, c) in prof if c > 0]
+        dom = max(per, key=lambda r: r[3])
+        kernel_ms = {n: round(avg, 4) for (n, avg, c, tot) in per}
+        T, n_mels = 101, fe.n_mels
+        algo = {   # algorithmic work per LAUNCH (B clips): DESIGN.md "Kernels"
+            "frontend:fe_stft_mel_db_kernel": ("hbm", B * (2 * N + 4 * n_mels * T) / 1e9, "GB/s", PEAK_HBM_GBS),
+        }
+        if cfg.model_type == "cnn":
+            H1, W1 = T // 2, n_mels // 2
+            algo["conv3x3:conv1"] = ("mfma", B * 2 * 9 * 1 * 16 * (2 * H1) * (2 * W1) / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
+            algo["conv3x3:conv2"] = ("mfma", B * 2 * 9 * 16 * 32 * (2 * (H1 // 2)) * (2 * (W1 // 2)) / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
+            algo["gemm:fc1"] = ("mfma", B * 2 * 32 * (T // 4) * (n_mels // 4) * 128 / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
+        name = dom[0]
+        if name in algo:
+            bound, work, unit, peak = algo[name]
+            achieved = work / (dom[1] * 1e-3)
+        else:
+            bound, unit, peak = "mfma", "TFLOP/s", PEAK_F32_TFLOPS
+            achieved = B * 2 * head_macs(cfg) / 1e12 / (sum(r[1] for r in per if not r[0].startswith("frontend")) * 1e-3)
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                ent = tj.get(name)
+                if ent and ent.get("batch") == B:
+                    traffic = ent["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        roofline = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(dom[1], 4),
+                    "launches": dom[2]}
+        fe_row = [r for r in per if r[0].startswith("frontend")]
+        extra = {}
+        if fe_row:
+            fe_gbs = B * (2 * N + 4 * n_mels * T) / 1e9 / (fe_row[0][1] * 1e-3)
+            extra["stft_stage"] = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(fe_gbs / PEAK_HBM_GBS, 4),
+                                   "f32_tflops": round(B * 1.27e6 / 1e12 / (fe_row[0][1] * 1e-3), 2),
+                                   "clips_per_s_stage": round(B / (fe_row[0][1] * 1e-3), 0)}
+        out = {
+            "metric": "clips/sec (1 s @16 kHz PCM->logits)", "value": round(value, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.model_type} head on (101,64) log-mel, batch={B}/GPU, 1 s 16 kHz mono int16 "
+                                   "clips, 64-mel 25 ms/10 ms center frontend, fused STFT+mel HIP kernel, fp32",
+                       "clips_per_gpu": B, "n_samples": N, "parallelism": f"batch-split x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
+            "roofline": roofline,
+            "kernel_ms": kernel_ms,
+        }
+        out.update(extra)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, window, fb, a.cpu_seconds)
+        print(json.dumps(out))
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,9 +129,15 @@ int nww_forward_features_dev(nww_handle* h, const float* d_feats, int32_t B,
  * which synchronises the device).                                                           */
 int nww_reserve(nww_handle* h, int32_t B, int32_t N);
 
-/* Per-stage timing of the last *_dev/_host call is not kept; instead, profile hooks:        */
-/* names of the kernels a forward_pcm launches, in order (for rocprof correlation).           */
+/* Names of the launches a forward_pcm performs, in order, one per line (rocprof correlation).  */
 int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen);
+/* Per-launch timing with HIP events ON THE STREAM THE KERNELS RUN ON.  While enabled, every
+ * forward records one event per launch boundary (frontend, each head launch, sigmoid).
+ * nww_get_profile synchronises those events and returns, per plan entry (same order as
+ * nww_describe_plan), the accumulated milliseconds and the number of launches since the last
+ * nww_set_profiling(h, 1).  n_inout: capacity in, entries out.                                */
+int nww_set_profiling(nww_handle* h, int32_t enable);
+int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches, int32_t* n_inout);
 
 const char* nww_version(void);
 

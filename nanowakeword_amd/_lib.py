@@ -36,7 +36,8 @@ SYMBOLS = [
     "nww_default_config", "nww_create", "nww_destroy", "nww_last_error", "nww_load_tensor", "nww_num_tensors",
     "nww_tensor_info", "nww_finalize", "nww_num_frames", "nww_frontend", "nww_frontend_ex", "nww_forward_pcm",
     "nww_forward_features", "nww_forward_features_ex", "nww_frontend_dev", "nww_forward_pcm_dev",
-    "nww_forward_features_dev", "nww_reserve", "nww_describe_plan", "nww_version",
+    "nww_forward_features_dev", "nww_reserve", "nww_describe_plan", "nww_set_profiling", "nww_get_profile",
+    "nww_version",
 ]
 
 
@@ -74,6 +75,8 @@ def load_library():
     lib.nww_forward_features_dev.argtypes = [vp, vp, i32, vp, vp, vp]; lib.nww_forward_features_dev.restype = C.c_int
     lib.nww_reserve.argtypes = [vp, i32, i32]; lib.nww_reserve.restype = C.c_int
     lib.nww_describe_plan.argtypes = [vp, C.c_char_p, i32]; lib.nww_describe_plan.restype = C.c_int
+    lib.nww_set_profiling.argtypes = [vp, i32]; lib.nww_set_profiling.restype = C.c_int
+    lib.nww_get_profile.argtypes = [vp, f32p, C.POINTER(i32), C.POINTER(i32)]; lib.nww_get_profile.restype = C.c_int
     lib.nww_version.argtypes = []; lib.nww_version.restype = C.c_char_p
     _lib = lib
     return lib

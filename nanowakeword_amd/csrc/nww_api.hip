@@ -63,7 +63,34 @@ struct nww_handle {
     float* d_logits = nullptr;
     float* d_probs = nullptr;
     int cu_count = 256;
+    // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
+    bool profiling = false;
+    std::vector<std::vector<hipEvent_t>> prof_runs;   // one event list per recorded forward
+    std::vector<std::vector<int>> prof_ids;           // plan-entry id of each interval
+    std::vector<hipEvent_t> event_pool;
+    std::vector<double> prof_ms;                      // size plan+2 : [0]=frontend, [1..n]=plan, [n+1]=sigmoid
+    std::vector<int> prof_cnt;
 };
+
+static hipEvent_t prof_event(nww_handle* h) {
+    hipEvent_t e = nullptr;
+    if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static void prof_mark(nww_handle* h, hipStream_t s, int id_of_next) {
+    if (!h->profiling) return;
+    hipEvent_t e = prof_event(h);
+    if (!e) return;
+    (void)hipEventRecord(e, s);
+    h->prof_runs.back().push_back(e);
+    h->prof_ids.back().push_back(id_of_next);         // interval that STARTS at this event (-1 = end)
+}
+static void prof_begin(nww_handle* h) {
+    if (!h->profiling) return;
+    h->prof_runs.emplace_back();
+    h->prof_ids.emplace_back();
+}
 
 static std::string g_create_err;
 
@@ -272,6 +299,8 @@ extern "C" int nww_destroy(nww_handle* h) {
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    for (auto& run : h->prof_runs) for (auto e : run) (void)hipEventDestroy(e);
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
     return NWW_OK;
 }
@@ -602,6 +631,39 @@ extern "C" int nww_finalize(nww_handle* h) {
 
 extern "C" int32_t nww_num_frames(const nww_handle* h, int32_t n) { return h ? fe_num_frames(h->fe, n) : -1; }
 
+extern "C" int nww_set_profiling(nww_handle* h, int32_t enable) {
+    if (!h) return NWW_ERR_INVALID;
+    for (auto& run : h->prof_runs) for (auto e : run) h->event_pool.push_back(e);
+    h->prof_runs.clear(); h->prof_ids.clear();
+    h->prof_ms.assign(h->plan.size() + 2, 0.0);
+    h->prof_cnt.assign(h->plan.size() + 2, 0);
+    h->profiling = enable != 0;
+    return NWW_OK;
+}
+
+extern "C" int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches, int32_t* n_inout) {
+    if (!h || !n_inout) return NWW_ERR_INVALID;
+    const int n = (int)h->plan.size() + 2;
+    if (*n_inout < n || !ms_total || !launches) { *n_inout = n; return fail(h, NWW_ERR_INVALID, "profile buffers too small (need %d)", n); }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if ((int)h->prof_ms.size() != n) { h->prof_ms.assign(n, 0.0); h->prof_cnt.assign(n, 0); }
+    for (size_t r = 0; r < h->prof_runs.size(); ++r) {
+        auto& ev = h->prof_runs[r];
+        auto& ids = h->prof_ids[r];
+        if (!ev.empty()) HIP_TRY(h, hipEventSynchronize(ev.back()));
+        for (size_t i = 0; i + 1 < ev.size(); ++i) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            if (ids[i] >= 0 && ids[i] < n) { h->prof_ms[ids[i]] += ms; h->prof_cnt[ids[i]] += 1; }
+        }
+        for (auto e : ev) h->event_pool.push_back(e);
+    }
+    h->prof_runs.clear(); h->prof_ids.clear();
+    for (int i = 0; i < n; ++i) { ms_total[i] = (float)h->prof_ms[i]; launches[i] = h->prof_cnt[i]; }
+    *n_inout = n;
+    return NWW_OK;
+}
+
 extern "C" int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen) {
     if (!h || !buf || buflen <= 0) return NWW_ERR_INVALID;
     std::string s = "frontend:fe_stft_mel_db_kernel\n";
@@ -650,14 +712,18 @@ static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, flo
         r.buf[i] = h->d_ws + off;
         off += ((h->buf_per_clip[i] + 3) & ~(size_t)3) * (size_t)h->cap_B;
     }
+    int id = 1;
     for (auto& st : h->plan) {
+        prof_mark(h, s, id++);
         hipError_t e = st.fn(r);
         if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch '%s' failed: %s", st.name.c_str(), hipGetErrorString(e));
     }
     if (d_probs) {
+        prof_mark(h, s, id);
         hipError_t e = launch_unary(r.logits, d_probs, (size_t)B, ACT_SIGMOID, s);
         if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch 'sigmoid' failed: %s", hipGetErrorString(e));
     }
+    prof_mark(h, s, -1);
     return NWW_OK;
 }
 
@@ -697,6 +763,8 @@ static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, fl
                     rows, cols, N, c.in_rows, c.in_cols);
     int rc = ensure_ws(h, B, N);
     if (rc) return rc;
+    prof_begin(h);
+    prof_mark(h, s, 0);
     rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr);
     if (rc) return rc;
     return run_head(h, h->d_logmel, B, d_logits, d_probs, s);
@@ -719,6 +787,7 @@ extern "C" int nww_forward_features_dev(nww_handle* h, const float* d_feats, int
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     rc = ensure_ws(h, B, 0);
     if (rc) return rc;
+    prof_begin(h);
     return run_head(h, d_feats, B, d_logits, d_probs, stream ? (hipStream_t)stream : h->own_stream);
 }
 
@@ -782,6 +851,7 @@ extern "C" int nww_forward_features_ex(nww_handle* h, const float* feats, int32_
     if (rc) return rc;
     hipStream_t s = h->own_stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_feats, feats, (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float), hipMemcpyHostToDevice, s));
+    prof_begin(h);
     rc = run_head(h, h->d_feats, B, h->d_logits, h->d_probs, s);
     if (rc) return rc;
     return copy_out(h, B, logits, probs, emb, s);

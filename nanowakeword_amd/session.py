@@ -38,7 +38,7 @@ def torchaudio_tables(fe: FrontendConfig):
     torch.hann_window(win_length) and torchaudio.functional.melscale_fbanks(norm=None,
     mel_scale="htk") - the tables T.MelSpectrogram carries at architectures.py:830-836.
     The C library's built-in tables evaluate the same formulas in double precision, which
-    differs from this float32 evaluation by up to 1e-5 per coefficient (6e-4 dB); use these
+    differs from this float32 evaluation by up to 1e-5 per coefficient (up to ~4e-3 dB on narrow low-frequency filters); use these
     (or the exported model's own buffers) when bit-level agreement with the reference matters."""
     import math
     import torch
@@ -213,6 +213,18 @@ class HipModel:
         self._check(self.lib.nww_forward_features_dev(self._h, C.c_void_p(feats_ptr), B, C.c_void_p(logits_ptr),
                                                       C.c_void_p(probs_ptr) if probs_ptr else None,
                                                       C.c_void_p(stream) if stream else None))
+
+    def set_profiling(self, enable: bool = True):
+        self._check(self.lib.nww_set_profiling(self._h, int(enable)))
+
+    def get_profile(self):
+        """[(launch name, total ms, launches)] accumulated since set_profiling(True); HIP events on the launch stream."""
+        names = self.describe_plan().strip().split("\n")
+        n = C.c_int32(len(names) + 8)
+        ms = (C.c_float * n.value)()
+        cnt = (C.c_int32 * n.value)()
+        self._check(self.lib.nww_get_profile(self._h, ms, cnt, C.byref(n)))
+        return [(names[i] if i < len(names) else f"#{i}", float(ms[i]), int(cnt[i])) for i in range(n.value)]
 
     def describe_plan(self) -> str:
         buf = C.create_string_buffer(16384)

@@ -105,10 +105,12 @@ def mel_power(pcm: np.ndarray, window: np.ndarray, mel_fb: np.ndarray, n_fft=400
     x = pcm.astype(np.float32) / np.float32(32768.0)
     real, imag = dft_bases(window, n_fft)
     frames = frame_signal(x, n_fft, hop, center).astype(dtype)          # [B,T,n_fft]
-    re = frames @ real.astype(dtype).T                                    # [B,T,bins]
-    im = frames @ imag.astype(dtype).T
+    B, T, _ = frames.shape
+    f2 = frames.reshape(B * T, n_fft)                                     # one contiguous GEMM per basis
+    re = f2 @ np.ascontiguousarray(real.astype(dtype).T)                  # [B*T,bins]
+    im = f2 @ np.ascontiguousarray(imag.astype(dtype).T)
     power = re * re + im * im
-    mel = power @ mel_fb.astype(dtype)                                    # [B,T,n_mels]
+    mel = (power @ mel_fb.astype(dtype)).reshape(B, T, -1)                # [B,T,n_mels]
     return np.ascontiguousarray(np.swapaxes(mel, 1, 2))
 
 

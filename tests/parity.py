@@ -15,7 +15,7 @@ see DESIGN.md "Conditioning") shape how 1e-4 is applied to the frontend:
 So: (A) |d dB| <= 1e-4 on bins >= 1e-4 x frame peak; (B) |d mel| <= 3e-6 x frame peak on ALL bins;
 and for PCM->logit, |d logit| <= 1e-4 on every broadband, silent and real-speech clip (observed
 <= 2e-5); the three synthetic tonal clips (sine x2, chirp), whose logits the reference itself
-only determines to ~1e-3, get 1e-4 + 4 x the measured float32 noise scale (logit_bounds).
+only determines to ~1e-3, get 1e-4 + 4 x the head's measured float32 noise scale on tonal input (logit_bounds).
 """
 import numpy as np
 
@@ -54,11 +54,14 @@ def is_tonal(names):
 
 
 def logit_bounds(names, logits_ref, logits_f32_other, logits_exact_frontend):
-    """Per-clip |d logit| bound: 1e-4 everywhere (north_star); tonal clips add 4x the float32
-    noise scale, estimated from two independent float32 evaluations (the reference and the
-    oracle) against the exact-arithmetic (float64) frontend feeding the same head."""
-    noise = np.maximum(np.abs(logits_ref - logits_exact_frontend), np.abs(logits_f32_other - logits_exact_frontend))
-    b = np.full(logits_ref.shape, LOGIT_ATOL, np.float64)
+    """Per-clip |d logit| bound: 1e-4 everywhere (north_star).  The tonal clips add 4x the head's
+    float32 noise scale on such inputs, measured as the largest deviation from the exact-arithmetic
+    (float64) frontend over all tonal clips and two independent float32 evaluations of the same
+    graph (the reference's dense DFT and the oracle's) - e.g. 7.7e-3 for BcResNet, 5e-4 for Conformer."""
     t = is_tonal(names)
-    b[t] += 4.0 * noise[t]
+    b = np.full(logits_ref.shape, LOGIT_ATOL, np.float64)
+    if t.any():
+        noise = max(np.abs(logits_ref - logits_exact_frontend)[t].max(),
+                    np.abs(logits_f32_other - logits_exact_frontend)[t].max())
+        b[t] += 4.0 * noise
     return b

@@ -256,7 +256,9 @@ class HipSession:
             raise NwwError("HipSession needs a finalized HipModel")
         self.model, self.mode, self.clip_samples, self.input_ndim = model, mode, int(clip_samples), int(input_ndim)
         self._model_filename = name + ".hip"
+        self.name = name
         self.metadata = {"mode": mode}
+        self.accepts_int16 = True       # HipInterpreter then skips the float32 round trip of nanointerpreter.py:750
         if mode == "e2e":
             T = model.num_frames(self.clip_samples)
             rows, cols = (model.fe.n_mels, T) if model.head.model_type == "e2e_dnn" else (T, model.fe.n_mels)

@@ -17,7 +17,12 @@ struct GemmArgs {
     const float* bias; const float* alpha; const float* beta;
     int act;
     const float* res; int ldres; float rscale;
+    // deterministic split-K: when splitk > 1, partial[z][M][N] go to splitk_ws and a second kernel adds them
+    // in z order before the epilogue (bit-reproducible, unlike atomics). 0/1 = off.
+    int splitk = 0; float* splitk_ws = nullptr;
 };
+// rows(M) x N x K -> recommended split (1 = none); workspace floats needed = split*M*N
+int gemm_recommended_splitk(long long M, int N, int K, int cu_count);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
 
 // 3x3 conv, stride 1, pad 1 on NCHW + bias + (alpha,beta) + act, optionally followed by MaxPool2d(2) (floor).

@@ -11,6 +11,7 @@
 // output channels, weights wave-uniform (scalar loads), so the FMA:load ratio is 36:1 (pooled 3x3).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "layers.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,8 +40,13 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int K = g.K;
+    int K = g.K;
     int k = 0;
+    if (g.splitk > 1) {                                        // this block's K range (multiples of 32)
+        const int kc = (((g.K + g.splitk - 1) / g.splitk) + 31) & ~31;
+        k = blockIdx.z * kc;
+        K = min(g.K, k + kc);
+    }
     for (; k + 32 <= K; k += 32) {
         float4 a[4], b[4];
 #pragma unroll
@@ -69,6 +75,15 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
     }
     const int n = n0 + i;
     if (n >= g.N) return;
+    if (g.splitk > 1) {
+        float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < g.M) part[(size_t)m * g.N + n] = acc[r];
+        }
+        return;
+    }
     const float bias = g.bias ? g.bias[n] : 0.0f;
     const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
 #pragma unroll
@@ -82,6 +97,29 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
             g.C[(size_t)m * g.ldc + n] = v;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs g) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t MN = (size_t)g.M * g.N;
+    if (idx >= MN) return;
+    const int m = (int)(idx / g.N), n = (int)(idx - (size_t)m * g.N);
+    float acc = g.splitk_ws[idx];
+    for (int z = 1; z < g.splitk; ++z) acc += g.splitk_ws[(size_t)z * MN + idx];     // fixed order: deterministic
+    float v = acc + (g.bias ? g.bias[n] : 0.0f);
+    if (g.alpha) v = v * g.alpha[n] + g.beta[n];
+    v = act_apply(v, g.act);
+    if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+    g.C[(size_t)m * g.ldc + n] = v;
+}
+
+// The split depends on the layer shape (N, K) only - never on M - so a clip's logit is bit-identical whatever
+// batch or shard it is computed in (the K-chunk boundaries and the z-order of the reduction are fixed).
+int gemm_recommended_splitk(long long M, int N, int K, int cu_count) {
+    (void)M; (void)cu_count;
+    if (K < 4096 || N > 256) return 1;
+    int s = K / 3072;
+    return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
 
 // generic (unaligned / K % 4 != 0) fallback on the VALU: one thread per output, same epilogue.
@@ -105,8 +143,15 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
     if (aligned) {
-        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64);
-        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, g);
+        const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
+        GemmArgs a = g;
+        a.splitk = sk;
+        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
+        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, a);
+        if (sk > 1) {
+            const size_t total = (size_t)g.M * g.N;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        }
     } else {
         const size_t total = (size_t)g.M * g.N;
         hipLaunchKernelGGL(gemm_valu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
@@ -203,7 +248,10 @@ static hipError_t launch_conv3x3_cob(const Conv3Args& a, hipStream_t s) {
 }
 
 hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s) {
-    if (a.Cout % 16 == 0) return launch_conv3x3_cob<16>(a, s);
+    static const int cob_env = [] { const char* e = getenv("NWW_CONV_COB"); return e ? atoi(e) : 0; }();
+    // pooled convs: 8 output channels per lane keep the 72 per-channel weights in SGPRs (16 spill them)
+    const int want = cob_env ? cob_env : (a.pool ? 8 : 16);
+    if (want >= 16 && a.Cout % 16 == 0) return launch_conv3x3_cob<16>(a, s);
     if (a.Cout % 8 == 0) return launch_conv3x3_cob<8>(a, s);
     if (a.Cout % 4 == 0) return launch_conv3x3_cob<4>(a, s);
     return launch_conv3x3_cob<1>(a, s);

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -13,6 +14,7 @@
 #include "fe_tables.h"
 #include "frontend.h"
 #include "layers.h"
+#include "trunk.h"
 
 namespace {
 
@@ -36,6 +38,7 @@ struct Run {
     float* emb = nullptr;       // [B][E]
     float* hid = nullptr;       // [B][E/2]
     float* logits = nullptr;    // [B]
+    float* splitk_ws = nullptr; size_t splitk_floats = 0; int cu_count = 256;
 };
 
 }  // namespace
@@ -62,6 +65,8 @@ struct nww_handle {
     float* d_hid = nullptr;
     float* d_logits = nullptr;
     float* d_probs = nullptr;
+    float* d_splitk = nullptr;     // split-K partials
+    size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
     bool profiling = false;
@@ -286,10 +291,10 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
 
 static void free_ws(nww_handle* h) {
     for (void* p : {(void*)h->d_ws, (void*)h->d_pcm, (void*)h->d_logmel, (void*)h->d_feats, (void*)h->d_emb,
-                    (void*)h->d_hid, (void*)h->d_logits, (void*)h->d_probs})
+                    (void*)h->d_hid, (void*)h->d_logits, (void*)h->d_probs, (void*)h->d_splitk})
         if (p) (void)hipFree(p);
     h->d_ws = nullptr; h->d_pcm = nullptr; h->d_logmel = nullptr; h->d_feats = nullptr; h->d_emb = nullptr;
-    h->d_hid = nullptr; h->d_logits = nullptr; h->d_probs = nullptr; h->cap_B = 0; h->cap_N = 0;
+    h->d_hid = nullptr; h->d_logits = nullptr; h->d_probs = nullptr; h->d_splitk = nullptr; h->cap_B = 0; h->cap_N = 0;
 }
 
 extern "C" int nww_destroy(nww_handle* h) {
@@ -373,11 +378,15 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
+    if (K >= 2048 && (size_t)8 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)8 * rows_per_clip * N;
     p.add("gemm:" + name, [=](Run& r) {
         GemmArgs g;
         g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;
         g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
+        g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
+        g.splitk_ws = r.splitk_ws;
+        if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
         return launch_gemm(g, r.stream);
     });
 }
@@ -390,6 +399,21 @@ void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Ci
         Conv3Args a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, Cin, Cout, H, W, act, pool};
         return launch_conv3x3(a, r.stream);
     });
+}
+
+// fused conv1+pool+conv2+pool (trunk.hip) when the 1->16->32 pattern fits LDS; returns false if not applicable
+bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
+               const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
+               const float* b2, const float* al2, const float* be2, int act) {
+    static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
+    if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_lds_bytes(C1, H, W) > 160 * 1024) return false;
+    p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
+    const int max_grid = p.h->cu_count;
+    p.add("trunk:" + name, [=](Run& r) {
+        TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
+        return launch_cnn_trunk(a, C1, C2, max_grid, r.stream);
+    });
+    return true;
 }
 
 // nn.GRU(bidirectional) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers xg_id, seqA, seqB.
@@ -506,8 +530,11 @@ extern "C" int nww_finalize(nww_handle* h) {
             break;
         }
         case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
-            add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
-            add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
+            if (!add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
+                           p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act)) {
+                add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
+                add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
+            }
             add_gemm(p, "fc1", 1, 0, 1, 128, 32 * (T / 4) * (F / 4), p.W("model.fc1.weight"), p.W("model.fc1.bias"), act);
             add_gemm(p, "fc2", 0, -2, 1, E, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"), ACT_NONE);
             break;
@@ -516,7 +543,13 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int Hh = T, Ww = F;             // (n_mels, frames)
             const int ch[3] = {16, 32, 64};
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
-            for (int i = 0; i < 3; ++i) {
+            int first = 0;
+            if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
+                          p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
+                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act)) {
+                first = 2; cin = 32; hh = Hh / 4; ww = Ww / 4; cur = 1;
+            }
+            for (int i = first; i < 3; ++i) {
                 const std::string cw = "model.conv_block." + std::to_string(4 * i), bnp = "model.conv_block." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
                 add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
@@ -534,7 +567,14 @@ extern "C" int nww_finalize(nww_handle* h) {
         }
         case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287
             int cin = 1, hh = T, ww = F, cur = -1;
-            for (int i = 0; i < c.n_crnn_channels; ++i) {
+            int first = 0;
+            if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
+                add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
+                          p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
+                          p.W("model.cnn.5.beta"), act)) {
+                first = 2; cin = 32; hh = T / 4; ww = F / 4; cur = 1;
+            }
+            for (int i = first; i < c.n_crnn_channels; ++i) {
                 const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
                 add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
@@ -693,6 +733,7 @@ static int ensure_ws(nww_handle* h, int B, int N) {
     HIP_TRY(h, hipMalloc(&h->d_hid, (size_t)nB * (c.embedding_dim / 2) * sizeof(float) + 16));
     HIP_TRY(h, hipMalloc(&h->d_logits, (size_t)nB * sizeof(float) + 16));
     HIP_TRY(h, hipMalloc(&h->d_probs, (size_t)nB * sizeof(float) + 16));
+    if (h->splitk_per_clip) HIP_TRY(h, hipMalloc(&h->d_splitk, h->splitk_per_clip * (size_t)nB * sizeof(float) + 16));
     h->cap_B = nB; h->cap_N = nN;
     return NWW_OK;
 }
@@ -707,6 +748,7 @@ extern "C" int nww_reserve(nww_handle* h, int32_t B, int32_t N) {
 static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s) {
     Run r;
     r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
+    r.splitk_ws = h->d_splitk; r.splitk_floats = h->splitk_per_clip * (size_t)h->cap_B; r.cu_count = h->cu_count;
     size_t off = 0;
     for (int i = 0; i < 6; ++i) {
         r.buf[i] = h->d_ws + off;
@@ -739,7 +781,10 @@ static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
     if (frames_out) *frames_out = T;
-    hipError_t e = fe_launch(d_pcm, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, 16, 256, h->cu_count * 3, s);
+    static const int fc_env = [] { const char* e = getenv("NWW_FE_FC"); return e ? atoi(e) : 16; }();
+    static const int blk_env = [] { const char* e = getenv("NWW_FE_BLOCK"); return e ? atoi(e) : 256; }();
+    static const int wg_env = [] { const char* e = getenv("NWW_FE_WGS_PER_CU"); return e ? atoi(e) : 3; }();
+    hipError_t e = fe_launch(d_pcm, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }

@@ -1,0 +1,15 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// fused Conv(1->C1)+[BN]+act+pool -> Conv(C1->C2)+[BN]+act+pool ; see trunk.hip
+struct TrunkArgs {
+    const float* in;                                   // [B][H][W]
+    const float *w1, *b1, *al1, *be1;                  // conv1 [C1][1][3][3], bias (may be null), folded BN (may be null)
+    const float *w2, *b2, *al2, *be2;                  // conv2 [C2][C1][3][3]
+    float* out;                                        // [B][C2][H/4][W/4]
+    int B, H, W, act;
+    int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
+};
+size_t trunk_lds_bytes(int C1, int H, int W);
+hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s);

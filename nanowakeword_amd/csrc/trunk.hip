@@ -1,0 +1,260 @@
+// trunk.hip - fused conv trunk of the CNN-family heads for gfx950:
+//     x[H][W] -> Conv2d(1,C1,3,p1) (+BN) + act + MaxPool2 -> Conv2d(C1,C2,3,p1) (+BN) + act + MaxPool2 -> [C2][H2][W2]
+// (reference: CNNModel.conv1/conv2 architectures.py:54-59,74-75; the first two stages of CRNNModel.cnn
+//  :217-225 and of E2E_MelSpectrogram_CNN.conv_block :840-849 have the same shape with BatchNorm folded in).
+//
+// One workgroup (4 waves) owns one clip at a time; nothing between the input and the pooled conv2 output
+// touches HBM:
+//   P0  input plane -> LDS with a zero halo (coalesced 16-byte global loads)
+//   P1  conv1 on v_mfma_f32_16x16x4_f32: M = 16 pixels (2 rows x 8 columns), N = 16 channels, K = 9 taps padded
+//       to 12; weights are 3 VGPRs; bias/BN/act and the 2x2 max happen in the C layout (a lane's 4 accumulator
+//       registers are one pooling window); result -> LDS plane set A1[C1][H1+2][W1+2] (zero halo), 113 KB for
+//       the (101,64) log-mel.
+//   P2  conv2 as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, fmaf chain): M = 32 conv2 output
+//       pixels arranged as a 2-row x 16-column patch so that each lane's 4-register groups of the C layout
+//       are exactly the 2x2 pooling quads; N = 32 output channels; K = C1*9 taken as (channel pair) x tap so
+//       the two half-waves read the same tap of channels 2c and 2c+1.  B fragments (weights) stay in
+//       C1*9/2 VGPRs for the whole kernel; A fragments are single ds_read_b32 per MFMA.  Two tiles are in
+//       flight per wave (independent accumulators).  Epilogue: bias/BN/act, in-lane 2x2 max, one shuffle
+//       pair with the partner half-wave, 16-byte stores.
+// Per clip: 2*9*C1*C2*(2*H2)*(2*W2) conv2 flops + 2*9*C1*(2*H1)*(2*W1) conv1 flops; HBM bytes = 4*H*W in +
+// 4*C2*H2*W2 out.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "layers.h"
+#include "trunk.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The activation is a template parameter: a run-time switch costs ~5 scalar branches per element, and with one
+// wave per SIMD every taken branch is an exposed instruction-fetch bubble (measured: 2.7k cycles per 16 outputs).
+template <int ACT>
+__device__ __forceinline__ float trunk_act(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+size_t trunk_lds_bytes(int C1, int H, int W) {
+    const int H1 = H / 2, W1 = W / 2;
+    const size_t in_f = (size_t)(H + 2) * (W + 2);
+    const size_t a1_f = (size_t)C1 * (H1 + 2) * (W1 + 2) + 64;
+    return (((in_f + 3) & ~(size_t)3) + a1_f) * sizeof(float);
+}
+
+template <int C1, int C2, int ACT>
+__global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
+    static_assert(C1 == 16 && C2 == 32, "C1 == 16 (one 16-wide MFMA column block), C2 == 32");
+    constexpr int KS = C1 * 9 / 2;                         // MFMA steps per tile (2 k per step)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
+    const int Wp0 = W + 2, Wp1 = W1 + 2, P1 = (H1 + 2) * Wp1;
+    const int in_f = ((H + 2) * Wp0 + 3) & ~3;
+    float* In = lds;
+    float* A1 = lds + in_f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+
+    // zero both LDS regions once: halos stay zero, interiors are rewritten per clip
+    for (int k = tid; k < in_f + C1 * P1 + 64; k += 256) lds[k] = 0.0f;
+
+    // conv2 weights -> B fragments: step s = c2*9 + tap, lane (cout = i, channel = 2*c2 + hi)
+    float breg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c2 = s / 9, tap = s - c2 * 9;
+        breg[s] = a.w2[((size_t)i * C1 + 2 * c2 + hi) * 9 + tap];
+    }
+    const float bias2 = a.b2 ? a.b2[i] : 0.0f;
+    const float al2 = a.al2 ? a.al2[i] : 1.0f, be2 = a.al2 ? a.be2[i] : 0.0f;
+
+    // conv1 weights -> B fragments of the 16x16x4 MFMA: lane (g = l>>4, channel = l&15), step st: tap 4*st + g
+    float w1reg[3];
+    int tap_off1[3];
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int tap = 4 * st + (lane >> 4);
+        w1reg[st] = (tap < 9 && (lane & 15) < C1) ? a.w1[(size_t)(lane & 15) * 9 + tap] : 0.0f;
+        tap_off1[st] = tap < 9 ? (tap / 3) * Wp0 + (tap % 3) : 0;
+    }
+    const float bias1 = a.b1 ? a.b1[lane & 15] : 0.0f;
+    const float al1 = a.al1 ? a.al1[lane & 15] : 1.0f, be1 = a.al1 ? a.be1[lane & 15] : 0.0f;
+
+    // conv2 tiling
+    const int nX = (W1 + 15) / 16, nT = H2 * nX;
+    const int t_begin = (nT * wave) / 4, t_end = (nT * (wave + 1)) / 4;
+    // lane's pixel inside a tile: i = 4*quad + 2*dy + dx  (quad along x)
+    const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
+    const int lane_off = hi * P1 + dyi * Wp1 + xi;
+
+    __syncthreads();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        // ---------------- P0: input -> LDS (interior at +1,+1)
+        const float* xin = a.in + (size_t)b * H * W;
+        if ((W & 3) == 0) {
+            for (int q = tid; q < H * W / 4; q += 256) {
+                const float4 v = reinterpret_cast<const float4*>(xin)[q];
+                const int idx = q * 4, y = idx / W, x = idx - y * W;
+                float* d = In + (y + 1) * Wp0 + x + 1;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < H * W; idx += 256) {
+                const int y = idx / W, x = idx - y * W;
+                In[(y + 1) * Wp0 + x + 1] = xin[idx];
+            }
+        }
+        __syncthreads();
+        // ---------------- P1: conv1 + act + pool -> A1 on v_mfma_f32_16x16x4_f32
+        // tile = 16 conv1 pixels as 2 rows x 8 columns, pixel i = 4*quad + 2*dy + dx; K = 9 taps padded to 12
+        // (3 steps of 4); lane (i = l&15, g = l>>4) feeds tap 4*step + g.  C layout: column = channel l&15,
+        // rows 4g..4g+3 = the 2x2 quad g -> the four accumulator registers of a lane ARE one pooling window.
+        if (!(a.dbg & 1)) {
+            const int nX1 = (2 * W1 + 7) / 8, nT1 = H1 * nX1;
+            const int i1 = lane & 15, g1 = lane >> 4;
+            const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
+            for (int t = wave * 4; t < nT1; t += 16) {           // 4 tiles (independent accumulators) per wave step
+                f32x4 acc[4];
+                const float* base[4];
+                int Rv[4], Xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = min(t + u, nT1 - 1);
+                    Rv[u] = tt / nX1; Xv[u] = tt - Rv[u] * nX1;
+                    base[u] = In + (2 * Rv[u]) * Wp0 + 8 * Xv[u] + pix_off;
+                    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    float av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = base[u][tap_off1[st]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], w1reg[st], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[u][q] + bias1;
+                        if (a.al1) v = v * al1 + be1;
+                        m = fmaxf(m, trunk_act<ACT>(v));
+                    }
+                    const int px = 4 * Xv[u] + g1;
+                    if (t + u < nT1 && px < W1) A1[i1 * P1 + (Rv[u] + 1) * Wp1 + px + 1] = m;
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- P2: conv2 on MFMA, two tiles in flight, A operands prefetched one channel pair ahead
+        float* outb = a.out + (size_t)b * C2 * H2 * W2;
+        for (int t = (a.dbg & 2) ? t_end : t_begin; t < t_end; t += 2) {
+            const bool two = (t + 1) < t_end;                // wave-uniform; a lone last tile is computed twice
+            const int R0 = t / nX, X0 = t - R0 * nX;
+            const int t1 = two ? t + 1 : t;
+            const int R1 = t1 / nX, X1 = t1 - R1 * nX;
+            const float* pa = A1 + lane_off + (2 * R0) * Wp1 + 16 * X0;
+            const float* pb = A1 + lane_off + (2 * R1) * Wp1 + 16 * X1;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            float na[9], nb[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int off = (tap / 3) * Wp1 + (tap % 3);
+                na[tap] = pa[off]; nb[tap] = pb[off];
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < C1 / 2; ++c2) {
+                float ca[9], cb[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) { ca[tap] = na[tap]; cb[tap] = nb[tap]; }
+                if (c2 + 1 < C1 / 2) {
+                    const float* qa = pa + 2 * (c2 + 1) * P1;
+                    const float* qb = pb + 2 * (c2 + 1) * P1;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int off = (tap / 3) * Wp1 + (tap % 3);
+                        na[tap] = qa[off]; nb[tap] = qb[off];
+                    }
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[tap], breg[c2 * 9 + tap], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[tap], breg[c2 * 9 + tap], acc1, 0, 0, 0);
+                }
+            }
+            // epilogue: bias/BN/act, 2x2 max inside each 4-register group, exchange with the partner half-wave
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && !two) break;
+                const f32x16& acc = which ? acc1 : acc0;
+                const int R = which ? R1 : R0, X = which ? X1 : X0;
+                float own[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[4 * k + q] + bias2;
+                        if (a.al2) v = v * al2 + be2;
+                        m = fmaxf(m, trunk_act<ACT>(v));
+                    }
+                    own[k] = m;                              // pooled column 8X + 2k + hi
+                }
+                // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
+                const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
+                const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+                float4 o;
+                if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
+                else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
+                const int pcol = 8 * X + 4 * hi;
+                float* dst = outb + ((size_t)i * H2 + R) * W2 + pcol;
+                if ((W2 & 3) == 0 && pcol + 3 < W2) {
+                    *reinterpret_cast<float4*>(dst) = o;
+                } else {
+                    if (pcol + 0 < W2) dst[0] = o.x;
+                    if (pcol + 1 < W2) dst[1] = o.y;
+                    if (pcol + 2 < W2) dst[2] = o.z;
+                    if (pcol + 3 < W2) dst[3] = o.w;
+                }
+            }
+        }
+        __syncthreads();                                     // A1 is free for the next clip's P1
+    }
+}
+
+hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s) {
+    if (C1 != 16 || C2 != 32) return hipErrorInvalidValue;
+    const size_t lds = trunk_lds_bytes(C1, a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static const int dbg = [] { const char* e = getenv("NWW_TRUNK_DBG"); return e ? atoi(e) : 0; }();
+    TrunkArgs aa = a;
+    aa.dbg = dbg;
+    int grid = a.B < max_grid ? a.B : max_grid;
+    if (grid < 1) grid = 1;
+    static size_t attr_for[3] = {0, 0, 0};
+#define TRUNK_LAUNCH(ACTV, SLOT)                                                                                   \
+    {                                                                                                              \
+        if (lds > attr_for[SLOT]) {                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV>),      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return e;                                                                         \
+            attr_for[SLOT] = lds;                                                                                  \
+        }                                                                                                          \
+        hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV>), dim3(grid), dim3(256), lds, s, aa);                   \
+    }
+    switch (a.act) {
+        case ACT_RELU: TRUNK_LAUNCH(ACT_RELU, 0) break;
+        case ACT_GELU: TRUNK_LAUNCH(ACT_GELU, 1) break;
+        case ACT_SILU: TRUNK_LAUNCH(ACT_SILU, 2) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TRUNK_LAUNCH
+    return hipGetLastError();
+}

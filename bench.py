@@ -69,13 +69,17 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
                 dt = time.perf_counter() - t0
                 if dt >= budget:
                     return n, dt
-    n, dt = timed(threads, seconds * 0.6)
-    n1, dt1 = timed(1, seconds * 0.4)
-    return {"value": round(n / dt, 1), "unit": "clips/s", "cores": int(threads), "kind": "port",
+    n1, dt1 = timed(1, seconds * 0.35)
+    best = (n1 / dt1, 1, n1, dt1)
+    for nt in sorted({min(8, ncpu), threads} - {1}):
+        n, dt = timed(nt, seconds * 0.3)
+        if n / dt > best[0]:
+            best = (n / dt, nt, n, dt)
+    return {"value": round(best[0], 1), "unit": "clips/s", "cores": int(best[1]), "kind": "port",
             "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu),
-            "sample": f"{n} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
-                      f"dense-DFT frontend + {cfg.model_type} head) in {dt:.1f} s on {threads} BLAS threads; "
-                      f"{n1} clips in {dt1:.1f} s on 1 thread"}
+            "sample": f"{best[2]} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
+                      f"dense-DFT frontend + {cfg.model_type} head) in {best[3]:.1f} s on {best[1]} BLAS thread(s) "
+                      f"(best of 1/8/{threads} threads; 1 thread = the reference interpreter's setting)"}
 
 
 def main():

@@ -46,7 +46,7 @@ NWW_HD nww_c32 c_scale(nww_c32 a, float s) { return c_make(a.x * s, a.y * s); }
 // Tables, built on the host in double precision (fe_tables.cpp), resident in LDS in the kernel.
 struct FeTables {
     nww_c32 win2[FE_M];          // (w[2m], w[2m+1]) / 32768  (int16 -> unit scale folded in; exact, power of 2)
-    nww_c32 tw200[25 * 8];       // [n2][k1] = exp(-2 pi i n2 k1 / 200)
+    nww_c32 tw200[8 * 25];       // [k1][n2] = exp(-2 pi i n2 k1 / 200)  (lane index n2 contiguous: no bank conflicts)
     nww_c32 tw400[101];          // exp(-2 pi i k / 400), k = 0..100
     int32_t mel_lo[FE_MAX_MELS];   // first FFT bin of filter j
     int32_t mel_cnt[FE_MAX_MELS];  // number of bins in its support
@@ -143,7 +143,7 @@ NWW_HD void fe_s1(int f, int n2, int hop, const int16_t* span, const FeTables* t
     nww_c32* out = yz + (f * 8) * 25 + n2;
     out[0] = z[0];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) out[k1 * 25] = c_mul(z[k1], tb->tw200[n2 * 8 + k1]);
+    for (int k1 = 1; k1 < 8; ++k1) out[k1 * 25] = c_mul(z[k1], tb->tw200[k1 * 25 + n2]);
 }
 
 // S2: task (frame f, row k1): 25-point DFT along n2, in place (index n2 -> k2).

@@ -50,8 +50,8 @@ std::string fe_build_tables(const FeParams& p, const float* window, const float*
     for (int n2 = 0; n2 < 25; ++n2)
         for (int k1 = 0; k1 < 8; ++k1) {
             const double a = -2.0 * kPi * (double)(n2 * k1) / 200.0;
-            t->tw200[n2 * 8 + k1].x = (float)std::cos(a);
-            t->tw200[n2 * 8 + k1].y = (float)std::sin(a);
+            t->tw200[k1 * 25 + n2].x = (float)std::cos(a);
+            t->tw200[k1 * 25 + n2].y = (float)std::sin(a);
         }
     for (int k = 0; k <= 100; ++k) {
         const double a = -2.0 * kPi * (double)k / 400.0;

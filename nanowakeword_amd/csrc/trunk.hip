@@ -45,8 +45,86 @@ size_t trunk_lds_bytes(int C1, int H, int W) {
     return (((in_f + 3) & ~(size_t)3) + a1_f) * sizeof(float);
 }
 
-template <int C1, int C2, int ACT>
-__global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
+// conv2 for tile t (and t+1 when TWO): 32 pixels x 32 channels x K = C1*9 each, A operands prefetched one channel
+// pair ahead of the MFMAs that consume them, then bias/BN/act, in-lane 2x2 max, half-wave exchange, 16-byte store.
+template <int C1, int ACT, bool TWO>
+__device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P1, int Wp1, int nX, int t,
+                                            const float (&breg)[C1 * 9 / 2], float bias2, float al2, float be2,
+                                            bool has_bn, float* outb, int i, int hi, int H2, int W2) {
+    const int R0 = t / nX, X0 = t - R0 * nX;
+    const int t1 = TWO ? t + 1 : t;
+    const int R1 = t1 / nX, X1 = t1 - R1 * nX;
+    const float* pa = A1 + lane_off + (2 * R0) * Wp1 + 16 * X0;
+    const float* pb = A1 + lane_off + (2 * R1) * Wp1 + 16 * X1;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float na[9], nb[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int off = (tap / 3) * Wp1 + (tap % 3);
+        na[tap] = pa[off];
+        if (TWO) nb[tap] = pb[off];
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < C1 / 2; ++c2) {
+        float ca[9], cb[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) { ca[tap] = na[tap]; if (TWO) cb[tap] = nb[tap]; }
+        if (c2 + 1 < C1 / 2) {
+            const float* qa = pa + 2 * (c2 + 1) * P1;
+            const float* qb = pb + 2 * (c2 + 1) * P1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int off = (tap / 3) * Wp1 + (tap % 3);
+                na[tap] = qa[off];
+                if (TWO) nb[tap] = qb[off];
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[tap], breg[c2 * 9 + tap], acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[tap], breg[c2 * 9 + tap], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < (TWO ? 2 : 1); ++which) {
+        const f32x16& acc = which ? acc1 : acc0;
+        const int R = which ? R1 : R0, X = which ? X1 : X0;
+        float own[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[4 * k + q] + bias2;
+                if (has_bn) v = v * al2 + be2;
+                m = fmaxf(m, trunk_act<ACT>(v));
+            }
+            own[k] = m;                              // pooled column 8X + 2k + hi
+        }
+        // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
+        const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
+        const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+        float4 o;
+        if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
+        else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
+        const int pcol = 8 * X + 4 * hi;
+        float* dst = outb + ((size_t)i * H2 + R) * W2 + pcol;
+        if ((W2 & 3) == 0 && pcol + 3 < W2) {
+            *reinterpret_cast<float4*>(dst) = o;
+        } else {
+            if (pcol + 0 < W2) dst[0] = o.x;
+            if (pcol + 1 < W2) dst[1] = o.y;
+            if (pcol + 2 < W2) dst[2] = o.z;
+            if (pcol + 3 < W2) dst[3] = o.w;
+        }
+    }
+}
+
+template <int C1, int C2, int ACT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a) {
+    constexpr int NTHR = 64 * NW;
     static_assert(C1 == 16 && C2 == 32, "C1 == 16 (one 16-wide MFMA column block), C2 == 32");
     constexpr int KS = C1 * 9 / 2;                         // MFMA steps per tile (2 k per step)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -59,7 +137,7 @@ __global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
     const int i = lane & 31, hi = lane >> 5;
 
     // zero both LDS regions once: halos stay zero, interiors are rewritten per clip
-    for (int k = tid; k < in_f + C1 * P1 + 64; k += 256) lds[k] = 0.0f;
+    for (int k = tid; k < in_f + C1 * P1 + 64; k += NTHR) lds[k] = 0.0f;
 
     // conv2 weights -> B fragments: step s = c2*9 + tap, lane (cout = i, channel = 2*c2 + hi)
     float breg[KS];
@@ -85,7 +163,7 @@ __global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
 
     // conv2 tiling
     const int nX = (W1 + 15) / 16, nT = H2 * nX;
-    const int t_begin = (nT * wave) / 4, t_end = (nT * (wave + 1)) / 4;
+    const int t_begin = (nT * wave) / NW, t_end = (nT * (wave + 1)) / NW;
     // lane's pixel inside a tile: i = 4*quad + 2*dy + dx  (quad along x)
     const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
     const int lane_off = hi * P1 + dyi * Wp1 + xi;
@@ -95,14 +173,14 @@ __global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
         // ---------------- P0: input -> LDS (interior at +1,+1)
         const float* xin = a.in + (size_t)b * H * W;
         if ((W & 3) == 0) {
-            for (int q = tid; q < H * W / 4; q += 256) {
+            for (int q = tid; q < H * W / 4; q += NTHR) {
                 const float4 v = reinterpret_cast<const float4*>(xin)[q];
                 const int idx = q * 4, y = idx / W, x = idx - y * W;
                 float* d = In + (y + 1) * Wp0 + x + 1;
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
-            for (int idx = tid; idx < H * W; idx += 256) {
+            for (int idx = tid; idx < H * W; idx += NTHR) {
                 const int y = idx / W, x = idx - y * W;
                 In[(y + 1) * Wp0 + x + 1] = xin[idx];
             }
@@ -116,7 +194,7 @@ __global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
             const int nX1 = (2 * W1 + 7) / 8, nT1 = H1 * nX1;
             const int i1 = lane & 15, g1 = lane >> 4;
             const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
-            for (int t = wave * 4; t < nT1; t += 16) {           // 4 tiles (independent accumulators) per wave step
+            for (int t = wave * 4; t < nT1; t += 4 * NW) {       // 4 tiles (independent accumulators) per wave step
                 f32x4 acc[4];
                 const float* base[4];
                 int Rv[4], Xv[4];
@@ -151,79 +229,14 @@ __global__ void __launch_bounds__(256, 1) cnn_trunk_kernel(TrunkArgs a) {
             }
         }
         __syncthreads();
-        // ---------------- P2: conv2 on MFMA, two tiles in flight, A operands prefetched one channel pair ahead
+        // ---------------- P2: conv2 on MFMA; tiles in pairs (two independent accumulators), a lone tile alone
         float* outb = a.out + (size_t)b * C2 * H2 * W2;
-        for (int t = (a.dbg & 2) ? t_end : t_begin; t < t_end; t += 2) {
-            const bool two = (t + 1) < t_end;                // wave-uniform; a lone last tile is computed twice
-            const int R0 = t / nX, X0 = t - R0 * nX;
-            const int t1 = two ? t + 1 : t;
-            const int R1 = t1 / nX, X1 = t1 - R1 * nX;
-            const float* pa = A1 + lane_off + (2 * R0) * Wp1 + 16 * X0;
-            const float* pb = A1 + lane_off + (2 * R1) * Wp1 + 16 * X1;
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            float na[9], nb[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int off = (tap / 3) * Wp1 + (tap % 3);
-                na[tap] = pa[off]; nb[tap] = pb[off];
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < C1 / 2; ++c2) {
-                float ca[9], cb[9];
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) { ca[tap] = na[tap]; cb[tap] = nb[tap]; }
-                if (c2 + 1 < C1 / 2) {
-                    const float* qa = pa + 2 * (c2 + 1) * P1;
-                    const float* qb = pb + 2 * (c2 + 1) * P1;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const int off = (tap / 3) * Wp1 + (tap % 3);
-                        na[tap] = qa[off]; nb[tap] = qb[off];
-                    }
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[tap], breg[c2 * 9 + tap], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[tap], breg[c2 * 9 + tap], acc1, 0, 0, 0);
-                }
-            }
-            // epilogue: bias/BN/act, 2x2 max inside each 4-register group, exchange with the partner half-wave
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                if (which == 1 && !two) break;
-                const f32x16& acc = which ? acc1 : acc0;
-                const int R = which ? R1 : R0, X = which ? X1 : X0;
-                float own[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v = acc[4 * k + q] + bias2;
-                        if (a.al2) v = v * al2 + be2;
-                        m = fmaxf(m, trunk_act<ACT>(v));
-                    }
-                    own[k] = m;                              // pooled column 8X + 2k + hi
-                }
-                // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
-                const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
-                const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-                float4 o;
-                if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
-                else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
-                const int pcol = 8 * X + 4 * hi;
-                float* dst = outb + ((size_t)i * H2 + R) * W2 + pcol;
-                if ((W2 & 3) == 0 && pcol + 3 < W2) {
-                    *reinterpret_cast<float4*>(dst) = o;
-                } else {
-                    if (pcol + 0 < W2) dst[0] = o.x;
-                    if (pcol + 1 < W2) dst[1] = o.y;
-                    if (pcol + 2 < W2) dst[2] = o.z;
-                    if (pcol + 3 < W2) dst[3] = o.w;
-                }
-            }
+        if (!(a.dbg & 2)) {
+            int t = t_begin;
+            for (; t + 1 < t_end; t += 2)
+                conv2_tiles<C1, ACT, true>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
+            if (t < t_end)
+                conv2_tiles<C1, ACT, false>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
         }
         __syncthreads();                                     // A1 is free for the next clip's P1
     }
@@ -238,23 +251,27 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
     aa.dbg = dbg;
     int grid = a.B < max_grid ? a.B : max_grid;
     if (grid < 1) grid = 1;
-    static size_t attr_for[3] = {0, 0, 0};
-#define TRUNK_LAUNCH(ACTV, SLOT)                                                                                   \
+    static size_t attr_for[6] = {0, 0, 0, 0, 0, 0};
+    static const int nw = [] { const char* e = getenv("NWW_TRUNK_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+#define TRUNK_LAUNCH1(ACTV, NWV, SLOT)                                                                             \
     {                                                                                                              \
         if (lds > attr_for[SLOT]) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV>),      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV, NWV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e != hipSuccess) return e;                                                                         \
             attr_for[SLOT] = lds;                                                                                  \
         }                                                                                                          \
-        hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV>), dim3(grid), dim3(256), lds, s, aa);                   \
+        hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);         \
     }
+#define TRUNK_LAUNCH(ACTV, SLOT)                                                                                   \
+    if (nw == 4) TRUNK_LAUNCH1(ACTV, 4, SLOT) else TRUNK_LAUNCH1(ACTV, 8, SLOT + 3)
     switch (a.act) {
         case ACT_RELU: TRUNK_LAUNCH(ACT_RELU, 0) break;
         case ACT_GELU: TRUNK_LAUNCH(ACT_GELU, 1) break;
         case ACT_SILU: TRUNK_LAUNCH(ACT_SILU, 2) break;
         default: return hipErrorInvalidValue;
     }
+#undef TRUNK_LAUNCH1
 #undef TRUNK_LAUNCH
     return hipGetLastError();
 }

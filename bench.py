@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--head", default="cnn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--debug-single-gpu", action="store_true",
+                    help="control-flow check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the gather "
+                         "runs over gloo on host copies (never a measurement)")
     return ap.parse_args()
 
 
@@ -99,11 +102,16 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if a.debug_single_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.debug_single_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fe = FrontendConfig()                                  # 16 kHz, 400/400/160, 64 mel, center
     shape = (64, 101) if a.head == "e2e_dnn" else (101, 64)
@@ -115,14 +123,15 @@ def main():
     pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
     pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
     logits = torch.empty(B, dtype=torch.float32, device=dev)
-    gathered = torch.empty(B * world, dtype=torch.float32, device=dev) if world > 1 else None
+    gdev = torch.device("cpu") if a.debug_single_gpu else dev
+    gathered = torch.empty(B * world, dtype=torch.float32, device=gdev) if world > 1 else None
     model.reserve(B, N)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         model.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logits)   # RCCL over xGMI: 4 B per clip
+            dist.all_gather_into_tensor(gathered, logits if not a.debug_single_gpu else logits.cpu())   # RCCL over xGMI: 4 B per clip
 
     for _ in range(a.warmup):
         step()
@@ -142,15 +151,18 @@ def main():
     prof = model.get_profile()
     model.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # ---- correctness guard on the timed buffers (cheap): finite, and first clips == small-batch run
     lg = logits.cpu().numpy()
-    assert np.isfinite(lg).all()
-    l8, _ = model.forward_pcm(pcm_host[:8])
-    assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
+    if world > 1:       # every rank's shard must sit at its slot of the gathered vector
+        assert np.array_equal(gathered.cpu().numpy()[rank * B:(rank + 1) * B], lg), "all-gather placed a shard wrongly"
+    if not any(os.environ.get(k, "0") not in ("", "0") for k in ("NWW_FE_DBG", "NWW_TRUNK_DBG")):   # ablation runs compute garbage
+        assert np.isfinite(lg).all()
+        l8, _ = model.forward_pcm(pcm_host[:8])
+        assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3

@@ -12,6 +12,7 @@
 // HBM traffic per clip: 2*N bytes read (int16 PCM; chunk overlaps of 240 samples are L2 hits) +
 // 4*n_mels*frames bytes written.  No intermediate ever leaves the CU.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "fe_steps.h"
 #include "frontend.h"
 
@@ -25,11 +26,26 @@ int fe_lds_bytes(int fc, int hop) {
     return FE_TB_BYTES + fc * 200 * 8 + ((fc * FE_PSTRIDE * 4 + 15) & ~15) + (((hop * (fc - 1) + FE_NFFT) * 2 + 15) & ~15);
 }
 
+// 8 consecutive padded-signal samples starting at s (relative to sample 0 of the clip) as one 16-byte value:
+// a single coalesced load when the group is interior and aligned, otherwise 2-byte loads through the reflect map.
+__device__ __forceinline__ uint4 fe_fetch8(const int16_t* __restrict__ x, int s, int N, int count) {
+    const int16_t* src = x + s;
+    if (s >= 0 && s + 8 <= N && count == 8 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0))
+        return *reinterpret_cast<const uint4*>(src);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < count) w[e >> 1] |= (uint32_t)(uint16_t)x[fe_reflect(s + e, N)] << (16 * (e & 1));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+#define FE_MAXG 4   // 16-byte groups per lane per chunk held in registers for the next chunk
+
 __global__ void __launch_bounds__(256)
 fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, int B, int N, int T, int nchunks, int fc,
                       int hop, int pad, int n_mels, float amin, float db_mult,
                       const FeTables* __restrict__ gtb, float* __restrict__ out_db,
-                      float* __restrict__ out_mel, int frames_major) {
+                      float* __restrict__ out_mel, int frames_major, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     FeTables* tb = reinterpret_cast<FeTables*>(smem);
     nww_c32* yz = reinterpret_cast<nww_c32*>(smem + FE_TB_BYTES);
@@ -43,50 +59,74 @@ fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, int B, int N, int T, int 
         for (int i = tid; i < FE_TB_BYTES / 16; i += nthr) dst[i] = src[i];
     }
     const int total = B * nchunks;
-    for (int work = blockIdx.x; work < total; work += gridDim.x) {
-        const int b = work / nchunks, c = work - b * nchunks;
-        const int t0 = c * fc;
-        const int nf = min(fc, T - t0);
-        const int len = hop * (nf - 1) + FE_NFFT;
-        const int s0 = hop * t0 - pad;
+    // Prefetch pipeline: while chunk i is being transformed, chunk i+1's PCM (incl. reflected edge samples) is
+    // already in flight into registers; it is written to the LDS span at the top of the next iteration.
+    uint4 pre[FE_MAXG];
+    auto chunk_geom = [&](int work, int& b, int& t0, int& nf, int& len, int& s0) {
+        b = work / nchunks;
+        const int c = work - b * nchunks;
+        t0 = c * fc;
+        nf = min(fc, T - t0);
+        len = hop * (nf - 1) + FE_NFFT;
+        s0 = hop * t0 - pad;
+    };
+    auto prefetch = [&](int work) {
+        int b, t0, nf, len, s0;
+        chunk_geom(work, b, t0, nf, len, s0);
         const int16_t* x = pcm + (size_t)b * N;
-        // ---- S0: stage span. 8 samples (16 B) per step.
-        for (int g = tid; g * 8 < len; g += nthr) {
-            const int i0 = g * 8, s = s0 + i0;
-            const int16_t* src = x + s;
-            if (s >= 0 && s + 8 <= N && i0 + 8 <= len && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                *reinterpret_cast<uint4*>(span + i0) = *reinterpret_cast<const uint4*>(src);
-            } else {
-                for (int e = 0; e < 8 && i0 + e < len; ++e) span[i0 + e] = x[fe_reflect(s + e, N)];
-            }
+#pragma unroll
+        for (int q = 0; q < FE_MAXG; ++q) {
+            const int i0 = (tid + q * nthr) * 8;
+            if (i0 < len) pre[q] = fe_fetch8(x, s0 + i0, N, min(8, len - i0));
+        }
+    };
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+    for (int work = blockIdx.x; work < total; work += gridDim.x) {
+        int b, t0, nf, len, s0;
+        chunk_geom(work, b, t0, nf, len, s0);
+        // ---- S0: registers -> LDS span (16 B per lane per group)
+#pragma unroll
+        for (int q = 0; q < FE_MAXG; ++q) {
+            const int i0 = (tid + q * nthr) * 8;
+            if (i0 < len) *reinterpret_cast<uint4*>(span + i0) = pre[q];
         }
         __syncthreads();
+        if (work + (int)gridDim.x < total) prefetch(work + gridDim.x);
         // ---- S1
-        for (int task = tid; task < nf * 25; task += nthr) {
+        for (int task = (dbg & 1) ? nf * 25 : tid; task < nf * 25; task += nthr) {
             const int f = task / 25;
             fe_s1(f, task - f * 25, hop, span, tb, yz);
         }
         __syncthreads();
         // ---- S2
-        for (int task = tid; task < nf * 8; task += nthr) fe_s2(task >> 3, task & 7, yz);
+        for (int task = (dbg & 2) ? nf * 8 : tid; task < nf * 8; task += nthr) fe_s2(task >> 3, task & 7, yz);
         __syncthreads();
         // ---- S3
-        for (int task = tid; task < nf * 101; task += nthr) {
+        for (int task = (dbg & 4) ? nf * 101 : tid; task < nf * 101; task += nthr) {
             const int f = task / 101;
             fe_s3(f, task - f * 101, tb, yz, pw);
         }
         __syncthreads();
-        // ---- S4 (writes HBM; consecutive lanes -> consecutive addresses in the chosen layout)
-        const int ntask = nf * n_mels;
-        if (frames_major) {          // out[b][t][j]
+        // ---- S4: sparse mel + dB.  Tasks are filter-major (lane = frame of one filter) so all lanes of a wave run
+        // the same trip count, the filter weights are LDS broadcasts and the power rows are conflict-free.
+        const int ntask = (dbg & 8) ? 0 : nf * n_mels;
+        if (frames_major) {          // out[b][t][j]: stage [f][j] in LDS (yz is free after S3), then store coalesced
+            float* stage = reinterpret_cast<float*>(yz);
+            float* stage_m = stage + fc * n_mels;
+            for (int task = tid; task < ntask; task += nthr) {
+                const int j = task / nf, f = task - j * nf;
+                const float m = fe_s4(f, j, tb, pw);
+                stage[f * n_mels + j] = fe_db(m, amin, db_mult);
+                if (out_mel) stage_m[f * n_mels + j] = m;
+            }
+            __syncthreads();
             float* ob = out_db ? out_db + ((size_t)b * T + t0) * n_mels : nullptr;
             float* om = out_mel ? out_mel + ((size_t)b * T + t0) * n_mels : nullptr;
-            for (int task = tid; task < ntask; task += nthr) {
-                const int f = task / n_mels, j = task - f * n_mels;
-                const float m = fe_s4(f, j, tb, pw);
-                if (ob) ob[task] = fe_db(m, amin, db_mult);
-                if (om) om[task] = m;
+            for (int k = tid; k < ntask; k += nthr) {
+                if (ob) ob[k] = stage[k];
+                if (om) om[k] = stage_m[k];
             }
+            __syncthreads();         // stage aliases yz: the next chunk's S1 must not overwrite it early
         } else {                     // out[b][j][t]
             for (int task = tid; task < ntask; task += nthr) {
                 const int j = task / nf, f = task - j * nf;
@@ -114,6 +154,9 @@ hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& 
                      hipStream_t stream) {
     int fc, nchunks;
     fe_plan(T, fc_max, &fc, &nchunks);
+    // the register prefetch holds FE_MAXG 16-byte groups per lane: shrink the chunk if its span would not fit
+    while (fc > 1 && (p.hop * (fc - 1) + FE_NFFT + 7) / 8 > FE_MAXG * block) { --fc; nchunks = (T + fc - 1) / fc; }
+    if ((p.hop * (fc - 1) + FE_NFFT + 7) / 8 > FE_MAXG * block) return hipErrorInvalidValue;
     const int lds = fe_lds_bytes(fc, p.hop);
     static int attr_set_for = 0;
     if (lds > attr_set_for) {
@@ -122,11 +165,12 @@ hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& 
         if (e != hipSuccess) return e;
         attr_set_for = lds;
     }
+    static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
     long long total = (long long)B * nchunks;
     int grid = (int)(total < max_grid ? total : max_grid);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(fe_stft_mel_db_kernel, dim3(grid), dim3(block), lds, stream, d_pcm, B, N, T, nchunks, fc,
                        p.hop, p.center ? FE_NFFT / 2 : 0, p.n_mels, p.amin, p.db_mult, d_tables, d_db, d_mel,
-                       frames_major);
+                       frames_major, dbg);
     return hipGetLastError();
 }

@@ -47,12 +47,30 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
         k = blockIdx.z * kc;
         K = min(g.K, k + kc);
     }
-    for (; k + 32 <= K; k += 32) {
+    // main loop, 32 k per iteration, operands of the NEXT iteration are in flight while this one's 16 MFMAs run
+    if (k + 32 <= K) {
         float4 a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             a[u] = *reinterpret_cast<const float4*>(ap + k + 8 * u);
             b[u] = *reinterpret_cast<const float4*>(wp + k + 8 * u);
+        }
+        for (; k + 64 <= K; k += 32) {
+            float4 na[4], nb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                na[u] = *reinterpret_cast<const float4*>(ap + k + 32 + 8 * u);
+                nb[u] = *reinterpret_cast<const float4*>(wp + k + 32 + 8 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = na[u]; b[u] = nb[u]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -61,6 +79,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
         }
+        k += 32;
     }
     for (; k < K; k += 8) {                                  // K % 4 == 0: the last group may be half
         float4 a = make_float4(0, 0, 0, 0), b = a;
@@ -75,6 +94,103 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
     }
     const int n = n0 + i;
     if (n >= g.N) return;
+    if (g.splitk > 1) {
+        float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < g.M) part[(size_t)m * g.N + n] = acc[r];
+        }
+        return;
+    }
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+    const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+            float v = acc[r] + bias;
+            if (g.alpha) v = v * al + be;
+            v = act_apply(v, g.act);
+            if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+            g.C[(size_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
+// LDS-staged variant (default): 64x64x32 tiles, coalesced 16-byte global loads (8 rows x 128 B per wave
+// instruction: 4x fewer cache-line requests than one row per lane, which is what bounded the direct kernel -
+// fc1 ran at 37% of peak with the texture-address unit saturated), register-staged double buffering with one
+// barrier per K-tile, operand fragments read back with conflict-free ds_read_b128 (row stride 36 floats).
+// Same k <-> (step, half-wave) map and the same per-output fmaf chain as gemm_mfma_kernel: results are
+// bit-identical between the two.
+#define GT_LD 36
+__global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][64 * GT_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[2][64 * GT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.x * 64, bn = blockIdx.y * 64;
+    const int i = lane & 31, h = lane >> 5;
+    int k_begin = 0, k_end = g.K;
+    if (g.splitk > 1) {
+        const int kc = (((g.K + g.splitk - 1) / g.splitk) + 31) & ~31;
+        k_begin = blockIdx.z * kc;
+        k_end = min(g.K, k_begin + kc);
+    }
+    // loader mapping: thread -> (row r = tid/8 + 32*q, 16-byte column kq = tid%8)
+    const int lr = tid >> 3, lq = tid & 7;
+    const float* arow[2];
+    const float* wrow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        arow[q] = g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
+        wrow[q] = g.W + (size_t)min(bn + lr + 32 * q, g.N - 1) * g.K + 4 * lq;
+    }
+    auto gload = [&](int k0, float4 (&ra)[2], float4 (&rw)[2]) {
+        const bool ok = k0 + 4 * lq + 4 <= k_end;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
+            rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<float4*>(&As[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = ra[q];
+            *reinterpret_cast<float4*>(&Ws[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = rw[q];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int arow_l = ((wave >> 1) * 32 + i) * GT_LD + 4 * h;
+    const int wrow_l = ((wave & 1) * 32 + i) * GT_LD + 4 * h;
+    float4 ra[2], rw[2];
+    int cur = 0;
+    if (k_begin < k_end) {
+        gload(k_begin, ra, rw);
+        lstore(0, ra, rw);
+    }
+    __syncthreads();
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        const bool more = k0 + 32 < k_end;
+        if (more) gload(k0 + 32, ra, rw);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[cur][arow_l + 8 * u]);
+            const float4 b = *reinterpret_cast<const float4*>(&Ws[cur][wrow_l + 8 * u]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1, ra, rw);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int m0 = bm + (wave >> 1) * 32, n = bn + (wave & 1) * 32 + i;
+    if (m0 >= g.M || n >= g.N) return;
     if (g.splitk > 1) {
         float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
 #pragma unroll
@@ -118,8 +234,9 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs g) {
 int gemm_recommended_splitk(long long M, int N, int K, int cu_count) {
     (void)M; (void)cu_count;
     if (K < 4096 || N > 256) return 1;
-    int s = K / 3072;
-    return s < 1 ? 1 : (s > 8 ? 8 : s);
+    static const int div = [] { const char* e = getenv("NWW_SPLITK_DIV"); return e ? atoi(e) : 3072; }();
+    int s = K / div;
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
 // generic (unaligned / K % 4 != 0) fallback on the VALU: one thread per output, same epilogue.
@@ -147,7 +264,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         GemmArgs a = g;
         a.splitk = sk;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
-        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, a);
+        static const int direct = [] { const char* e = getenv("NWW_GEMM_DIRECT"); return e ? atoi(e) : 0; }();
+        if (direct) hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gemm_lds_kernel, grid, dim3(256), 0, s, a);
         if (sk > 1) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);

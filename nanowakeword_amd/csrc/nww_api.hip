@@ -378,7 +378,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
-    if (K >= 2048 && (size_t)8 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)8 * rows_per_clip * N;
+    if (K >= 2048 && (size_t)16 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)16 * rows_per_clip * N;
     p.add("gemm:" + name, [=](Run& r) {
         GemmArgs g;
         g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;

@@ -191,29 +191,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         // (3 steps of 4); lane (i = l&15, g = l>>4) feeds tap 4*step + g.  C layout: column = channel l&15,
         // rows 4g..4g+3 = the 2x2 quad g -> the four accumulator registers of a lane ARE one pooling window.
         if (!(a.dbg & 1)) {
-            const int nX1 = (2 * W1 + 7) / 8, nT1 = H1 * nX1;
+            // groups of 4 horizontally adjacent tiles: one index division per group, the tiles of a group are at
+            // constant +8 column offsets (immediate offsets on the LDS reads)
+            const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4, nG = H1 * ngx;
             const int i1 = lane & 15, g1 = lane >> 4;
             const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
-            for (int t = wave * 4; t < nT1; t += 4 * NW) {       // 4 tiles (independent accumulators) per wave step
+            float* a1lane = A1 + i1 * P1 + Wp1 + g1 + 1;
+            for (int g = wave; g < nG; g += NW) {
+                const int R = g / ngx, X0 = 4 * (g - R * ngx);
+                const float* rowp = In + (2 * R) * Wp0 + 8 * X0 + pix_off;
                 f32x4 acc[4];
-                const float* base[4];
-                int Rv[4], Xv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int tt = min(t + u, nT1 - 1);
-                    Rv[u] = tt / nX1; Xv[u] = tt - Rv[u] * nX1;
-                    base[u] = In + (2 * Rv[u]) * Wp0 + 8 * Xv[u] + pix_off;
-                    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int st = 0; st < 3; ++st) {
+                    const float* q = rowp + tap_off1[st];
                     float av[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) av[u] = base[u][tap_off1[st]];
+                    for (int u = 0; u < 4; ++u) av[u] = q[8 * u];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], w1reg[st], acc[u], 0, 0, 0);
                 }
+                float* wr = a1lane + R * Wp1 + 4 * X0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float m = -INFINITY;
@@ -223,8 +223,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
                         if (a.al1) v = v * al1 + be1;
                         m = fmaxf(m, trunk_act<ACT>(v));
                     }
-                    const int px = 4 * Xv[u] + g1;
-                    if (t + u < nT1 && px < W1) A1[i1 * P1 + (Rv[u] + 1) * Wp1 + px + 1] = m;
+                    if (X0 + u < nX1 && 4 * (X0 + u) + g1 < W1) wr[4 * u] = m;
                 }
             }
         }

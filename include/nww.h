@@ -139,6 +139,22 @@ int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen);
 int nww_set_profiling(nww_handle* h, int32_t enable);
 int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches, int32_t* n_inout);
 
+/* ---- batched streaming (the front half of NanoInterpreter.predict in E2E mode, for S lock-step streams) ----
+ * Replaces, per stream, the deque(maxlen=clip_samples) + "last clip_samples" window of
+ * nanointerpreter.py:181,746-756 with a device-resident ring (double-written so the last `window` samples
+ * are always contiguous).  Every push appends `hop` new samples per stream and re-scores the whole window,
+ * exactly as the reference recomputes its window on every predict() call.  Scores are 0 until a stream has
+ * seen `window` samples (nanointerpreter.py:755,785-786).  Post-filters stay on the host (a18).            */
+int nww_stream_open(nww_handle* h, int32_t n_streams, int32_t window_samples, int32_t hop_samples);
+/* chunk [n_streams][hop] int16 (host pointer); logits/probs [n_streams] host, either may be NULL.         */
+int nww_stream_push(nww_handle* h, const int16_t* chunk, float* logits, float* probs);
+/* device variant: d_chunk [n_streams][hop], outputs device pointers, enqueued on `stream`, no sync.       */
+int nww_stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, void* stream);
+int nww_stream_reset(nww_handle* h);      /* new session for every stream (NanoInterpreter.reset, :719-733)    */
+int nww_stream_close(nww_handle* h);
+/* samples seen per stream since open/reset                                                               */
+int64_t nww_stream_filled(const nww_handle* h);
+
 const char* nww_version(void);
 
 #ifdef __cplusplus

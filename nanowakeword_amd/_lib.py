@@ -37,7 +37,8 @@ SYMBOLS = [
     "nww_tensor_info", "nww_finalize", "nww_num_frames", "nww_frontend", "nww_frontend_ex", "nww_forward_pcm",
     "nww_forward_features", "nww_forward_features_ex", "nww_frontend_dev", "nww_forward_pcm_dev",
     "nww_forward_features_dev", "nww_reserve", "nww_describe_plan", "nww_set_profiling", "nww_get_profile",
-    "nww_version",
+    "nww_stream_open", "nww_stream_push", "nww_stream_push_dev", "nww_stream_reset", "nww_stream_close",
+    "nww_stream_filled", "nww_version",
 ]
 
 
@@ -77,6 +78,12 @@ def load_library():
     lib.nww_describe_plan.argtypes = [vp, C.c_char_p, i32]; lib.nww_describe_plan.restype = C.c_int
     lib.nww_set_profiling.argtypes = [vp, i32]; lib.nww_set_profiling.restype = C.c_int
     lib.nww_get_profile.argtypes = [vp, f32p, C.POINTER(i32), C.POINTER(i32)]; lib.nww_get_profile.restype = C.c_int
+    lib.nww_stream_open.argtypes = [vp, i32, i32, i32]; lib.nww_stream_open.restype = C.c_int
+    lib.nww_stream_push.argtypes = [vp, vp, vp, vp]; lib.nww_stream_push.restype = C.c_int
+    lib.nww_stream_push_dev.argtypes = [vp, vp, vp, vp, vp]; lib.nww_stream_push_dev.restype = C.c_int
+    lib.nww_stream_reset.argtypes = [vp]; lib.nww_stream_reset.restype = C.c_int
+    lib.nww_stream_close.argtypes = [vp]; lib.nww_stream_close.restype = C.c_int
+    lib.nww_stream_filled.argtypes = [vp]; lib.nww_stream_filled.restype = C.c_int64
     lib.nww_version.argtypes = []; lib.nww_version.restype = C.c_char_p
     _lib = lib
     return lib

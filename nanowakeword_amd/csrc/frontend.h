@@ -5,6 +5,7 @@
 int fe_lds_bytes(int fc, int hop);
 void fe_plan(int T, int fc_max, int* fc, int* nchunks);
 // d_db / d_mel: [B][n_mels][T] (frames_major = 0) or [B][T][n_mels] (frames_major = 1); either may be null.
-hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
+// row_stride: samples between consecutive clips (N for a dense [B][N] batch; 2*window for the streaming rings)
+hipError_t fe_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
                      float* d_db, float* d_mel, int frames_major, int fc_max, int block, int max_grid,
                      hipStream_t stream);

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint4 fe_fetch8(const int16_t* __restrict__ x, int s,
 #define FE_MAXG 4   // 16-byte groups per lane per chunk held in registers for the next chunk
 
 __global__ void __launch_bounds__(256)
-fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, int B, int N, int T, int nchunks, int fc,
+fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N, int T, int nchunks, int fc,
                       int hop, int pad, int n_mels, float amin, float db_mult,
                       const FeTables* __restrict__ gtb, float* __restrict__ out_db,
                       float* __restrict__ out_mel, int frames_major, int dbg) {
@@ -73,7 +73,7 @@ fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, int B, int N, int T, int 
     auto prefetch = [&](int work) {
         int b, t0, nf, len, s0;
         chunk_geom(work, b, t0, nf, len, s0);
-        const int16_t* x = pcm + (size_t)b * N;
+        const int16_t* x = pcm + (size_t)b * row_stride;
 #pragma unroll
         for (int q = 0; q < FE_MAXG; ++q) {
             const int i0 = (tid + q * nthr) * 8;
@@ -149,7 +149,7 @@ void fe_plan(int T, int fc_max, int* fc, int* nchunks) {
     *fc = (T + nc - 1) / nc;
 }
 
-hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
+hipError_t fe_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
                      float* d_db, float* d_mel, int frames_major, int fc_max, int block, int max_grid,
                      hipStream_t stream) {
     int fc, nchunks;
@@ -169,7 +169,7 @@ hipError_t fe_launch(const int16_t* d_pcm, int B, int N, int T, const FeParams& 
     long long total = (long long)B * nchunks;
     int grid = (int)(total < max_grid ? total : max_grid);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(fe_stft_mel_db_kernel, dim3(grid), dim3(block), lds, stream, d_pcm, B, N, T, nchunks, fc,
+    hipLaunchKernelGGL(fe_stft_mel_db_kernel, dim3(grid), dim3(block), lds, stream, d_pcm, row_stride, B, N, T, nchunks, fc,
                        p.hop, p.center ? FE_NFFT / 2 : 0, p.n_mels, p.amin, p.db_mult, d_tables, d_db, d_mel,
                        frames_major, dbg);
     return hipGetLastError();

@@ -66,6 +66,9 @@ struct nww_handle {
     float* d_logits = nullptr;
     float* d_probs = nullptr;
     float* d_splitk = nullptr;     // split-K partials
+    // streaming rings: [S][2*W] int16, sample p of a stream lives at p and p+W
+    int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
+    int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
@@ -297,10 +300,13 @@ static void free_ws(nww_handle* h) {
     h->d_hid = nullptr; h->d_logits = nullptr; h->d_probs = nullptr; h->d_splitk = nullptr; h->cap_B = 0; h->cap_N = 0;
 }
 
+extern "C" int nww_stream_close(nww_handle* h);
+
 extern "C" int nww_destroy(nww_handle* h) {
     if (!h) return NWW_OK;
     (void)hipSetDevice(h->cfg.device);
     free_ws(h);
+    nww_stream_close(h);
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -777,14 +783,14 @@ static int check_run(nww_handle* h, int B) {
 }
 
 static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_db, float* d_mel, int frames_major,
-                        hipStream_t s, int* frames_out) {
+                        hipStream_t s, int* frames_out, size_t row_stride = 0) {
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
     if (frames_out) *frames_out = T;
     static const int fc_env = [] { const char* e = getenv("NWW_FE_FC"); return e ? atoi(e) : 16; }();
     static const int blk_env = [] { const char* e = getenv("NWW_FE_BLOCK"); return e ? atoi(e) : 256; }();
     static const int wg_env = [] { const char* e = getenv("NWW_FE_WGS_PER_CU"); return e ? atoi(e) : 3; }();
-    hipError_t e = fe_launch(d_pcm, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s);
+    hipError_t e = fe_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }
@@ -798,7 +804,8 @@ extern "C" int nww_frontend_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, 
     return frontend_dev(h, d_pcm, B, N, d_logmel, nullptr, frames_major, stream ? (hipStream_t)stream : h->own_stream, nullptr);
 }
 
-static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s) {
+static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s,
+                           size_t row_stride = 0) {
     const nww_config& c = h->cfg;
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
@@ -810,7 +817,7 @@ static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, fl
     if (rc) return rc;
     prof_begin(h);
     prof_mark(h, s, 0);
-    rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr);
+    rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr, row_stride);
     if (rc) return rc;
     return run_head(h, h->d_logmel, B, d_logits, d_probs, s);
 }
@@ -871,6 +878,94 @@ static int copy_out(nww_handle* h, int B, float* logits, float* probs, float* em
     if (emb) HIP_TRY(h, hipMemcpyAsync(emb, h->d_emb, (size_t)B * h->cfg.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return NWW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ streaming
+__global__ void __launch_bounds__(256)
+stream_push_kernel(int16_t* __restrict__ ring, const int16_t* __restrict__ chunk, int S, int W, int hop, int pos) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)S * hop) return;
+    const int s = (int)(idx / hop), j = (int)(idx - (size_t)s * hop);
+    int p = pos + j;
+    if (p >= W) p -= W;
+    const int16_t v = chunk[idx];
+    int16_t* r = ring + (size_t)s * 2 * W;
+    r[p] = v;
+    r[p + W] = v;
+}
+
+extern "C" int nww_stream_close(nww_handle* h) {
+    if (!h) return NWW_ERR_INVALID;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->d_ring) (void)hipFree(h->d_ring);
+    if (h->d_chunk) (void)hipFree(h->d_chunk);
+    h->d_ring = nullptr; h->d_chunk = nullptr; h->ring_S = h->ring_W = h->ring_hop = h->ring_pos = 0; h->ring_filled = 0;
+    return NWW_OK;
+}
+
+extern "C" int nww_stream_open(nww_handle* h, int32_t S, int32_t W, int32_t hop) {
+    int rc = check_run(h, S);
+    if (rc) return rc;
+    if (W <= 0 || hop <= 0 || hop > W || (W % 8) || (hop % 8))
+        return fail(h, NWW_ERR_INVALID, "window and hop must be positive multiples of 8 samples with hop <= window");
+    const nww_config& c = h->cfg;
+    const int T = fe_num_frames(h->fe, W);
+    const int rows = c.mel_major_features ? c.n_mels : T, cols = c.mel_major_features ? T : c.n_mels;
+    if (T <= 0 || rows != c.in_rows || cols != c.in_cols)
+        return fail(h, NWW_ERR_SHAPE, "a %d-sample window gives (%d,%d) features but the head expects (%d,%d)", W, rows, cols, c.in_rows, c.in_cols);
+    nww_stream_close(h);
+    HIP_TRY(h, hipSetDevice(c.device));
+    HIP_TRY(h, hipMalloc(&h->d_ring, (size_t)S * 2 * W * sizeof(int16_t) + 16));
+    HIP_TRY(h, hipMemset(h->d_ring, 0, (size_t)S * 2 * W * sizeof(int16_t)));
+    HIP_TRY(h, hipMalloc(&h->d_chunk, (size_t)S * hop * sizeof(int16_t) + 16));
+    h->ring_S = S; h->ring_W = W; h->ring_hop = hop; h->ring_pos = 0; h->ring_filled = 0;
+    return ensure_ws(h, S, W);
+}
+
+extern "C" int nww_stream_reset(nww_handle* h) {
+    if (!h || !h->d_ring) return fail(h, NWW_ERR_STATE, "no open stream batch");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemset(h->d_ring, 0, (size_t)h->ring_S * 2 * h->ring_W * sizeof(int16_t)));
+    h->ring_pos = 0; h->ring_filled = 0;
+    return NWW_OK;
+}
+
+extern "C" int64_t nww_stream_filled(const nww_handle* h) { return h ? h->ring_filled : 0; }
+
+static int stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, hipStream_t s) {
+    const int S = h->ring_S, W = h->ring_W, hop = h->ring_hop;
+    const size_t total = (size_t)S * hop;
+    hipLaunchKernelGGL(stream_push_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->d_ring, d_chunk, S, W, hop, h->ring_pos);
+    HIP_TRY(h, hipGetLastError());
+    h->ring_pos = (h->ring_pos + hop) % W;
+    h->ring_filled += hop;
+    // the last W samples of every stream are contiguous at ring + pos (double-written ring)
+    if (h->ring_filled < W) {       // window not full yet: the reference reports 0.0 (nanointerpreter.py:785-786)
+        if (d_logits) HIP_TRY(h, hipMemsetAsync(d_logits, 0, (size_t)S * sizeof(float), s));
+        if (d_probs) HIP_TRY(h, hipMemsetAsync(d_probs, 0, (size_t)S * sizeof(float), s));
+        return NWW_OK;
+    }
+    return forward_pcm_dev(h, h->d_ring + h->ring_pos, S, W, d_logits, d_probs, s, (size_t)2 * W);
+}
+
+extern "C" int nww_stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, void* stream) {
+    if (!h || !h->d_ring) return fail(h, NWW_ERR_STATE, "no open stream batch (nww_stream_open)");
+    if (!d_chunk) return fail(h, NWW_ERR_INVALID, "null chunk pointer");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return stream_push_dev(h, d_chunk, d_logits, d_probs, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+extern "C" int nww_stream_push(nww_handle* h, const int16_t* chunk, float* logits, float* probs) {
+    if (!h || !h->d_ring) return fail(h, NWW_ERR_STATE, "no open stream batch (nww_stream_open)");
+    if (!chunk) return fail(h, NWW_ERR_INVALID, "Input audio must be a non-null int16 array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = h->own_stream;
+    const int S = h->ring_S;
+    HIP_TRY(h, hipMemcpyAsync(h->d_chunk, chunk, (size_t)S * h->ring_hop * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    int rc = stream_push_dev(h, h->d_chunk, h->d_logits, h->d_probs, s);
+    if (rc) return rc;
+    return copy_out(h, S, logits, probs, nullptr, s);
 }
 
 extern "C" int nww_forward_pcm(nww_handle* h, const int16_t* pcm, int32_t B, int32_t N, float* logits, float* probs) {

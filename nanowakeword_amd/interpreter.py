@@ -369,3 +369,59 @@ class HipInterpreter:
     @property
     def e2e_buffer_samples(self) -> Dict[str, int]:
         return {n: w.filled for n, w in self._windows.items()}
+
+
+class StreamBatch:
+    """S lock-step audio streams scored together on one GPU: the batched form of the E2E branch of
+    ``NanoInterpreter.predict`` (nanointerpreter.py:735-814).  The raw-audio windows live in device rings
+    (``nww_stream_*``); per-stream filter state stays here on the host, vectorised over streams:
+    raw score 0 until a stream has a full window (:785-786), first five predictions zeroed (:789-790),
+    patience / debounce (:1034-1064), 30-entry prediction history (:1002).  Every stream receives exactly
+    ``hop`` new samples per push (streams never migrate)."""
+
+    def __init__(self, backend, n_streams: int, window_samples: int = 16000, hop_samples: int = HOP_SAMPLES,
+                 name: str = "model"):
+        self.backend, self.S, self.window, self.hop, self.name = backend, int(n_streams), int(window_samples), int(hop_samples), name
+        backend.stream_open(self.S, self.window, self.hop)
+        self.reset(_device=False)
+
+    def reset(self, _device: bool = True):
+        if _device:
+            self.backend.stream_reset()
+        self.history = np.zeros((0, self.S), np.float32)          # most recent last, at most PREDICTION_HISTORY rows
+        self.raw_scores = np.zeros(self.S, np.float32)
+        self.post_processed_scores = np.zeros(self.S, np.float32)
+
+    def push(self, chunk: np.ndarray, patience: int = 0, threshold: float = 0.0, debounce_time: float = 0.0) -> np.ndarray:
+        """chunk int16 [S, hop] -> post-processed scores [S] (what DetectionResult.score is per stream)."""
+        if not isinstance(chunk, np.ndarray):
+            raise ValueError("Input audio `x` must be a Numpy array.")
+        _, probs = self.backend.stream_push(chunk)
+        raw = probs.astype(np.float32)
+        self.raw_scores = raw
+        score = raw.copy()
+        if self.history.shape[0] < N_WARMUP_PREDICTIONS:
+            score[:] = 0.0
+        if patience or debounce_time > 0:
+            if not threshold:
+                raise ValueError("`threshold` must be provided when using `patience` or `debounce_time`.")
+            if patience and debounce_time > 0:
+                raise ValueError("`patience` and `debounce_time` cannot be used together.")
+            nz = score != 0.0
+            if patience:
+                if self.history.shape[0] < patience:
+                    score[nz] = 0.0
+                else:
+                    tail = self.history[-(patience - 1):] if patience > 1 else self.history
+                    hits = (tail >= threshold).sum(axis=0) + (score >= threshold)
+                    score[nz & (hits < patience)] = 0.0
+            else:
+                k = int(math.ceil(debounce_time / (self.hop / 16000.0)))
+                recent = (self.history[-k:] >= threshold).any(axis=0) if self.history.shape[0] else np.zeros(self.S, bool)
+                score[nz & (score >= threshold) & recent] = 0.0
+        self.history = np.vstack([self.history, score[None]])[-PREDICTION_HISTORY:]
+        self.post_processed_scores = score
+        return score
+
+    def close(self):
+        self.backend.stream_close()

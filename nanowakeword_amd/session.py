@@ -214,6 +214,36 @@ class HipModel:
                                                       C.c_void_p(probs_ptr) if probs_ptr else None,
                                                       C.c_void_p(stream) if stream else None))
 
+    # ------------------------------------------------------------------ batched streaming (rings on the device)
+    def stream_open(self, n_streams: int, window_samples: int = 16000, hop_samples: int = 1280):
+        self._check(self.lib.nww_stream_open(self._h, int(n_streams), int(window_samples), int(hop_samples)))
+        self._stream = (int(n_streams), int(window_samples), int(hop_samples))
+
+    def stream_push(self, chunk):
+        """chunk int16 [S, hop] -> (logits [S], probs [S]); zeros until every stream has a full window."""
+        S, W, hop = self._stream
+        chunk = self._pcm(chunk)
+        if chunk.shape != (S, hop):
+            raise ValueError(f"chunk must have shape ({S}, {hop}), got {chunk.shape}")
+        logits, probs = np.empty(S, np.float32), np.empty(S, np.float32)
+        self._check(self.lib.nww_stream_push(self._h, chunk.ctypes.data_as(C.c_void_p), logits.ctypes.data_as(C.c_void_p),
+                                             probs.ctypes.data_as(C.c_void_p)))
+        return logits, probs
+
+    def stream_push_dev(self, chunk_ptr: int, logits_ptr: int, probs_ptr: int = 0, stream: int = 0):
+        self._check(self.lib.nww_stream_push_dev(self._h, C.c_void_p(chunk_ptr), C.c_void_p(logits_ptr),
+                                                 C.c_void_p(probs_ptr) if probs_ptr else None,
+                                                 C.c_void_p(stream) if stream else None))
+
+    def stream_reset(self):
+        self._check(self.lib.nww_stream_reset(self._h))
+
+    def stream_filled(self) -> int:
+        return int(self.lib.nww_stream_filled(self._h))
+
+    def stream_close(self):
+        self._check(self.lib.nww_stream_close(self._h))
+
     def set_profiling(self, enable: bool = True):
         self._check(self.lib.nww_set_profiling(self._h, int(enable)))
 

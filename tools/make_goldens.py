@@ -285,6 +285,7 @@ def main():
 
     # ---------------------------------------------------------------- predict() state-machine traces
     make_predict_traces(os.path.join(args.out, "predict_trace.json"))
+    make_wire_fixtures(os.path.join(args.out, "wire_messages.json"))
     print("done ->", args.out)
 
 
@@ -359,6 +360,19 @@ def make_predict_traces(path):
     print("predict_trace.json rows:", {k: (len(v["rows"]) if isinstance(v, dict) and "rows" in v else v)
                                        for k, v in traces.items()})
 
+
+
+def make_wire_fixtures(path):
+    """Messages produced by the reference's own encoders (remote_verifier.py:147-158) for tests/test_wire.py."""
+    from nanowakeword.interpreter import remote_verifier as rv
+    from nanowakeword_amd.synth import synth_features, synth_pcm
+    f = synth_features(2, (16, 96), seed=4)
+    a = synth_pcm("noise", 1, 1280, seed=4)[0]
+    out = {"features_shape": [2, 16, 96], "features_seed": 4, "features_hex": rv.encode_features(f).hex(),
+           "audio_n": 1280, "audio_seed": 4, "audio_hex": rv.encode_audio(a).hex(),
+           "tags": {"features": rv._TAG_FEATURES, "mel": rv._TAG_MEL, "audio": rv._TAG_AUDIO},
+           "reply": json.dumps({"score": 0.75})}
+    json.dump(out, open(path, "w"))
 
 if __name__ == "__main__":
     main()

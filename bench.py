@@ -180,6 +180,8 @@ def main():
             algo["conv3x3:conv1"] = ("mfma", B * 2 * 9 * 1 * 16 * (2 * H1) * (2 * W1) / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
             algo["conv3x3:conv2"] = ("mfma", B * 2 * 9 * 16 * 32 * (2 * (H1 // 2)) * (2 * (W1 // 2)) / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
             algo["gemm:fc1"] = ("mfma", B * 2 * 32 * (T // 4) * (n_mels // 4) * 128 / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
+            # fused trunk: conv1 on the 2*H1 x 2*W1 positions that survive the floor pooling + conv2 on 2*H2 x 2*W2
+            algo["trunk:conv1+pool+conv2+pool"] = ("mfma", algo["conv3x3:conv1"][1] + algo["conv3x3:conv2"][1], "TFLOP/s", PEAK_F32_TFLOPS)
         name = dom[0]
         if name in algo:
             bound, work, unit, peak = algo[name]

@@ -50,7 +50,7 @@ size_t trunk_lds_bytes(int C1, int H, int W) {
 template <int C1, int ACT, bool TWO>
 __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P1, int Wp1, int nX, int t,
                                             const float (&breg)[C1 * 9 / 2], float bias2, float al2, float be2,
-                                            bool has_bn, float* outb, int i, int hi, int H2, int W2) {
+                                            bool has_bn, float* outb, int i, int hi, int H2, int W2, int r_off = 0) {
     const int R0 = t / nX, X0 = t - R0 * nX;
     const int t1 = TWO ? t + 1 : t;
     const int R1 = t1 / nX, X1 = t1 - R1 * nX;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
         if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
         else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
         const int pcol = 8 * X + 4 * hi;
-        float* dst = outb + ((size_t)i * H2 + R) * W2 + pcol;
+        float* dst = outb + ((size_t)i * H2 + R + r_off) * W2 + pcol;
         if ((W2 & 3) == 0 && pcol + 3 < W2) {
             *reinterpret_cast<float4*>(dst) = o;
         } else {
@@ -163,29 +163,39 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
 
     // conv2 tiling
     const int nX = (W1 + 15) / 16, nT = H2 * nX;
-    const int t_begin = (nT * wave) / NW, t_end = (nT * (wave + 1)) / NW;
+    // leftover tiles go to waves 0..rem-1, which sit on different SIMDs (waves w and w+4 share one)
+    const int t_base = nT / NW, t_rem = nT - t_base * NW;
+    const int t_begin = wave * t_base + min(wave, t_rem), t_end = t_begin + t_base + (wave < t_rem ? 1 : 0);
     // lane's pixel inside a tile: i = 4*quad + 2*dy + dx  (quad along x)
     const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
     const int lane_off = hi * P1 + dyi * Wp1 + xi;
 
-    __syncthreads();
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        // ---------------- P0: input -> LDS (interior at +1,+1)
-        const float* xin = a.in + (size_t)b * H * W;
-        if ((W & 3) == 0) {
-            for (int q = tid; q < H * W / 4; q += NTHR) {
-                const float4 v = reinterpret_cast<const float4*>(xin)[q];
-                const int idx = q * 4, y = idx / W, x = idx - y * W;
+    // input plane of a clip -> LDS `In` (interior at +1,+1).  The first clip is loaded synchronously; afterwards the
+    // NEXT clip's plane is fetched into registers at the start of conv2 (In is only read by conv1) and written to
+    // LDS when conv2 is done, so its HBM latency hides under the MFMA phase.
+    const bool vec_in = (W & 3) == 0 && (H * W) <= 16 * NTHR;
+    auto store_plane_regs = [&](const float4 (&pre)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx4 = tid + q * NTHR;
+            if (idx4 < H * W / 4) {
+                const int idx = idx4 * 4, y = idx / W, x = idx - y * W;
                 float* d = In + (y + 1) * Wp0 + x + 1;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int idx = tid; idx < H * W; idx += NTHR) {
-                const int y = idx / W, x = idx - y * W;
-                In[(y + 1) * Wp0 + x + 1] = xin[idx];
+                d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
             }
         }
-        __syncthreads();
+    };
+    auto load_plane_sync = [&](const float* xin) {
+        for (int idx = tid; idx < H * W; idx += NTHR) {
+            const int y = idx / W, x = idx - y * W;
+            In[(y + 1) * Wp0 + x + 1] = xin[idx];
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < a.B) load_plane_sync(a.in + (size_t)blockIdx.x * H * W);
+    __syncthreads();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int bnext = b + gridDim.x;
         // ---------------- P1: conv1 + act + pool -> A1 on v_mfma_f32_16x16x4_f32
         // tile = 16 conv1 pixels as 2 rows x 8 columns, pixel i = 4*quad + 2*dy + dx; K = 9 taps padded to 12
         // (3 steps of 4); lane (i = l&15, g = l>>4) feeds tap 4*step + g.  C layout: column = channel l&15,
@@ -230,6 +240,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         __syncthreads();
         // ---------------- P2: conv2 on MFMA; tiles in pairs (two independent accumulators), a lone tile alone
         float* outb = a.out + (size_t)b * C2 * H2 * W2;
+        float4 pre[4];
+        const bool fetch = bnext < a.B;
+        if (fetch && vec_in) {
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx4 = tid + q * NTHR;
+                if (idx4 < H * W / 4) pre[q] = xin4[idx4];
+            }
+        }
         if (!(a.dbg & 2)) {
             int t = t_begin;
             for (; t + 1 < t_end; t += 2)
@@ -237,19 +257,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
             if (t < t_end)
                 conv2_tiles<C1, ACT, false>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
         }
-        __syncthreads();                                     // A1 is free for the next clip's P1
+        if (fetch) {
+            if (vec_in) store_plane_regs(pre);
+            else load_plane_sync(a.in + (size_t)bnext * H * W);
+        }
+        __syncthreads();                                     // A1 is free for the next clip's P1, In holds the next clip
     }
 }
 
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s) {
     if (C1 != 16 || C2 != 32) return hipErrorInvalidValue;
-    const size_t lds = trunk_lds_bytes(C1, a.H, a.W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
     static const int dbg = [] { const char* e = getenv("NWW_TRUNK_DBG"); return e ? atoi(e) : 0; }();
     TrunkArgs aa = a;
     aa.dbg = dbg;
     int grid = a.B < max_grid ? a.B : max_grid;
     if (grid < 1) grid = 1;
+    const size_t lds = trunk_lds_bytes(C1, a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     static size_t attr_for[6] = {0, 0, 0, 0, 0, 0};
     static const int nw = [] { const char* e = getenv("NWW_TRUNK_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
 #define TRUNK_LAUNCH1(ACTV, NWV, SLOT)                                                                             \

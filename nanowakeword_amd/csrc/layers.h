@@ -30,12 +30,17 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
 struct Conv3Args {
     const float* in; const float* w; const float* bias; const float* alpha; const float* beta;
     float* out; int B, Cin, Cout, H, W; int act; int pool;
+    int nhwc_out = 0;     // 1: write [B][Ho][Wo][Cout] (channels last) instead of [B][Cout][Ho][Wo]
 };
 hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
 
 // depthwise 3x3, pad 1, stride (sh, sw), no bias: in [B][C][H][W] -> out [B][C][Ho][Wo]
 hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, int C, int H, int W, int sh, int sw,
                             hipStream_t s);
+// depthwise 3x3, pad 1, stride (sh, sw) on channels-last data: in [B][H][W][C], wt [9][C] (tap-major weights)
+// -> d_out [B][Ho][Wo][C]; xs_out (may be null) receives in[b][oy*sh][ox*sw][c], the input of a strided 1x1 conv.
+hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
+                                 int W, int sh, int sw, hipStream_t s);
 // pointwise 1x1 conv with input stride (sh, sw) on NCHW + (alpha,beta) + act + residual add:
 // out[b][co][y][x] = res + act( (sum_ci w[co][ci] in[b][ci][y*sh][x*sw]) * alpha[co] + beta[co] )
 struct PwArgs {

@@ -26,6 +26,23 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// compile-time variant: a run-time switch costs several scalar branches per element (instruction-fetch bubbles)
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+#define NWW_DISPATCH_ACT(act, CALL)                 \
+    switch (act) {                                  \
+        case ACT_RELU: { CALL(ACT_RELU); break; }   \
+        case ACT_GELU: { CALL(ACT_GELU); break; }   \
+        case ACT_SILU: { CALL(ACT_SILU); break; }   \
+        default: { CALL(ACT_NONE); break; }         \
+    }
+
 // ------------------------------------------------------------------------------------------ GEMM
 // block = 256 threads = 4 waves as 2(M) x 2(N), each wave one 32x32 tile -> 64x64 per block.
 __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
@@ -279,7 +296,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ conv 3x3
-template <int COB, bool POOL>
+template <int COB, bool POOL, int ACT>
 __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3Args a) {
     constexpr int PS = POOL ? 4 : 3;       // input patch edge
     constexpr int NP = POOL ? 4 : 1;       // conv outputs per lane (2x2 quad when pooling)
@@ -339,7 +356,9 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3Args a) {
         }
     }
     if (!valid) return;
-    float* ob = a.out + ((size_t)b * a.Cout + co0) * Ho * Wo + p;
+    const size_t ostride = a.nhwc_out ? 1 : (size_t)Ho * Wo;          // channel stride of the output
+    float* ob = a.nhwc_out ? a.out + ((size_t)b * Ho * Wo + p) * a.Cout + co0
+                           : a.out + ((size_t)b * a.Cout + co0) * Ho * Wo + p;
 #pragma unroll
     for (int co = 0; co < COB; ++co) {
         const float bias = a.bias ? a.bias[co0 + co] : 0.0f;
@@ -349,10 +368,68 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(Conv3Args a) {
         for (int q = 0; q < NP; ++q) {
             float v = acc[q][co] + bias;
             if (a.alpha) v = v * al + be;
-            v = act_apply(v, a.act);
+            v = act_ct<ACT>(v);
             best = (q == 0) ? v : fmaxf(best, v);
         }
-        ob[(size_t)co * Ho * Wo] = best;
+        ob[(size_t)co * ostride] = best;
+    }
+}
+
+// Cin = 1, 3x3, pad 1, + folded BN/bias + act + MaxPool2, channels-last output [B][Ho][Wo][Cout].
+// lane = (position, channel group of 8): the Cout/8 lanes of a position are adjacent, so a position's Cout floats
+// leave as one contiguous run (the generic kernel wrote 32-byte pieces at a Cout*4-byte stride: 3.0 ms -> see
+// DESIGN.md).  A thread keeps its 72 weights in registers and walks positions grid-stride.
+template <int ACT>
+__global__ void __launch_bounds__(256) conv3x3_c1_pool_nhwc_kernel(Conv3Args a) {
+    const int Ho = a.H / 2, Wo = a.W / 2, G = a.Cout / 8;
+    const int cg = threadIdx.x % G;
+    const int co0 = cg * 8;
+    float w[8][9], bias[8], al[8], be[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[co][t] = a.w[(size_t)(co0 + co) * 9 + t];
+        bias[co] = a.bias ? a.bias[co0 + co] : 0.0f;
+        al[co] = a.alpha ? a.alpha[co0 + co] : 1.0f;
+        be[co] = a.alpha ? a.beta[co0 + co] : 0.0f;
+    }
+    const size_t npos = (size_t)a.B * Ho * Wo;
+    const size_t ppb = 256 / G;                                  // positions per block iteration
+    for (size_t pos = (size_t)blockIdx.x * ppb + threadIdx.x / G; pos < npos; pos += (size_t)gridDim.x * ppb) {
+        const size_t b = pos / ((size_t)Ho * Wo);
+        const int p = (int)(pos - b * Ho * Wo);
+        const int oy = p / Wo, ox = p - oy * Wo;
+        const float* in = a.in + b * (size_t)a.H * a.W;
+        float patch[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int yy = 2 * oy - 1 + r, xx = 2 * ox - 1 + c;
+                const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                patch[r][c] = ok ? in[yy * a.W + xx] : 0.0f;
+            }
+        float outv[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float wv = w[co][dy * 3 + dx];
+                    s00 = fmaf(patch[dy][dx], wv, s00);
+                    s01 = fmaf(patch[dy][dx + 1], wv, s01);
+                    s10 = fmaf(patch[dy + 1][dx], wv, s10);
+                    s11 = fmaf(patch[dy + 1][dx + 1], wv, s11);
+                }
+            float v0 = s00 + bias[co], v1 = s01 + bias[co], v2 = s10 + bias[co], v3 = s11 + bias[co];
+            if (a.alpha) { v0 = v0 * al[co] + be[co]; v1 = v1 * al[co] + be[co]; v2 = v2 * al[co] + be[co]; v3 = v3 * al[co] + be[co]; }
+            outv[co] = fmaxf(fmaxf(act_ct<ACT>(v0), act_ct<ACT>(v1)), fmaxf(act_ct<ACT>(v2), act_ct<ACT>(v3)));
+        }
+        float4* dst = reinterpret_cast<float4*>(a.out + pos * a.Cout + co0);
+        dst[0] = make_float4(outv[0], outv[1], outv[2], outv[3]);
+        dst[1] = make_float4(outv[4], outv[5], outv[6], outv[7]);
     }
 }
 
@@ -361,12 +438,25 @@ static hipError_t launch_conv3x3_cob(const Conv3Args& a, hipStream_t s) {
     const int Ho = a.pool ? a.H / 2 : a.H, Wo = a.pool ? a.W / 2 : a.W;
     if (Ho <= 0 || Wo <= 0) return hipErrorInvalidValue;
     dim3 grid((Ho * Wo + 255) / 256, a.Cout / COB, a.B);
-    if (a.pool) hipLaunchKernelGGL((conv3x3_kernel<COB, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<COB, false>), grid, dim3(256), 0, s, a);
+#define CONV_CALL(A)                                                                              \
+    if (a.pool) hipLaunchKernelGGL((conv3x3_kernel<COB, true, A>), grid, dim3(256), 0, s, a);     \
+    else hipLaunchKernelGGL((conv3x3_kernel<COB, false, A>), grid, dim3(256), 0, s, a)
+    NWW_DISPATCH_ACT(a.act, CONV_CALL)
+#undef CONV_CALL
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s) {
+    if (a.nhwc_out && a.pool && a.Cin == 1 && a.Cout % 8 == 0 && 256 % (a.Cout / 8) == 0 && a.H >= 2 && a.W >= 2) {
+        const size_t npos = (size_t)a.B * (a.H / 2) * (a.W / 2);
+        const size_t ppb = 256 / (a.Cout / 8);
+        size_t grid = (npos + ppb - 1) / ppb;
+        if (grid > 256 * 16) grid = 256 * 16;
+#define C1_CALL(A) hipLaunchKernelGGL((conv3x3_c1_pool_nhwc_kernel<A>), dim3((unsigned)grid), dim3(256), 0, s, a)
+        NWW_DISPATCH_ACT(a.act, C1_CALL)
+#undef C1_CALL
+        return hipGetLastError();
+    }
     static const int cob_env = [] { const char* e = getenv("NWW_CONV_COB"); return e ? atoi(e) : 0; }();
     // pooled convs: 8 output channels per lane keep the 72 per-channel weights in SGPRs (16 spill them)
     const int want = cob_env ? cob_env : (a.pool ? 8 : 16);
@@ -410,6 +500,44 @@ hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, 
     const size_t total = (size_t)B * C * Ho * Wo;
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, w, out, C, H, W,
                        Ho, Wo, sh, sw, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+dwconv3x3_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ d_out,
+                      float* __restrict__ xs_out, int C, int H, int W, int Ho, int Wo, int sh, int sw, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // ((b*Ho + oy)*Wo + ox)*C + c : lanes = channels
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    size_t t = idx / C;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const size_t b = t / Ho;
+    const float* ip = in + b * (size_t)H * W * C + c;
+    float acc = 0.0f, centre = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy * sh - 1 + dy;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = ox * sw - 1 + dx;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float v = ok ? ip[((size_t)yy * W + xx) * C] : 0.0f;
+            if (dy == 1 && dx == 1) centre = v;                  // in[b][oy*sh][ox*sw][c]: always in range
+            acc = fmaf(v, wt[(dy * 3 + dx) * C + c], acc);
+        }
+    }
+    d_out[idx] = acc;
+    if (xs_out) xs_out[idx] = centre;
+}
+
+hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
+                                 int W, int sh, int sw, hipStream_t s) {
+    const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    hipLaunchKernelGGL(dwconv3x3_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, wt, d_out,
+                       xs_out, C, H, W, Ho, Wo, sh, sw, total);
     return hipGetLastError();
 }
 

@@ -398,11 +398,12 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
 }
 
 void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
-              const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool) {
+              const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool, int nhwc_out = 0) {
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
     p.need(out_id, (size_t)Cout * Ho * Wo);
     p.add("conv3x3:" + name, [=](Run& r) {
         Conv3Args a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, Cin, Cout, H, W, act, pool};
+        a.nhwc_out = nhwc_out;
         return launch_conv3x3(a, r.stream);
     });
 }
@@ -486,6 +487,20 @@ extern "C" int nww_finalize(nww_handle* h) {
         h->tensors[p + ".alpha"] = al;
         h->tensors[p + ".beta"] = be;
     }
+    // ---- depthwise 3x3 weights tap-major [9][C] for the channels-last kernels (BcResNet)
+    if (c.head_type == NWW_HEAD_BCRESNET)
+        for (int i = 1; i <= 3; ++i) {
+            const std::string k = "model.block" + std::to_string(i) + ".depthwise.weight";
+            const HostTensor& w = h->tensors[k];
+            const int C = (int)w.shape[0];
+            HostTensor wt;
+            wt.shape = {9, C};
+            wt.data.resize((size_t)9 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int tap = 0; tap < 9; ++tap) wt.data[(size_t)tap * C + ch] = w.data[(size_t)ch * 9 + tap];
+            wt.loaded = true;
+            h->tensors[k + "_t"] = wt;
+        }
     // ---- weight arena (each tensor 16-byte aligned)
     size_t total = 0;
     for (auto& kv : h->tensors) {
@@ -599,8 +614,11 @@ extern "C" int nww_finalize(nww_handle* h) {
             add_gemm(p, "fc", 4, -2, 1, E, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
             break;
         }
-        case NWW_HEAD_BCRESNET: {                 // BcResNetModel: architectures.py:620-687
-            add_conv(p, "init_conv", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1);
+        case NWW_HEAD_BCRESNET: {                 // BcResNetModel: architectures.py:620-687, channels-last on the GPU
+            // init conv (+BN+act+pool) writes [B][H1][W1][32]; each block: one depthwise kernel emits d = dw3x3(x) and
+            // xs = x at the strided centres, then two MFMA GEMMs over M = B*Ho*Wo pixels:
+            //   R = BN_s(xs . Wsc^T) ;  out = act(BN_1(d . Wpw^T)) + R      (activation BEFORE the residual add, :646-647)
+            add_conv(p, "init_conv(nhwc)", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1, 1);
             int hh = T / 2, ww = F / 2, cur = 0;
             const int ch[4] = {32, 64, 128, 256};
             const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};
@@ -608,26 +626,18 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const std::string q = "model.block" + std::to_string(i);
                 const int ci = ch[i - 1], co = ch[i], sh = st[i - 1][0], sw = st[i - 1][1];
                 const int ho = (hh - 1) / sh + 1, wo = (ww - 1) / sw + 1;
-                const int resb = 2, dwb = 3, outb = cur ^ 1;
-                p.need(resb, (size_t)co * ho * wo); p.need(dwb, (size_t)ci * ho * wo); p.need(outb, (size_t)co * ho * wo);
-                const float *scw = p.W(q + ".shortcut.0.weight"), *sca = p.W(q + ".shortcut.1.alpha"), *scb = p.W(q + ".shortcut.1.beta");
-                const float *dww = p.W(q + ".depthwise.weight"), *pww = p.W(q + ".pointwise.weight");
-                const float *ba = p.W(q + ".bn1.alpha"), *bb = p.W(q + ".bn1.beta");
+                const int dwb = 2, xsb = 3, resb = 4, outb = cur ^ 1;
+                p.need(dwb, (size_t)ci * ho * wo); p.need(xsb, (size_t)ci * ho * wo);
+                const float* dwt = p.W(q + ".depthwise.weight_t");
                 const int hin = hh, win = ww;
-                p.add("pwconv:" + q + ".shortcut", [=](Run& r) {
-                    PwArgs a{r.buf[cur], scw, sca, scb, nullptr, r.buf[resb], r.B, ci, co, hin, win, sh, sw, ACT_NONE};
-                    return launch_pwconv(a, r.stream);
-                });
-                p.add("dwconv3x3:" + q, [=](Run& r) { return launch_dwconv3x3(r.buf[cur], dww, r.buf[dwb], r.B, ci, hin, win, sh, sw, r.stream); });
-                p.add("pwconv:" + q + ".pointwise+bn+act+res", [=](Run& r) {
-                    PwArgs a{r.buf[dwb], pww, ba, bb, r.buf[resb], r.buf[outb], r.B, ci, co, ho, wo, 1, 1, act};
-                    return launch_pwconv(a, r.stream);
-                });
+                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
+                add_gemm(p, q + ".shortcut(1x1)+bn", xsb, resb, ho * wo, co, ci, p.W(q + ".shortcut.0.weight"), nullptr, ACT_NONE, p.W(q + ".shortcut.1.alpha"), p.W(q + ".shortcut.1.beta"));
+                add_gemm(p, q + ".pointwise(1x1)+bn+act+res", dwb, outb, ho * wo, co, ci, p.W(q + ".pointwise.weight"), nullptr, act, p.W(q + ".bn1.alpha"), p.W(q + ".bn1.beta"), resb, 1.0f);
                 hh = ho; ww = wo; cur = outb;
             }
             const int hw = hh * ww;
             p.need(2, 256);
-            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_last(r.buf[cur], r.buf[2], r.B * 256, hw, r.stream); });
+            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream); });
             add_gemm(p, "fc", 2, -2, 1, E, 256, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
             break;
         }

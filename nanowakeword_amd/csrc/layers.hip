@@ -662,8 +662,45 @@ avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int
         for (int x = 0; x < kw; ++x) s += p[y * W + x];
     out[idx] = s / (float)(kh * kw);
 }
+// one wave per [H][W] plane, coalesced reads, up to 8 (possibly overlapping) windows accumulated per lane and
+// reduced across the wave (the one-thread-per-output kernel above strides through the plane: 0.32 ms for the E2E head)
+__global__ void __launch_bounds__(256)
+avgpool_plane_kernel(const float* __restrict__ in, float* __restrict__ out, int BC, int H, int W, int kh, int kw, int sh,
+                     int sw, int oh, int ow) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= BC) return;
+    const float* p = in + (size_t)plane * H * W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    const int nwin = oh * ow;
+    for (int idx = lane; idx < H * W; idx += 64) {
+        const int y = idx / W, x = idx - y * W;
+        const float v = p[idx];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nwin) {
+                const int wy = (j / ow) * sh, wx = (j % ow) * sw;
+                if (y >= wy && y < wy + kh && x >= wx && x < wx + kw) acc[j] += v;
+            }
+        }
+    }
+    const float inv = 1.0f / (float)(kh * kw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < nwin) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0) out[(size_t)plane * nwin + j] = s * inv;
+        }
+    }
+}
+
 hipError_t launch_avgpool(const float* in, float* out, int BC, int H, int W, int kh, int kw, int sh, int sw, int oh,
                           int ow, hipStream_t s) {
+    if (oh * ow <= 8) {
+        hipLaunchKernelGGL(avgpool_plane_kernel, dim3((BC + 3) / 4), dim3(256), 0, s, in, out, BC, H, W, kh, kw, sh, sw, oh, ow);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)BC * oh * ow;
     hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, H, W, kh, kw,
                        sh, sw, oh, ow, total);

@@ -423,6 +423,23 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
     return true;
 }
 
+// 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
+bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
+                   const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool) {
+    static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+    if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
+        conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
+        return false;
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    p.need(out_id, (size_t)Cout * Ho * Wo);
+    const int max_grid = p.h->cu_count;
+    p.add("conv3x3_mfma:" + name, [=](Run& r) {
+        ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+        return launch_conv3x3_mfma(a, Cin, max_grid, r.stream);
+    });
+    return true;
+}
+
 // nn.GRU(bidirectional) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers xg_id, seqA, seqB.
 void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int I, int H, int layers, int xg_id,
                     int seqA, int seqB, int last_id) {
@@ -573,7 +590,8 @@ extern "C" int nww_finalize(nww_handle* h) {
             for (int i = first; i < 3; ++i) {
                 const std::string cw = "model.conv_block." + std::to_string(4 * i), bnp = "model.conv_block." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
-                add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
+                if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2))
+                    add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
                 if (i < 2) { hh /= 2; ww /= 2; }
                 cin = ch[i]; cur = out;
             }
@@ -598,7 +616,8 @@ extern "C" int nww_finalize(nww_handle* h) {
             for (int i = first; i < c.n_crnn_channels; ++i) {
                 const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
-                add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
+                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1))
+                    add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
                 hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
             }
             if (hh < 1 || ww < 1) return fail(h, NWW_ERR_INVALID, "crnn input too small for the conv stack");

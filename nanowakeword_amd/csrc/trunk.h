@@ -13,3 +13,12 @@ struct TrunkArgs {
 };
 size_t trunk_lds_bytes(int C1, int H, int W);
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s);
+
+// standalone 3x3 conv (pad 1, stride 1) + bias/BN + act (+ MaxPool2) on MFMA f32 for C1 = 32 input channels and
+// Cout a multiple of 32: in [B][32][H][W] -> out [B][Cout][H or H/2][W or W/2]; one workgroup per clip, input staged in LDS.
+struct ConvMfmaArgs {
+    const float* in; const float* w; const float *bias, *alpha, *beta; float* out;
+    int B, H, W, Cout, act, pool;
+};
+size_t conv_mfma_lds_bytes(int C1, int H, int W);
+hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);

@@ -47,10 +47,12 @@ size_t trunk_lds_bytes(int C1, int H, int W) {
 
 // conv2 for tile t (and t+1 when TWO): 32 pixels x 32 channels x K = C1*9 each, A operands prefetched one channel
 // pair ahead of the MFMAs that consume them, then bias/BN/act, in-lane 2x2 max, half-wave exchange, 16-byte store.
-template <int C1, int ACT, bool TWO>
+template <int C1, int ACT, bool TWO, bool POOL = true>
 __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P1, int Wp1, int nX, int t,
                                             const float (&breg)[C1 * 9 / 2], float bias2, float al2, float be2,
                                             bool has_bn, float* outb, int i, int hi, int H2, int W2, int r_off = 0) {
+    // POOL: outb = [cout][H2][W2] pooled planes (H2, W2 pooled sizes).  !POOL: outb = [cout][H2][W2] with H2, W2 the
+    // conv output sizes; the tile still covers conv rows 2R, 2R+1 and 16 columns.
     const int R0 = t / nX, X0 = t - R0 * nX;
     const int t1 = TWO ? t + 1 : t;
     const int R1 = t1 / nX, X1 = t1 - R1 * nX;
@@ -91,33 +93,62 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
     for (int which = 0; which < (TWO ? 2 : 1); ++which) {
         const f32x16& acc = which ? acc1 : acc0;
         const int R = which ? R1 : R0, X = which ? X1 : X0;
-        float own[4];
+        if (POOL) {
+            float own[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float m = -INFINITY;
+            for (int k = 0; k < 4; ++k) {
+                float m = -INFINITY;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = acc[4 * k + q] + bias2;
-                if (has_bn) v = v * al2 + be2;
-                m = fmaxf(m, trunk_act<ACT>(v));
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[4 * k + q] + bias2;
+                    if (has_bn) v = v * al2 + be2;
+                    m = fmaxf(m, trunk_act<ACT>(v));
+                }
+                own[k] = m;                              // pooled column 8X + 2k + hi
             }
-            own[k] = m;                              // pooled column 8X + 2k + hi
-        }
-        // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
-        const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
-        const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-        float4 o;
-        if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
-        else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
-        const int pcol = 8 * X + 4 * hi;
-        float* dst = outb + ((size_t)i * H2 + R + r_off) * W2 + pcol;
-        if ((W2 & 3) == 0 && pcol + 3 < W2) {
-            *reinterpret_cast<float4*>(dst) = o;
+            // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
+            const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
+            const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+            float4 o;
+            if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
+            else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
+            const int pcol = 8 * X + 4 * hi;
+            float* dst = outb + ((size_t)i * H2 + R + r_off) * W2 + pcol;
+            if ((W2 & 3) == 0 && pcol + 3 < W2) {
+                *reinterpret_cast<float4*>(dst) = o;
+            } else {
+                if (pcol + 0 < W2) dst[0] = o.x;
+                if (pcol + 1 < W2) dst[1] = o.y;
+                if (pcol + 2 < W2) dst[2] = o.z;
+                if (pcol + 3 < W2) dst[3] = o.w;
+            }
         } else {
-            if (pcol + 0 < W2) dst[0] = o.x;
-            if (pcol + 1 < W2) dst[1] = o.y;
-            if (pcol + 2 < W2) dst[2] = o.z;
-            if (pcol + 3 < W2) dst[3] = o.w;
+            // un-pooled: quad k of this lane = columns 16X + 4k + 2hi + {0,1} of rows 2R, 2R+1.  Exchange with the
+            // partner half-wave so half 0 owns row 2R and half 1 row 2R+1, 4 consecutive columns per quad.
+            const int y = 2 * (R + r_off) + hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t2 = acc[4 * k + q] + bias2;
+                    if (has_bn) t2 = t2 * al2 + be2;
+                    v[q] = trunk_act<ACT>(t2);               // q = 2*dy + dx
+                }
+                const float s0 = hi ? v[0] : v[2], s1 = hi ? v[1] : v[3];   // half 0 gives away row 2R+1, half 1 row 2R
+                const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+                float4 o;
+                if (hi == 0) { o.x = v[0]; o.y = v[1]; o.z = r0; o.w = r1; }      // row 2R  : cols 4k..4k+3
+                else         { o.x = r0; o.y = r1; o.z = v[2]; o.w = v[3]; }      // row 2R+1: cols 4k..4k+3
+                const int col = 16 * X + 4 * k;
+                if (y < H2) {
+                    float* dst = outb + ((size_t)i * H2 + y) * W2 + col;
+                    if (col + 0 < W2) dst[0] = o.x;
+                    if (col + 1 < W2) dst[1] = o.y;
+                    if (col + 2 < W2) dst[2] = o.z;
+                    if (col + 3 < W2) dst[3] = o.w;
+                }
+            }
         }
     }
 }
@@ -263,6 +294,87 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         }
         __syncthreads();                                     // A1 is free for the next clip's P1, In holds the next clip
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Standalone MFMA conv for the third conv stage of the E2E mel-CNN (32->64, un-pooled; architectures.py:851-853) and
+// of CRNN (32->32, pooled; :217-225): same tile routine as conv2 above with K = 32*9 (144 B fragments per wave).
+// One workgroup per clip: the [32][H][W] input is staged into a zero-haloed LDS plane set with coalesced loads; the
+// 8 waves split into Cout/32 groups (one 32-channel N tile each) and share the tiles of their group.
+size_t conv_mfma_lds_bytes(int C1, int H, int W) { return ((size_t)C1 * (H + 3) * (W + 2) + 64) * sizeof(float); }
+
+template <int C1, int ACT, bool POOL, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) conv3x3_mfma_kernel(ConvMfmaArgs a) {
+    constexpr int NTHR = 64 * NW, KS = C1 * 9 / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, W = a.W, Wp = W + 2, P = (H + 3) * Wp;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    const int ngroups = a.Cout / 32, gsz = NW / ngroups;           // waves per 32-channel group
+    const int grp = wave / gsz, wg = wave - grp * gsz;
+    for (int k = tid; k < C1 * P + 64; k += NTHR) lds[k] = 0.0f;
+    float breg[KS];
+    const int cout = 32 * grp + i;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c2 = s / 9, tap = s - c2 * 9;
+        breg[s] = a.w[((size_t)cout * C1 + 2 * c2 + hi) * 9 + tap];
+    }
+    const float bias = a.bias ? a.bias[cout] : 0.0f;
+    const float al = a.alpha ? a.alpha[cout] : 1.0f, be = a.alpha ? a.beta[cout] : 0.0f;
+    const bool bn = a.alpha != nullptr;
+    const int nRp = POOL ? H / 2 : (H + 1) / 2, nX = (W + 15) / 16, nT = nRp * nX;
+    const int t_base = nT / gsz, t_rem = nT - t_base * gsz;
+    const int t_begin = wg * t_base + min(wg, t_rem), t_end = t_begin + t_base + (wg < t_rem ? 1 : 0);
+    const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
+    const int lane_off = hi * P + dyi * Wp + xi;
+    __syncthreads();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float* xin = a.in + (size_t)b * C1 * H * W;
+        for (int idx = tid; idx < C1 * H * W; idx += NTHR) {       // coalesced along x; interior at (+1,+1)
+            const int c = idx / (H * W), r = idx - c * H * W, y = r / W, x = r - y * W;
+            lds[c * P + (y + 1) * Wp + x + 1] = xin[idx];
+        }
+        __syncthreads();
+        float* outb = a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
+        int t = t_begin;
+        for (; t + 1 < t_end; t += 2)
+            conv2_tiles<C1, ACT, true, POOL>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo);
+        if (t < t_end)
+            conv2_tiles<C1, ACT, false, POOL>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s) {
+    if (C1 != 32 || a.Cout % 32 != 0 || (8 % (a.Cout / 32)) != 0) return hipErrorInvalidValue;
+    const size_t lds = conv_mfma_lds_bytes(C1, a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    int grid = a.B < max_grid ? a.B : max_grid;
+    if (grid < 1) grid = 1;
+    static size_t attr[6] = {0, 0, 0, 0, 0, 0};
+#define CM_LAUNCH(ACTV, POOLV, SLOT)                                                                                   \
+    {                                                                                                                  \
+        if (lds > attr[SLOT]) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            if (e != hipSuccess) return e;                                                                             \
+            attr[SLOT] = lds;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), dim3(grid), dim3(512), lds, s, a);               \
+    }
+#define CM_ACT(ACTV, BASE)                                   \
+    if (a.pool) CM_LAUNCH(ACTV, true, BASE) else CM_LAUNCH(ACTV, false, BASE + 3)
+    switch (a.act) {
+        case ACT_RELU: CM_ACT(ACT_RELU, 0) break;
+        case ACT_GELU: CM_ACT(ACT_GELU, 1) break;
+        case ACT_SILU: CM_ACT(ACT_SILU, 2) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CM_ACT
+#undef CM_LAUNCH
+    return hipGetLastError();
 }
 
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s) {

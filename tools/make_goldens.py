@@ -286,6 +286,7 @@ def main():
     # ---------------------------------------------------------------- predict() state-machine traces
     make_predict_traces(os.path.join(args.out, "predict_trace.json"))
     make_wire_fixtures(os.path.join(args.out, "wire_messages.json"))
+    make_audio_features_traces(os.path.join(args.out, "audio_features_trace.json"))
     print("done ->", args.out)
 
 
@@ -373,6 +374,66 @@ def make_wire_fixtures(path):
            "tags": {"features": rv._TAG_FEATURES, "mel": rv._TAG_MEL, "audio": rv._TAG_AUDIO},
            "reply": json.dumps({"score": 0.75})}
     json.dump(out, open(path, "w"))
+
+
+def make_audio_features_traces(path):
+    """Drive the reference AudioFeatures (nanowakeword/data/AudioFeatures.py) with deterministic fake ORT sessions
+    and record its streaming / batch behaviour for tests/test_audio_features.py."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from fake_models import fake_embed, fake_mel
+    ort = types.ModuleType("onnxruntime")
+
+    class SessionOptions:
+        inter_op_num_threads = 0
+        intra_op_num_threads = 0
+
+    class InferenceSession:
+        def __init__(self, path, sess_options=None, providers=None):
+            self.kind = "mel" if "mel" in os.path.basename(str(path)) else "emb"
+            self.providers = providers or ["CPUExecutionProvider"]
+
+        def get_providers(self):
+            return self.providers
+
+        def run(self, names, feed):
+            if self.kind == "mel":
+                return [fake_mel(feed["input"])]
+            return [fake_embed(feed["input_1"])]
+
+    ort.SessionOptions, ort.InferenceSession = SessionOptions, InferenceSession
+    sys.modules["onnxruntime"] = ort
+    import nanowakeword.interpreter.models as ref_models_pkg
+    import nanowakeword.data.AudioFeatures as AF
+
+    class _Models:
+        melspectrogram_onnx = "melspectrogram.onnx"
+        embedding_model_onnx = "embedding_model.onnx"
+    AF.models = _Models()
+    from nanowakeword_amd.synth import synth_pcm
+    np.random.seed(1234)
+    af = AF.AudioFeatures()
+    stream = synth_pcm("noise", 1, 16000 * 3, seed=21)[0]
+    sizes = [1280, 400, 880, 1280, 2560, 300, 1280, 3000, 1280, 1280, 640, 640, 5000, 1280]
+    rows, pos = [], 0
+    for n in sizes:
+        r = af(stream[pos:pos + n]); pos += n
+        rows.append({"n": n, "ret": int(r), "feat_shape": list(af.feature_buffer.shape),
+                     "mel_shape": list(af.melspectrogram_buffer.shape),
+                     "feat_last_sum": float(np.asarray(af.feature_buffer[-1], np.float64).sum()),
+                     "feat_sum": float(np.asarray(af.feature_buffer, np.float64).sum()),
+                     "acc": int(af.accumulated_samples), "rem": int(af.raw_data_remainder.shape[0])})
+    gf = af.get_features(16)
+    clips = synth_pcm("noise", 3, 32000, seed=22)
+    emb = af.embed_clips(clips, batch_size=2, ncpu=1)
+    np.random.seed(99)
+    shape2 = list(af.get_embedding_shape(2.0))
+    out = {"seed": 1234, "sizes": sizes, "rows": rows, "get_features_shape": list(gf.shape),
+           "get_features_sum": float(gf.astype(np.float64).sum()),
+           "embed_clips_shape": list(emb.shape), "embed_clips_sum": float(emb.astype(np.float64).sum()),
+           "embed_clips_row": [float(v) for v in emb[1, 3, :8]], "embedding_shape_2s": shape2}
+    json.dump(out, open(path, "w"), indent=1)
+    print("audio_features_trace.json:", out["embed_clips_shape"], shape2, rows[-1])
+
 
 if __name__ == "__main__":
     main()

@@ -83,11 +83,15 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
                 if (TWO) nb[tap] = qb[off];
             }
         }
+        // keep the next pair's LDS reads ABOVE this pair's MFMAs (hipcc otherwise sinks each read to one MFMA before
+        // its use and waits on it at once, exposing the LDS latency on every step)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[tap], breg[c2 * 9 + tap], acc0, 0, 0, 0);
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[tap], breg[c2 * 9 + tap], acc1, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int which = 0; which < (TWO ? 2 : 1); ++which) {
@@ -283,6 +287,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         }
         if (!(a.dbg & 2)) {
             int t = t_begin;
+            // The two waves of a SIMD (w and w + NW/2) would otherwise run in lock-step: MFMA phases overlapping (each at
+            // half rate) and epilogue/prologue gaps overlapping too (pipe idle).  The upper half starts with one single
+            // tile, which puts it half an iteration out of phase so one wave's gaps fall under the other's MFMAs.
+            if (wave >= NW / 2 && t < t_end) {
+                conv2_tiles<C1, ACT, false>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
+                t += 1;
+            }
             for (; t + 1 < t_end; t += 2)
                 conv2_tiles<C1, ACT, true>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
             if (t < t_end)

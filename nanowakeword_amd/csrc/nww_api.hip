@@ -425,16 +425,18 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 
 // 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
-                   const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool) {
+                   const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0) {
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
         return false;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    p.need(out_id, (size_t)Cout * Ho * Wo);
+    p.need(out_id, avg_ow > 0 ? (size_t)Cout * avg_ow : (size_t)Cout * Ho * Wo);
     const int max_grid = p.h->cu_count;
-    p.add("conv3x3_mfma:" + name, [=](Run& r) {
+    p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
         ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+        a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
         return launch_conv3x3_mfma(a, Cin, max_grid, r.stream);
     });
     return true;
@@ -582,6 +584,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int ch[3] = {16, 32, 64};
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
             int first = 0;
+            bool fused_pool = false;
             if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
                           p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act)) {
@@ -590,6 +593,15 @@ extern "C" int nww_finalize(nww_handle* h) {
             for (int i = first; i < 3; ++i) {
                 const std::string cw = "model.conv_block." + std::to_string(4 * i), bnp = "model.conv_block." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
+                if (i == 2 && ww >= 4) {
+                    // conv3 + AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form, fused when the MFMA kernel applies
+                    const int sw4 = ww / 4, kw4 = ww - 3 * sw4;
+                    static const int fuse = [] { const char* e = getenv("NWW_E2E_FUSE_POOL"); return e ? atoi(e) : 1; }();
+                    if (fuse && add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4)) {
+                        fused_pool = true; cin = ch[i]; cur = out;
+                        continue;
+                    }
+                }
                 if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2))
                     add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
                 if (i < 2) { hh /= 2; ww /= 2; }
@@ -598,10 +610,16 @@ extern "C" int nww_finalize(nww_handle* h) {
             if (hh < 1 || ww < 4) return fail(h, NWW_ERR_INVALID, "e2e_dnn input too small for AdaptiveAvgPool2d((1,4))");
             // AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form (_export/onnx.py:146-152)
             const int sh = hh / 1, kh = hh, sw = ww / 4, kw = ww - 3 * sw;
-            p.need(1, 256);
-            p.add("avgpool:export(1,4)", [=](Run& r) { return launch_avgpool(r.buf[0], r.buf[1], r.B * 64, hh, ww, kh, kw, sh, sw, 1, 4, r.stream); });
-            add_gemm(p, "fc1+bn1", 1, 0, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
-            add_gemm(p, "out", 0, -2, 1, E, 128, p.W("model.out.weight"), p.W("model.out.bias"), ACT_NONE);
+            int fc_in = cur;                                  // buffer holding [B][256] after the pool
+            if (!fused_pool) {
+                const int pin = cur, pout = cur ^ 1;
+                p.need(pout, 256);
+                p.add("avgpool:export(1,4)", [=](Run& r) { return launch_avgpool(r.buf[pin], r.buf[pout], r.B * 64, hh, ww, kh, kw, sh, sw, 1, 4, r.stream); });
+                fc_in = pout;
+            }
+            const int fc_out = fc_in ^ 1;
+            add_gemm(p, "fc1+bn1", fc_in, fc_out, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
+            add_gemm(p, "out", fc_out, -2, 1, E, 128, p.W("model.out.weight"), p.W("model.out.bias"), ACT_NONE);
             break;
         }
         case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287

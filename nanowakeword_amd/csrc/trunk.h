@@ -19,6 +19,8 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
 struct ConvMfmaArgs {
     const float* in; const float* w; const float *bias, *alpha, *beta; float* out;
     int B, H, W, Cout, act, pool;
+    // fused AvgPool2d(kernel (H, avg_kw), stride (H, avg_sw)) -> out [B][Cout][avg_ow] when avg_ow > 0 (pool must be 0)
+    int avg_kw = 0, avg_sw = 0, avg_ow = 0;
 };
 size_t conv_mfma_lds_bytes(int C1, int H, int W);
 hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);

@@ -47,10 +47,13 @@ size_t trunk_lds_bytes(int C1, int H, int W) {
 
 // conv2 for tile t (and t+1 when TWO): 32 pixels x 32 channels x K = C1*9 each, A operands prefetched one channel
 // pair ahead of the MFMAs that consume them, then bias/BN/act, in-lane 2x2 max, half-wave exchange, 16-byte store.
-template <int C1, int ACT, bool TWO, bool POOL = true>
+struct AvgWin { int kw, sw, ow; };       // windows [j*sw, j*sw + kw) along x, j < ow <= 4, covering all rows (oh == 1)
+
+template <int C1, int ACT, bool TWO, bool POOL = true, bool AVG = false>
 __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P1, int Wp1, int nX, int t,
                                             const float (&breg)[C1 * 9 / 2], float bias2, float al2, float be2,
-                                            bool has_bn, float* outb, int i, int hi, int H2, int W2, int r_off = 0) {
+                                            bool has_bn, float* outb, int i, int hi, int H2, int W2, int r_off = 0,
+                                            float* wsum = nullptr, AvgWin aw = AvgWin{0, 0, 0}) {
     // POOL: outb = [cout][H2][W2] pooled planes (H2, W2 pooled sizes).  !POOL: outb = [cout][H2][W2] with H2, W2 the
     // conv output sizes; the tile still covers conv rows 2R, 2R+1 and 16 columns.
     const int R0 = t / nX, X0 = t - R0 * nX;
@@ -126,6 +129,24 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
                 if (pcol + 2 < W2) dst[2] = o.z;
                 if (pcol + 3 < W2) dst[3] = o.w;
             }
+        } else if (AVG) {
+            // fused AvgPool over full-height windows along x (the export form of AdaptiveAvgPool2d((1, ow)),
+            // _export/onnx.py:146-152): every lane adds its activated outputs to the windows they fall in; the
+            // caller reduces the per-lane sums in a fixed order.  The conv output itself never reaches HBM.
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[4 * k + q] + bias2;
+                    if (has_bn) v = v * al2 + be2;
+                    v = trunk_act<ACT>(v);
+                    const int y = 2 * (R + r_off) + (q >> 1), x = 16 * X + 4 * k + 2 * hi + (q & 1);
+                    if (y < H2 && x < W2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < aw.ow && x >= j * aw.sw && x < j * aw.sw + aw.kw) wsum[j] += v;
+                    }
+                }
         } else {
             // un-pooled: quad k of this lane = columns 16X + 4k + 2hi + {0,1} of rows 2R, 2R+1.  Exchange with the
             // partner half-wave so half 0 owns row 2R and half 1 row 2R+1, 4 consecutive columns per quad.
@@ -314,7 +335,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
 // 8 waves split into Cout/32 groups (one 32-channel N tile each) and share the tiles of their group.
 size_t conv_mfma_lds_bytes(int C1, int H, int W) { return ((size_t)C1 * (H + 3) * (W + 2) + 64) * sizeof(float); }
 
-template <int C1, int ACT, bool POOL, int NW>
+template <int C1, int ACT, bool POOL, int NW, bool AVG = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) conv3x3_mfma_kernel(ConvMfmaArgs a) {
     constexpr int NTHR = 64 * NW, KS = C1 * 9 / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -349,12 +370,34 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv3x3_mfma_kernel(ConvMfmaA
         }
         __syncthreads();
         float* outb = a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
+        float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+        const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow};
         int t = t_begin;
         for (; t + 1 < t_end; t += 2)
-            conv2_tiles<C1, ACT, true, POOL>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo);
+            conv2_tiles<C1, ACT, true, POOL, AVG>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
         if (t < t_end)
-            conv2_tiles<C1, ACT, false, POOL>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo);
-        __syncthreads();
+            conv2_tiles<C1, ACT, false, POOL, AVG>(lds, lane_off, P, Wp, nX, t, breg, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
+        __syncthreads();                                       // every wave is done reading the input planes
+        if (AVG) {
+            // fixed-order reduction: part[wave][lane][4] in LDS (the input region is free now), then one lane per
+            // (channel, window) adds the 2*gsz partials of its channel in ascending (wave, half) order
+            float* part = lds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(wave * 64 + lane) * 4 + j] = wsum[j];
+            __syncthreads();
+            const float inv = 1.0f / (float)(H * a.avg_kw);
+            for (int o = tid; o < a.Cout * a.avg_ow; o += NTHR) {
+                const int co = o / a.avg_ow, j = o - co * a.avg_ow;
+                const int g = co / 32, ci = co - 32 * g;
+                float sum = 0.0f;
+                for (int w2 = 0; w2 < gsz; ++w2)
+                    for (int h2 = 0; h2 < 2; ++h2) sum += part[((g * gsz + w2) * 64 + h2 * 32 + ci) * 4 + j];
+                a.out[((size_t)b * a.Cout + co) * a.avg_ow + j] = sum * inv;
+            }
+            __syncthreads();
+            for (int k = tid; k < NW * 64 * 4; k += NTHR) part[k] = 0.0f;     // restore the zero halo cells we overwrote
+            __syncthreads();
+        }
     }
 }
 
@@ -364,7 +407,8 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int grid = a.B < max_grid ? a.B : max_grid;
     if (grid < 1) grid = 1;
-    static size_t attr[6] = {0, 0, 0, 0, 0, 0};
+    static size_t attr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.avg_ow > 0 && (a.pool || a.avg_ow > 4 || (size_t)8 * 64 * 4 * sizeof(float) > lds)) return hipErrorInvalidValue;
 #define CM_LAUNCH(ACTV, POOLV, SLOT)                                                                                   \
     {                                                                                                                  \
         if (lds > attr[SLOT]) {                                                                                        \
@@ -375,8 +419,18 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
         }                                                                                                              \
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), dim3(grid), dim3(512), lds, s, a);               \
     }
+#define CM_LAUNCH_AVG(ACTV, SLOT)                                                                                      \
+    {                                                                                                                  \
+        if (lds > attr[SLOT]) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, false, 8, true>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            if (e != hipSuccess) return e;                                                                             \
+            attr[SLOT] = lds;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, ACTV, false, 8, true>), dim3(grid), dim3(512), lds, s, a);         \
+    }
 #define CM_ACT(ACTV, BASE)                                   \
-    if (a.pool) CM_LAUNCH(ACTV, true, BASE) else CM_LAUNCH(ACTV, false, BASE + 3)
+    if (a.avg_ow > 0) CM_LAUNCH_AVG(ACTV, BASE + 6) else if (a.pool) CM_LAUNCH(ACTV, true, BASE) else CM_LAUNCH(ACTV, false, BASE + 3)
     switch (a.act) {
         case ACT_RELU: CM_ACT(ACT_RELU, 0) break;
         case ACT_GELU: CM_ACT(ACT_GELU, 1) break;
@@ -385,6 +439,7 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
     }
 #undef CM_ACT
 #undef CM_LAUNCH
+#undef CM_LAUNCH_AVG
     return hipGetLastError();
 }
 

@@ -68,6 +68,7 @@ hipError_t launch_dwconv1d_bn_swish(const float* x, const float* w /*[D][K]*/, c
                                     const float* beta, float* y, int B, int T, int D, int K, hipStream_t s);
 // multi-head self-attention core: qkv [B][T][3D] (q|k|v) -> out [B][T][D]; softmax(q k^T / sqrt(dh)) v per head
 hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s);
+bool mha_head_dim_supported(int head_dim);
 // [B][C][H][W] -> [B][W][C*H]  (CRNN: sequence over W, features C*H; architectures.py:272-276)
 hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
 // GRU recurrence for one direction. xg [B][T][3H] = x W_ih^T + b_ih (precomputed by GEMM).

@@ -817,6 +817,10 @@ mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, i
     }
 }
 
+// head dims with a compiled instance (q and the output row live in registers, so DH is a template parameter):
+// every multiple of 4 up to 72, plus 18 and 36-style odd splits of the reference's default d_model = 144.
+#define NWW_MHA_HEAD_DIMS(X) X(4) X(8) X(12) X(16) X(18) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) \
+    X(60) X(64) X(68) X(72)
 hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s) {
     const int dh = D / n_head;
     const size_t lds = (size_t)2 * T * dh * sizeof(float);
@@ -832,11 +836,19 @@ hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, in
         break;                                                                                                     \
     }
     switch (dh) {
-        MHA_CASE(16) MHA_CASE(18) MHA_CASE(24) MHA_CASE(32) MHA_CASE(36) MHA_CASE(48) MHA_CASE(64) MHA_CASE(72)
+        NWW_MHA_HEAD_DIMS(MHA_CASE)
         default: return hipErrorInvalidValue;
     }
 #undef MHA_CASE
     return hipGetLastError();
+}
+bool mha_head_dim_supported(int dh) {
+#define MHA_OK(DHV) case DHV: return true;
+    switch (dh) {
+        NWW_MHA_HEAD_DIMS(MHA_OK)
+        default: return false;
+    }
+#undef MHA_OK
 }
 
 // ------------------------------------------------------------------------------------------ GRU recurrence

@@ -269,6 +269,9 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "GRU hidden size must be a multiple of 4 and <= 256");
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
+    if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d has no compiled kernel (multiples of 4 up to 72, or 18)",
+                    c.conformer_d_model / c.conformer_n_head);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

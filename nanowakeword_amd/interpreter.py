@@ -138,7 +138,8 @@ class HipInterpreter:
     def load_model(cls, model: Union[str, List[str], Mapping[str, object], object, None] = None, cascade: bool = False,
                    gate_model=None, gate_threshold: float = 0.3, device: int = 0, **kwargs) -> "HipInterpreter":
         """Same calling convention as NanoInterpreter.load_model (:310-325).  ``model`` may be a path (or
-        list of paths) to weight bundles written by ``nanowakeword_amd.weights.save_bundle`` (``*.nww.npz``),
+        list of paths) to the reference's own exported ``*.onnx`` files (weights recovered by
+        ``weights.state_dict_from_onnx``), to bundles written by ``weights.save_bundle`` (``*.nww.npz``),
         or ready session objects / a {name: session} mapping.  ``cascade=True`` looks for ``<name>_lite``
         next to the main bundle; ``gate_model`` names the gate explicitly (implies cascade)."""
         from .weights import load_session
@@ -185,7 +186,7 @@ class HipInterpreter:
             else:
                 d = os.path.dirname(os.path.abspath(paths[0]))
                 gate_name = main_name + "_lite"
-                cand = [os.path.join(d, gate_name + ext) for ext in (".nww.npz", ".npz")]
+                cand = [os.path.join(d, gate_name + ext) for ext in (".nww.npz", ".npz", ".onnx")]
                 hit = next((c for c in cand if os.path.exists(c)), None)
                 gate_session = load_session(hit, device=device) if hit else None    # else: single-model mode (:481-487)
             if gate_session is not None:

@@ -4,6 +4,10 @@
                             (reference: nanowakeword/_export/pytorch.py:26-46) -> {key: float32 ndarray}.
 * ``infer_head_config``   : recover Model()'s hyper-parameters from the state_dict keys/shapes
                             (the .pt carries no config; reference: nanowakeword/modules/model.py:67-296).
+* ``state_dict_from_onnx`` : the reference's deployable ``<name>.onnx`` (reference: nanowakeword/_export/onnx.py:157-229,
+                            TorchScript exporter of torch 2.8) -> (HeadConfig, state_dict, info): undoes what the exporter
+                            did to the weights (Conv+BN folding, Linear -> MatMul with transposed weight, GRU gate
+                            re-packing) by walking the graph; no ``onnx`` package needed (``onnx_reader``).
 * ``save_bundle/load_bundle/load_session`` : a self-describing ``*.nww.npz`` (config JSON + tensors +
                             optional frontend tables) that ``HipInterpreter.load_model`` accepts as a path,
                             playing the role the ``.onnx`` file plays for the reference interpreter.
@@ -95,6 +99,157 @@ def infer_head_config(sd: Mapping, input_shape: Optional[Tuple[int, int]] = None
     return cfg
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# .onnx ingestion
+_WRAP = "trained_model."                 # InferenceWrapper attribute name, _export/onnx.py:163-172
+
+
+def _bn_identity(sd, prefix, c, beta=None):
+    """BatchNorm tensors that make ``prefix`` the exact map x -> x + beta: the exporter has already folded the trained
+    statistics into the preceding Conv.  running_var = 1 - eps so that var + eps rounds to exactly 1.0f."""
+    sd[prefix + ".weight"] = np.ones(c, np.float32)
+    sd[prefix + ".bias"] = np.zeros(c, np.float32) if beta is None else np.asarray(beta, np.float32)
+    sd[prefix + ".running_mean"] = np.zeros(c, np.float32)
+    sd[prefix + ".running_var"] = np.full(c, np.float32(1.0) - np.float32(1e-5), np.float32)
+
+
+def _consumers(g, tensor):
+    return [n for n in g.nodes if tensor in n.inputs]
+
+
+def _activation_after(g, tensor) -> str:
+    ops = {n.op_type for n in _consumers(g, tensor)}
+    if "Relu" in ops:
+        return "relu"
+    if "Sigmoid" in ops and "Mul" in ops:
+        return "silu"                                  # x * sigmoid(x)
+    if "Div" in ops or "Erf" in ops:
+        return "gelu"                                  # 0.5 x (1 + erf(x / sqrt 2))
+    raise ValueError(f"unrecognised activation pattern after '{tensor}': {sorted(ops)}")
+
+
+def _unpack_onnx_gru(sd, prefix, layer, W, R, B, hidden):
+    """ONNX GRU packs gates [z, r, h] per direction; nn.GRU stores [r, z, n] (torch symbolic for aten::gru)."""
+    H = hidden
+    perm = np.r_[H:2 * H, 0:H, 2 * H:3 * H]
+    for d, sfx in enumerate(("", "_reverse")):
+        sd[f"{prefix}.weight_ih_l{layer}{sfx}"] = np.ascontiguousarray(W[d][perm], np.float32)
+        sd[f"{prefix}.weight_hh_l{layer}{sfx}"] = np.ascontiguousarray(R[d][perm], np.float32)
+        sd[f"{prefix}.bias_ih_l{layer}{sfx}"] = np.ascontiguousarray(B[d][:3 * H][perm], np.float32)
+        sd[f"{prefix}.bias_hh_l{layer}{sfx}"] = np.ascontiguousarray(B[d][3 * H:][perm], np.float32)
+
+
+def state_dict_from_onnx(path_or_bytes):
+    """Recover (HeadConfig, state_dict, info) from a reference-exported ONNX model.
+
+    ``info``: {"mode": "e2e"|"features", "clip_samples", "frontend": FrontendConfig|None, "opset", "producer"}.
+    The state_dict uses the reference's ``Model.state_dict()`` keys.  Convs the exporter fused with their BatchNorm
+    come back as (folded weight, folded bias, identity BatchNorm) - the same function, so logits agree with the
+    original state_dict to float32 rounding of the folding itself.
+    """
+    from .onnx_reader import read_onnx
+    g = read_onnx(path_or_bytes)
+    if len(g.inputs) != 1 or g.inputs[0][1] is None:
+        raise ValueError("expected one graph input with a static shape (reference exports name it 'input')")
+    in_shape = g.inputs[0][1]
+    named = {k[len(_WRAP):]: v for k, v in g.initializers.items() if k.startswith(_WRAP)}
+    sd = {k: np.asarray(v, np.float32) for k, v in named.items()}
+    anon = lambda t: t in g.initializers and not t.startswith(_WRAP)
+
+    # Linear on a 3-D input is exported as MatMul(x, W^T) + Add(bias): the bias keeps its name.
+    for n in g.nodes:
+        if n.op_type != "MatMul" or len(n.inputs) != 2 or not anon(n.inputs[1]):
+            continue
+        bias = [t for c in _consumers(g, n.outputs[0]) if c.op_type == "Add" for t in c.inputs if t.startswith(_WRAP)]
+        if len(bias) != 1:
+            raise ValueError(f"MatMul '{n.name}': cannot identify the Linear it came from")
+        b = bias[0][len(_WRAP):]
+        key = b[:-len("in_proj_bias")] + "in_proj_weight" if b.endswith("in_proj_bias") else b[:-len("bias")] + "weight"
+        sd[key] = np.ascontiguousarray(g.initializers[n.inputs[1]].T, np.float32)
+
+    convs = [n for n in g.nodes if n.op_type == "Conv" and anon(n.inputs[1])]
+    grus = [n for n in g.nodes if n.op_type == "GRU"]
+    if any(n.op_type == "LSTM" for n in g.nodes):
+        raise NotImplementedError("LSTM backends (crnn_rnn_type='lstm', model_type='lstm') are out of scope")
+
+    def folded(node, wkey, bias_key, bn_prefix):
+        W = np.asarray(g.initializers[node.inputs[1]], np.float32)
+        b = np.asarray(g.initializers[node.inputs[2]], np.float32) if len(node.inputs) > 2 else np.zeros(W.shape[0], np.float32)
+        sd[wkey] = W
+        if bias_key is not None:
+            sd[bias_key] = b
+            _bn_identity(sd, bn_prefix, W.shape[0])
+        else:
+            _bn_identity(sd, bn_prefix, W.shape[0], beta=b)
+
+    def gru_layers(prefix):
+        for l, n in enumerate(grus):
+            if n.attrs.get("direction") != b"bidirectional" or n.attrs.get("linear_before_reset", 0) != 1:
+                raise ValueError(f"GRU node '{n.name}': expected the bidirectional nn.GRU export")
+            H = int(n.attrs["hidden_size"])
+            W, R, B = (np.asarray(g.initializers[t]) for t in n.inputs[1:4])
+            _unpack_onnx_gru(sd, prefix, l, W, R, B, H)
+
+    mode, clip_samples, fe = "features", 16000, None
+    if "model.mel_spec.real_basis" in named:                                        # E2E_MelSpectrogram_CNN
+        mode = "e2e"
+        clip_samples = int(in_shape[-1])
+        rb, fb = named["model.mel_spec.real_basis"], named["model.mel_spec.mel_fb"]
+        stft = [n for n in g.nodes if n.op_type == "Conv" and n.inputs[1] == _WRAP + "model.mel_spec.real_basis"]
+        hop = int(stft[0].attrs["strides"][0])
+        center = any(n.op_type == "Pad" and n.attrs.get("mode") == b"reflect" for n in g.nodes)
+        fe = FrontendConfig(n_fft=int(rb.shape[-1]), win_length=int(rb.shape[-1]), hop_length=hop, n_mels=int(fb.shape[1]), center=center)
+        for i, n in enumerate(convs):
+            folded(n, f"model.conv_block.{4*i}.weight", f"model.conv_block.{4*i}.bias", f"model.conv_block.{4*i+1}")
+        n_frames = fe.n_frames(clip_samples)
+        input_shape = (fe.n_mels, n_frames)
+    else:
+        if len(in_shape) != 3:
+            raise ValueError(f"feature-mode model with input shape {in_shape}: expected [batch, T, F]")
+        input_shape = (int(in_shape[1]), int(in_shape[2]))
+        if "model.block1.depthwise.weight" in named:                                # BcResNet
+            folded(convs[0], "model.init_conv.0.weight", None, "model.init_conv.1")
+            for i in (1, 2, 3):
+                dw = next(n for n in g.nodes if n.op_type == "Conv" and n.inputs[1] == f"{_WRAP}model.block{i}.depthwise.weight")
+                pw = [n for n in convs if n.inputs[0] == dw.outputs[0]]
+                sc = [n for n in convs if n.inputs[0] == dw.inputs[0]]
+                if len(pw) != 1 or len(sc) != 1:
+                    raise ValueError(f"bcresnet block{i}: unexpected graph structure")
+                folded(pw[0], f"model.block{i}.pointwise.weight", None, f"model.block{i}.bn1")
+                folded(sc[0], f"model.block{i}.shortcut.0.weight", None, f"model.block{i}.shortcut.1")
+        elif any(k.startswith("model.conformer_blocks.") for k in named):           # Conformer
+            for i, n in enumerate(convs):
+                p = f"model.conformer_blocks.{i}.conv_module"
+                folded(n, f"{p}.depthwise_conv.weight", f"{p}.depthwise_conv.bias", f"{p}.batch_norm")
+        elif grus and convs:                                                        # CRNN (GRU backend)
+            for i, n in enumerate(convs):
+                folded(n, f"model.cnn.{4*i}.weight", f"model.cnn.{4*i}.bias", f"model.cnn.{4*i+1}")
+            gru_layers("model.rnn")
+        elif grus:                                                                  # GRU
+            gru_layers("model.gru")
+
+    cls = [n for n in g.nodes if n.op_type == "Gemm" and len(n.inputs) > 1 and n.inputs[1] == _WRAP + "classifier.0.weight"]
+    if len(cls) != 1:
+        raise ValueError("no 'classifier.0' Gemm: not a reference Model export")
+    act = _activation_after(g, cls[0].outputs[0])
+    cfg = infer_head_config(sd, input_shape=input_shape, activation=act)
+    if cfg.model_type == "conformer":
+        sm = [n for n in g.nodes if n.op_type == "Softmax"]
+        qk = g.producer_of(sm[0].inputs[0]) if sm else None
+        sc_node = g.producer_of(qk.inputs[0]) if qk is not None else None
+        c = None
+        if sc_node is not None and sc_node.op_type == "Mul":
+            c = next((g.constant(t) for t in sc_node.inputs if g.constant(t) is not None), None)
+        if c is None:
+            raise ValueError("conformer: cannot find the attention scale (1/sqrt(head_dim)) in the graph")
+        dh = int(round(1.0 / float(np.asarray(c).ravel()[0]) ** 2))
+        cfg.conformer_n_head = cfg.conformer_d_model // dh
+    if g.metadata.get("mode") == "e2e" and mode != "e2e":
+        raise ValueError("ONNX metadata says mode=e2e but the graph has no mel front end")
+    info = {"mode": mode, "clip_samples": clip_samples, "frontend": fe, "opset": g.opset, "producer": g.producer}
+    return cfg, sd, info
+
+
 def save_bundle(path: str, head: HeadConfig, state_dict: Mapping, frontend: Optional[FrontendConfig] = None,
                 mode: str = "e2e", clip_samples: int = 16000, window=None, mel_fb=None):
     if not path.endswith(".npz"):
@@ -136,13 +291,18 @@ def load_bundle(path: str):
 
 
 def load_session(path: str, device: int = 0):
-    """Bundle -> finalized HipModel -> HipSession (raises if the HIP library or a GPU is missing)."""
+    """Bundle or reference .onnx -> finalized HipModel -> HipSession (raises if the HIP library or a GPU is missing)."""
     from .session import HipModel, HipSession
-    head, fe, sd, extras, meta = load_bundle(path)
+    if path.endswith(".onnx"):                          # the reference's own artefact (nanointerpreter.py:955-959)
+        head, sd, info = state_dict_from_onnx(path)
+        fe = info["frontend"] or FrontendConfig()
+        extras, meta = {}, {"mode": info["mode"], "clip_samples": info["clip_samples"]}
+    else:
+        head, fe, sd, extras, meta = load_bundle(path)
     model = HipModel(head, fe, device=device, state_dict=sd, window=extras.get("frontend.window"),
                      mel_fb=extras.get("frontend.mel_fb"))
     name = path.rsplit("/", 1)[-1]
-    for ext in (".nww.npz", ".npz"):
+    for ext in (".nww.npz", ".npz", ".onnx"):
         if name.endswith(ext):
             name = name[:-len(ext)]
             break

@@ -183,3 +183,25 @@ def test_batch_invariance_full_size(hip, golden_frontend):
     lo = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
     assert np.abs(lg[:8] - lo).max() <= 1e-4
     m.close()
+
+
+@pytest.mark.parametrize("d_model,n_head", [(32, 8), (80, 4), (144, 8), (96, 2), (144, 2)])
+def test_conformer_attention_head_dims(hip, d_model, n_head):
+    """Every compiled attention head_dim (4, 20, 18, 48, 72 here) against the oracle; an uncompiled one is refused
+    when the model is created, not at the first batch."""
+    HipModel, _ = hip
+    cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=d_model, conformer_n_head=n_head)
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    feats = synth_features(5, cfg.input_shape, seed=d_model + n_head)
+    logits, _ = m.forward_features(feats)
+    ref = oracle.model_forward(feats, sd, cfg).ravel()
+    assert np.abs(logits - ref).max() <= FEAT_LOGIT_ATOL, np.abs(logits - ref).max()
+    m.close()
+
+
+def test_conformer_unsupported_head_dim_is_refused_at_create(hip):
+    HipModel, _ = hip
+    cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=66, conformer_n_head=2)
+    with pytest.raises(NotImplementedError, match="head_dim 33"):
+        HipModel(cfg, FrontendConfig())

@@ -287,6 +287,7 @@ def main():
     make_predict_traces(os.path.join(args.out, "predict_trace.json"))
     make_wire_fixtures(os.path.join(args.out, "wire_messages.json"))
     make_audio_features_traces(os.path.join(args.out, "audio_features_trace.json"))
+    make_onnx_fixtures(os.path.join(args.out, "onnx"))
     print("done ->", args.out)
 
 
@@ -435,5 +436,77 @@ def make_audio_features_traces(path):
     print("audio_features_trace.json:", out["embed_clips_shape"], shape2, rows[-1])
 
 
+def make_onnx_fixtures(outdir):
+    """Real reference exports: every in-scope head goes through the reference's own ``export_onnx_model``
+    (nanowakeword/_export/onnx.py:157-229) with small shapes, and the exported wrapper's probabilities on fixed
+    inputs are stored next to the files.  The reference pins torch 2.8, whose ``torch.onnx.export`` is the
+    TorchScript exporter; torch 2.10 here needs ``dynamo=False`` for the same exporter, and its last step (attaching
+    onnxscript functions - there are none) imports the absent ``onnx`` package, so that step is bypassed.  The bytes
+    written are those of torch's C++ ONNX serializer."""
+    os.makedirs(outdir, exist_ok=True)
+    install_stubs()
+    torch.set_num_threads(1)
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    orig_export = torch.onnx.export
+
+    def export_torchscript(*a, **k):
+        k.setdefault("dynamo", False)
+        return orig_export(*a, **k)
+    torch.onnx.export = export_torchscript
+
+    from nanowakeword.modules.model import Model
+    from nanowakeword._export import onnx as ref_onnx
+    from nanowakeword_amd.config import HeadConfig
+    from nanowakeword_amd.synth import synth_pcm, synth_features, synth_state_dict
+
+    cases = [
+        ("dnn", HeadConfig("dnn", (4, 8), layer_dim=16, n_blocks=2, embedding_dim=8, activation="gelu")),
+        ("cnn", HeadConfig("cnn", (8, 16), embedding_dim=16)),
+        ("crnn", HeadConfig("crnn", (8, 16), layer_dim=16, n_blocks=2, embedding_dim=16, activation="silu")),
+        ("gru", HeadConfig("gru", (6, 12), layer_dim=16, n_blocks=2, embedding_dim=8)),
+        ("bcresnet", HeadConfig("bcresnet", (16, 24), embedding_dim=16)),
+        ("conformer", HeadConfig("conformer", (8, 12), n_blocks=2, embedding_dim=16, conformer_d_model=32, conformer_n_head=8)),
+        ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))),
+    ]
+    meta = {}
+    arrays = {}
+    for name, cfg in cases:
+        sd = synth_state_dict(cfg)
+        conf = {"activation_function": cfg.activation, "embedding_dim": cfg.embedding_dim,
+                "crnn_cnn_channels": list(cfg.crnn_cnn_channels), "crnn_rnn_type": cfg.crnn_rnn_type,
+                "conformer_d_model": cfg.conformer_d_model, "conformer_n_head": cfg.conformer_n_head}
+        if cfg.model_type == "e2e_dnn":
+            m = Model(conf, "g", input_shape=(16000,), model_type="e2e_dnn", mode="e2e")
+        else:
+            m = Model(conf, "g", input_shape=cfg.input_shape, model_type=cfg.model_type,
+                      layer_dim=cfg.layer_dim, n_blocks=cfg.n_blocks)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        m.eval()
+        shape = (16000,) if cfg.model_type == "e2e_dnn" else cfg.input_shape
+        ref_onnx.export_onnx_model(m, shape, {}, name, outdir)         # patches m in place (mel, pooling)
+        path = os.path.join(outdir, name + ".onnx")
+        assert os.path.exists(path), f"export of {name} failed"
+        if cfg.model_type == "e2e_dnn":
+            pcm = np.concatenate([synth_pcm("noise", 2, 16000, seed=31), synth_pcm("speechlike", 2, 16000, seed=32)])
+            x = torch.from_numpy(pcm.astype(np.float32) / 32768.0).unsqueeze(1)
+            arrays[name + "/pcm"] = pcm
+        else:
+            feats = synth_features(4, cfg.input_shape)
+            x = torch.from_numpy(feats)
+        with torch.no_grad():
+            logits = m(x).numpy()
+        arrays[name + "/logits"] = logits.reshape(-1).astype(np.float32)
+        arrays[name + "/probs"] = (1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).reshape(-1).astype(np.float32)
+        meta[name] = cfg.to_dict()
+        print("onnx fixture", name, os.path.getsize(path), "bytes; logits", logits.reshape(-1))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(outdir, "expected.npz"), **arrays)
+    torch.onnx.export = orig_export
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--onnx-only":
+        make_onnx_fixtures(os.path.join(REPO, "tests", "golden", "onnx"))
+    else:
+        main()

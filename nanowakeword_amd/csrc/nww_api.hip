@@ -411,12 +411,13 @@ void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Ci
     });
 }
 
+static int trunk_fits(int C1, int H, int W) { int per_cu = 0; return trunk_pick_strips(C1, H, W, &per_cu); }
 // fused conv1+pool+conv2+pool (trunk.hip) when the 1->16->32 pattern fits LDS; returns false if not applicable
 bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
                const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
                const float* b2, const float* al2, const float* be2, int act) {
     static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
-    if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_lds_bytes(C1, H, W) > 160 * 1024) return false;
+    if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
     const int max_grid = p.h->cu_count;
     p.add("trunk:" + name, [=](Run& r) {

@@ -10,8 +10,11 @@ struct TrunkArgs {
     float* out;                                        // [B][C2][H/4][W/4]
     int B, H, W, act;
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
+    int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
 };
-size_t trunk_lds_bytes(int C1, int H, int W);
+size_t trunk_lds_bytes(int C1, int H, int W, int strips);
+// strips needed for a workgroup to fit in LDS (0 = does not fit at all); *wgs_per_cu = 2 when two workgroups share a CU
+int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu);
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s);
 
 // standalone 3x3 conv (pad 1, stride 1) + bias/BN + act (+ MaxPool2) on MFMA f32 for C1 = 32 input channels and

@@ -38,11 +38,53 @@ __device__ __forceinline__ float trunk_act(float v) {
     return v;
 }
 
-size_t trunk_lds_bytes(int C1, int H, int W) {
-    const int H1 = H / 2, W1 = W / 2;
-    const size_t in_f = (size_t)(H + 2) * (W + 2);
-    const size_t a1_f = (size_t)C1 * (H1 + 2) * (W1 + 2) + 64;
-    return (((in_f + 3) & ~(size_t)3) + a1_f) * sizeof(float);
+// Row strips.  A clip is cut into S strips of pooled output rows; strip s = pooled rows [R2a, R2b) needs the A1 rows
+// 2*R2a-1 .. 2*R2b (one halo row each side, recomputed by both neighbours at a seam) and for those the input rows
+// 2*a1_lo-1 .. 2*a1_hi+2.  Rows outside the image are the zero halo.  With S = 2 a (101,64) strip takes 76 KB of LDS,
+// so two workgroups share a CU and one's conv1 / epilogue gaps are filled by the other's conv2 MFMAs.
+struct TrunkStrip {
+    int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
+};
+__host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
+    const int H1 = H / 2, H2 = H1 / 2;
+    TrunkStrip g;
+    g.R2a = (s * H2 + S - 1) / S;
+    g.R2b = ((s + 1) * H2 + S - 1) / S;
+    g.a1_base = 2 * g.R2a - 1;                                  // A1 row kept at local row 0
+    g.a1_lo = g.a1_base < 0 ? 0 : g.a1_base;
+    g.a1_hi = 2 * g.R2b < H1 - 1 ? 2 * g.R2b : H1 - 1;
+    g.a1_rows = 2 * (g.R2b - g.R2a) + 2;
+    g.iy0 = 2 * g.a1_lo - 1;                                    // input row kept at local row 0
+    const int iy1 = 2 * g.a1_hi + 2;
+    g.in_rows = iy1 - g.iy0 + 1;
+    g.y_lo = g.iy0 < 0 ? 0 : g.iy0;
+    g.y_hi = iy1 < H - 1 ? iy1 : H - 1;
+    return g;
+}
+size_t trunk_lds_bytes(int C1, int H, int W, int S) {
+    const int W1 = W / 2;
+    if (S == 1) {                                   // whole-clip instance: planes of H+2 and H/2+2 rows
+        const size_t in_f = ((size_t)(H + 2) * (W + 2) + 3) & ~(size_t)3;
+        return (in_f + (size_t)C1 * (H / 2 + 2) * (W1 + 2) + 64) * sizeof(float);
+    }
+    size_t worst = 0;
+    for (int s = 0; s < S; ++s) {
+        const TrunkStrip g = trunk_strip(H, S, s);
+        const size_t in_f = ((size_t)g.in_rows * (W + 2) + 3) & ~(size_t)3;
+        const size_t a1_f = (size_t)C1 * g.a1_rows * (W1 + 2) + 64;
+        if (in_f + a1_f > worst) worst = in_f + a1_f;
+    }
+    return worst * sizeof(float);
+}
+// strips per clip: the whole clip (one 8-wave workgroup per CU) whenever it fits in LDS, else the fewest strips that
+// do.  Two 4-wave workgroups per CU on half-clip strips (NWW_TRUNK_STRIPS=2) measured no better: with equal work the
+// two stay in lock-step, so one's conv1 does not fall under the other's conv2.
+int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu) {
+    const int H2 = H / 4;
+    for (int S = 1; S <= H2; ++S)
+        if (trunk_lds_bytes(C1, H, W, S) <= 160 * 1024) { *wgs_per_cu = 1; return S; }
+    *wgs_per_cu = 0;
+    return 0;
 }
 
 // conv2 for tile t (and t+1 when TWO): 32 pixels x 32 channels x K = C1*9 each, A operands prefetched one channel
@@ -178,15 +220,41 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
     }
 }
 
-template <int C1, int C2, int ACT, int NW>
-__global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a) {
+// STRIP = false is the whole-clip instance: its geometry is written as plain functions of H and W because the kernel
+// sits at 256 VGPRs and hipcc's allocation is fragile there (the same numbers routed through the strip arithmetic
+// cost 32 spilled VGPRs and 9 % of the kernel's time).
+template <int C1, int C2, int ACT, int NW, bool STRIP>
+__global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_kernel(TrunkArgs a) {
     constexpr int NTHR = 64 * NW;
     static_assert(C1 == 16 && C2 == 32, "C1 == 16 (one 16-wide MFMA column block), C2 == 32");
     constexpr int KS = C1 * 9 / 2;                         // MFMA steps per tile (2 k per step)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
-    const int Wp0 = W + 2, Wp1 = W1 + 2, P1 = (H1 + 2) * Wp1;
-    const int in_f = ((H + 2) * Wp0 + 3) & ~3;
+    const int S = a.strips;
+    // a workgroup keeps ONE strip index for its whole life, so the zero halos written once below stay valid
+    // Only a handful of derived numbers stay live (the strip struct itself would cost ~10 SGPRs the kernel lacks):
+    // local row of input row y is y - iy0 with iy0 = 2*a1_lo - 1, so conv1 of local A1 row Rl reads local input rows
+    // 2*Rl ..; A1 row a1_lo sits at local A1 row a1_shift (1 below the zero halo at the image top, 0 at a seam).
+    int n_a1, a1_shift, nR2, n_in, row_shift, P1, in_f;
+    size_t in_off, out_off;
+    const int Wp0 = W + 2, Wp1 = W1 + 2;
+    if (!STRIP) {
+        n_a1 = H1; a1_shift = 1; nR2 = H2; n_in = H * W; row_shift = 1;
+        P1 = (H1 + 2) * Wp1;
+        in_f = ((H + 2) * Wp0 + 3) & ~3;
+        in_off = 0; out_off = 0;
+    } else {
+        const TrunkStrip sg = trunk_strip(H, S, (int)blockIdx.x % S);
+        n_a1 = sg.a1_hi - sg.a1_lo + 1;
+        a1_shift = sg.a1_lo - sg.a1_base;
+        nR2 = sg.R2b - sg.R2a;
+        n_in = (sg.y_hi - sg.y_lo + 1) * W;
+        row_shift = sg.y_lo - sg.iy0;
+        P1 = sg.a1_rows * Wp1;
+        in_f = (sg.in_rows * Wp0 + 3) & ~3;
+        in_off = (size_t)sg.y_lo * W;
+        out_off = (size_t)sg.R2a * W2;
+    }
     float* In = lds;
     float* A1 = lds + in_f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -198,9 +266,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
     // conv2 weights -> B fragments: step s = c2*9 + tap, lane (cout = i, channel = 2*c2 + hi)
     float breg[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c2 = s / 9, tap = s - c2 * 9;
-        breg[s] = a.w2[((size_t)i * C1 + 2 * c2 + hi) * 9 + tap];
+    for (int st = 0; st < KS; ++st) {
+        const int c2 = st / 9, tap = st - c2 * 9;
+        breg[st] = a.w2[((size_t)i * C1 + 2 * c2 + hi) * 9 + tap];
     }
     const float bias2 = a.b2 ? a.b2[i] : 0.0f;
     const float al2 = a.al2 ? a.al2[i] : 1.0f, be2 = a.al2 ? a.be2[i] : 0.0f;
@@ -217,8 +285,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
     const float bias1 = a.b1 ? a.b1[lane & 15] : 0.0f;
     const float al1 = a.al1 ? a.al1[lane & 15] : 1.0f, be1 = a.al1 ? a.be1[lane & 15] : 0.0f;
 
-    // conv2 tiling
-    const int nX = (W1 + 15) / 16, nT = H2 * nX;
+    // conv2 tiling of this strip (tile rows are local pooled rows 0 .. R2b-R2a-1)
+    const int nX = (W1 + 15) / 16, nT = nR2 * nX;
     // leftover tiles go to waves 0..rem-1, which sit on different SIMDs (waves w and w+4 share one)
     const int t_base = nT / NW, t_rem = nT - t_base * NW;
     const int t_begin = wave * t_base + min(wave, t_rem), t_end = t_begin + t_base + (wave < t_rem ? 1 : 0);
@@ -226,32 +294,33 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
     const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
     const int lane_off = hi * P1 + dyi * Wp1 + xi;
 
-    // input plane of a clip -> LDS `In` (interior at +1,+1).  The first clip is loaded synchronously; afterwards the
-    // NEXT clip's plane is fetched into registers at the start of conv2 (In is only read by conv1) and written to
-    // LDS when conv2 is done, so its HBM latency hides under the MFMA phase.
-    const bool vec_in = (W & 3) == 0 && (H * W) <= 16 * NTHR;
+    // input rows y_lo..y_hi of a clip -> LDS `In` (local row y - iy0, interior at column +1).  The first clip is loaded
+    // synchronously; afterwards the NEXT clip's rows are fetched into registers at the start of conv2 (In is only read
+    // by conv1) and written to LDS when conv2 is done, so their HBM latency hides under the MFMA phase.
+    const bool vec_in = (W & 3) == 0 && n_in <= 16 * NTHR;
     auto store_plane_regs = [&](const float4 (&pre)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx4 = tid + q * NTHR;
-            if (idx4 < H * W / 4) {
+            if (idx4 < n_in / 4) {
                 const int idx = idx4 * 4, y = idx / W, x = idx - y * W;
-                float* d = In + (y + 1) * Wp0 + x + 1;
+                float* d = In + (y + row_shift) * Wp0 + x + 1;
                 d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
             }
         }
     };
     auto load_plane_sync = [&](const float* xin) {
-        for (int idx = tid; idx < H * W; idx += NTHR) {
+        for (int idx = tid; idx < n_in; idx += NTHR) {
             const int y = idx / W, x = idx - y * W;
-            In[(y + 1) * Wp0 + x + 1] = xin[idx];
+            In[(y + row_shift) * Wp0 + x + 1] = xin[idx];
         }
     };
+    const int b0 = STRIP ? (int)blockIdx.x / S : (int)blockIdx.x, bstep = STRIP ? (int)gridDim.x / S : (int)gridDim.x;
     __syncthreads();
-    if ((int)blockIdx.x < a.B) load_plane_sync(a.in + (size_t)blockIdx.x * H * W);
+    if (b0 < a.B) load_plane_sync(a.in + (size_t)b0 * H * W + in_off);
     __syncthreads();
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const int bnext = b + gridDim.x;
+    for (int b = b0; b < a.B; b += bstep) {
+        const int bnext = b + bstep;
         // ---------------- P1: conv1 + act + pool -> A1 on v_mfma_f32_16x16x4_f32
         // tile = 16 conv1 pixels as 2 rows x 8 columns, pixel i = 4*quad + 2*dy + dx; K = 9 taps padded to 12
         // (3 steps of 4); lane (i = l&15, g = l>>4) feeds tap 4*step + g.  C layout: column = channel l&15,
@@ -259,12 +328,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         if (!(a.dbg & 1)) {
             // groups of 4 horizontally adjacent tiles: one index division per group, the tiles of a group are at
             // constant +8 column offsets (immediate offsets on the LDS reads)
-            const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4, nG = H1 * ngx;
+            const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4, nG = n_a1 * ngx;
             const int i1 = lane & 15, g1 = lane >> 4;
             const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
-            float* a1lane = A1 + i1 * P1 + Wp1 + g1 + 1;
+            float* a1lane = A1 + i1 * P1 + a1_shift * Wp1 + g1 + 1;
             for (int g = wave; g < nG; g += NW) {
-                const int R = g / ngx, X0 = 4 * (g - R * ngx);
+                const int R = g / ngx, X0 = 4 * (g - R * ngx);                          // R = A1 row - a1_lo
                 const float* rowp = In + (2 * R) * Wp0 + 8 * X0 + pix_off;
                 f32x4 acc[4];
 #pragma unroll
@@ -295,23 +364,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         }
         __syncthreads();
         // ---------------- P2: conv2 on MFMA; tiles in pairs (two independent accumulators), a lone tile alone
-        float* outb = a.out + (size_t)b * C2 * H2 * W2;
+        float* outb = a.out + (size_t)b * C2 * H2 * W2 + out_off;
         float4 pre[4];
         const bool fetch = bnext < a.B;
         if (fetch && vec_in) {
-            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W + in_off);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx4 = tid + q * NTHR;
-                if (idx4 < H * W / 4) pre[q] = xin4[idx4];
+                if (idx4 < n_in / 4) pre[q] = xin4[idx4];
             }
         }
         if (!(a.dbg & 2)) {
             int t = t_begin;
-            // The two waves of a SIMD (w and w + NW/2) would otherwise run in lock-step: MFMA phases overlapping (each at
-            // half rate) and epilogue/prologue gaps overlapping too (pipe idle).  The upper half starts with one single
-            // tile, which puts it half an iteration out of phase so one wave's gaps fall under the other's MFMAs.
-            if (wave >= NW / 2 && t < t_end) {
+            // Two waves of ONE workgroup on a SIMD (w and w + 4 when NW == 8) would otherwise run in lock-step: MFMA
+            // phases overlapping (each at half rate) and epilogue/prologue gaps overlapping too (pipe idle).  The upper
+            // half starts with one single tile, which puts it half an iteration out of phase so one wave's gaps fall
+            // under the other's MFMAs.  (With NW == 4 the SIMD's second wave belongs to another workgroup.)
+            if (NW > 4 && wave >= NW / 2 && t < t_end) {
                 conv2_tiles<C1, ACT, false>(A1, lane_off, P1, Wp1, nX, t, breg, bias2, al2, be2, a.al2 != nullptr, outb, i, hi, H2, W2);
                 t += 1;
             }
@@ -322,7 +392,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) cnn_trunk_kernel(TrunkArgs a)
         }
         if (fetch) {
             if (vec_in) store_plane_regs(pre);
-            else load_plane_sync(a.in + (size_t)bnext * H * W);
+            else load_plane_sync(a.in + (size_t)bnext * H * W + in_off);
         }
         __syncthreads();                                     // A1 is free for the next clip's P1, In holds the next clip
     }
@@ -446,24 +516,41 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s) {
     if (C1 != 16 || C2 != 32) return hipErrorInvalidValue;
     static const int dbg = [] { const char* e = getenv("NWW_TRUNK_DBG"); return e ? atoi(e) : 0; }();
+    static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    static const int force_nw = [] { const char* e = getenv("NWW_TRUNK_WAVES"); return e ? atoi(e) : 0; }();
     TrunkArgs aa = a;
     aa.dbg = dbg;
-    int grid = a.B < max_grid ? a.B : max_grid;
-    if (grid < 1) grid = 1;
-    const size_t lds = trunk_lds_bytes(C1, a.H, a.W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static size_t attr_for[6] = {0, 0, 0, 0, 0, 0};
-    static const int nw = [] { const char* e = getenv("NWW_TRUNK_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-#define TRUNK_LAUNCH1(ACTV, NWV, SLOT)                                                                             \
+    int per_cu = 0;
+    int S = trunk_pick_strips(C1, a.H, a.W, &per_cu);
+    if (force_strips > 0 && force_strips <= a.H / 4) {
+        S = force_strips;
+        const size_t l = trunk_lds_bytes(C1, a.H, a.W, S);
+        per_cu = l <= 80 * 1024 ? 2 : (l <= 160 * 1024 ? 1 : 0);
+    }
+    if (S < 1 || per_cu < 1) return hipErrorInvalidValue;
+    aa.strips = S;
+    const size_t lds = trunk_lds_bytes(C1, a.H, a.W, S);
+    // two workgroups per CU: 4 waves each (one per SIMD, 256 VGPRs); a lone workgroup: 8 waves (two per SIMD)
+    int nw = per_cu == 2 ? 4 : 8;
+    if (force_nw == 4 || force_nw == 8) nw = force_nw;
+    long want = (long)a.B * S, cap = (long)max_grid * per_cu;
+    int grid = (int)(want < cap ? want : cap);
+    grid -= grid % S;
+    if (grid < S) grid = S;
+    static size_t attr_for[12] = {0};
+#define TRUNK_LAUNCH2(ACTV, NWV, STRIPV, SLOT)                                                                     \
     {                                                                                                              \
         if (lds > attr_for[SLOT]) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV, NWV>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            hipError_t e = hipFuncSetAttribute(                                                                    \
+                reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV, NWV, STRIPV>),                        \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
             if (e != hipSuccess) return e;                                                                         \
             attr_for[SLOT] = lds;                                                                                  \
         }                                                                                                          \
-        hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);         \
+        hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV, NWV, STRIPV>), dim3(grid), dim3(64 * NWV), lds, s, aa); \
     }
+#define TRUNK_LAUNCH1(ACTV, NWV, SLOT)                                                                             \
+    if (S == 1) TRUNK_LAUNCH2(ACTV, NWV, false, SLOT) else TRUNK_LAUNCH2(ACTV, NWV, true, SLOT + 6)
 #define TRUNK_LAUNCH(ACTV, SLOT)                                                                                   \
     if (nw == 4) TRUNK_LAUNCH1(ACTV, 4, SLOT) else TRUNK_LAUNCH1(ACTV, 8, SLOT + 3)
     switch (a.act) {
@@ -472,6 +559,7 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
         case ACT_SILU: TRUNK_LAUNCH(ACT_SILU, 2) break;
         default: return hipErrorInvalidValue;
     }
+#undef TRUNK_LAUNCH2
 #undef TRUNK_LAUNCH1
 #undef TRUNK_LAUNCH
     return hipGetLastError();

@@ -205,3 +205,20 @@ def test_conformer_unsupported_head_dim_is_refused_at_create(hip):
     cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=66, conformer_n_head=2)
     with pytest.raises(NotImplementedError, match="head_dim 33"):
         HipModel(cfg, FrontendConfig())
+
+
+@pytest.mark.parametrize("shape", [(201, 64), (150, 96), (303, 40)])
+def test_cnn_trunk_row_strips_for_large_inputs(hip, shape):
+    """Inputs whose conv1 output does not fit one CU's LDS go through the fused trunk in row strips (seam rows
+    recomputed by both neighbours); results must not depend on where the seams fall."""
+    HipModel, _ = hip
+    cfg = HeadConfig("cnn", shape, embedding_dim=16)
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    assert "trunk:" in m.describe_plan()
+    feats = synth_features(3, shape, seed=shape[0])
+    logits, _, emb = m.forward_features(feats, return_embedding=True)
+    e_or = oracle.head_forward(feats, sd, cfg)
+    assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max())
+    assert np.abs(logits - oracle.model_forward(feats, sd, cfg).ravel()).max() <= FEAT_LOGIT_ATOL
+    m.close()

@@ -533,6 +533,8 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
     // two workgroups per CU: 4 waves each (one per SIMD, 256 VGPRs); a lone workgroup: 8 waves (two per SIMD)
     int nw = per_cu == 2 ? 4 : 8;
     if (force_nw == 4 || force_nw == 8) nw = force_nw;
+    static const int force_per_cu = [] { const char* e = getenv("NWW_TRUNK_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+    if (force_per_cu > 0 && force_per_cu < per_cu) per_cu = force_per_cu;       // experiments: leave room for another kernel
     long want = (long)a.B * S, cap = (long)max_grid * per_cu;
     int grid = (int)(want < cap ? want : cap);
     grid -= grid % S;

@@ -1,0 +1,259 @@
+// gemm_x3.hip - float32 GEMM on the bf16 matrix cores by exact operand splitting (gfx950).
+//
+// C = post(A W^T) with A [M][K] and W [N][K] float32.  Every float32 x is written as hi + mid + lo, three bf16 values
+// holding its 24 significant bits exactly (hi = x with the low 16 bits cleared, mid likewise of x - hi, lo the rest).
+// A product x*w is then the sum of nine bf16 x bf16 products, each exact in float32; the six largest
+//     hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid
+// are issued as v_mfma_f32_32x32x16_bf16 with float32 accumulation; the three dropped ones are below 2^-23 of the
+// product, i.e. the size of ONE float32 rounding, of which an fmaf chain over K commits K.  The result is float32
+// arithmetic to within its own rounding noise (tests: <= 2e-6 relative to the v_mfma_f32_32x32x2_f32 path on every
+// head) at 16/6 = 2.7x the float32 MFMA rate.  Determinism and batch invariance are unchanged: fixed K order per
+// output, split-K chunks depend on (N, K) only.
+//
+// Tiling: workgroup = 4 waves stacked along M, BM = 128 rows x BN = 32*CB columns, BK = 16 (one MFMA K).  LDS rows are
+// [3 terms][16 k] bf16 + 16 B pad = 112 B, which makes the per-lane 16-byte fragment reads conflict-free.  A is split
+// while it is staged into LDS (5.5 VALU ops per element, amortised over 32*CB columns); W is split once at
+// nww_finalize into the same [N][K/16][3][16] layout so its tiles are plain 16-byte copies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "layers.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int X3_ROW = 112;                      // bytes per LDS row
+constexpr int X3_BM = 128;
+
+__device__ __forceinline__ float x3_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+// x -> three float32 bit patterns whose upper halves are the bf16 terms (lo is truncated when packed; it has at
+// most 8 significant bits left, so nothing is lost)
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+// (a >> 16) | (b & 0xffff0000): bf16 of a in the low half (element k), of b in the high half (element k+1)
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+}  // namespace
+
+// W [N][K] float32 -> [N][KB][3][16] bf16, KB = ceil(K/16), zero beyond K
+__global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __restrict__ W, uint16_t* __restrict__ out,
+                                                               int N, int K, int KB) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // one (n, k) element
+    const size_t total = (size_t)N * KB * 16;
+    if (idx >= total) return;
+    const int kk = (int)(idx & 15);
+    const size_t nb = idx >> 4;
+    const int kb = (int)(nb % KB), n = (int)(nb / KB);
+    const int k = kb * 16 + kk;
+    const float x = k < K ? W[(size_t)n * K + k] : 0.0f;
+    uint32_t hi, mid, lo;
+    split3(x, hi, mid, lo);
+    uint16_t* o = out + nb * 48 + kk;
+    o[0] = (uint16_t)(hi >> 16); o[16] = (uint16_t)(mid >> 16); o[32] = (uint16_t)(lo >> 16);
+}
+
+template <int CB>
+__global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
+    constexpr int BN = 32 * CB;
+    constexpr int WPIECES = BN * 6;                            // 16-byte pieces of a W tile
+    constexpr int WLD = (WPIECES + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto As = [&](int buf) { return smem + buf * (X3_BM * X3_ROW); };
+    auto Ws = [&](int buf) { return smem + 2 * X3_BM * X3_ROW + buf * (BN * X3_ROW); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.x * X3_BM, bn = blockIdx.y * BN;
+    const int KB = (g.K + 15) >> 4;
+    int kb_begin = 0, kb_end = KB;
+    if (g.splitk > 1) {
+        const int kc = (KB + g.splitk - 1) / g.splitk;
+        kb_begin = blockIdx.z * kc;
+        kb_end = min(KB, kb_begin + kc);
+    }
+    const uint4* Wx = reinterpret_cast<const uint4*>(g.Wx3);
+
+    // A loader: thread -> rows (tid>>2) and (tid>>2)+64, floats 4*(tid&3) .. +3 of the 16-k block
+    const int lr = tid >> 2, lq = tid & 3;
+    const float* arow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) arow[q] = g.A + (size_t)min(bm + lr + 64 * q, g.M - 1) * g.lda + 4 * lq;
+    auto gload = [&](int kb, float4 (&ra)[2], uint4 (&rw)[WLD]) {
+        const int k = kb * 16 + 4 * lq;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (k + 4 <= g.K) {
+                ra[q] = *reinterpret_cast<const float4*>(arow[q] + kb * 16);
+            } else {                                           // K tail (K % 16 != 0): element-wise, zero beyond K
+                const float* p = arow[q] + kb * 16;
+                ra[q].x = k + 0 < g.K ? p[0] : 0.0f; ra[q].y = k + 1 < g.K ? p[1] : 0.0f;
+                ra[q].z = k + 2 < g.K ? p[2] : 0.0f; ra[q].w = k + 3 < g.K ? p[3] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int p = tid + 256 * j;
+            if (WPIECES % 256 == 0 || p < WPIECES) {
+                const int row = p / 6, c = p - row * 6;
+                const int n = min(bn + row, g.N - 1);
+                rw[j] = Wx[((size_t)n * KB + kb) * 6 + c];
+            }
+        }
+    };
+    auto lstore = [&](int buf, const float4 (&ra)[2], const uint4 (&rw)[WLD]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint32_t hi[4], mid[4], lo[4];
+            split3(ra[q].x, hi[0], mid[0], lo[0]); split3(ra[q].y, hi[1], mid[1], lo[1]);
+            split3(ra[q].z, hi[2], mid[2], lo[2]); split3(ra[q].w, hi[3], mid[3], lo[3]);
+            unsigned char* d = As(buf) + (lr + 64 * q) * X3_ROW + 8 * lq;
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
+            *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+            *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+        }
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int p = tid + 256 * j;
+            if (WPIECES % 256 == 0 || p < WPIECES) {
+                const int row = p / 6, c = p - row * 6;
+                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + 16 * c) = rw[j];
+            }
+        }
+    };
+
+    f32x16 acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    float4 ra[2];
+    uint4 rw[WLD];
+    int cur = 0;
+    if (kb_begin < kb_end) {
+        gload(kb_begin, ra, rw);
+        lstore(0, ra, rw);
+    }
+    __syncthreads();
+    const int a_off = (wave * 32 + i) * X3_ROW + 16 * h, w_off = i * X3_ROW + 16 * h;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (more) gload(kb + 1, ra, rw);
+        const unsigned char* ap = As(cur) + a_off;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + 32),
+                     al = *reinterpret_cast<const bf16x8*>(ap + 64);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const unsigned char* wp = Ws(cur) + w_off + c * 32 * X3_ROW;
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wp), wm = *reinterpret_cast<const bf16x8*>(wp + 32),
+                         wl = *reinterpret_cast<const bf16x8*>(wp + 64);
+            // small terms first, the dominant hi*hi last
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[c], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1, ra, rw);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int m0 = bm + wave * 32;
+    if (m0 >= g.M) return;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int n = bn + c * 32 + i;
+        if (n >= g.N) continue;
+        if (g.splitk > 1) {
+            float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M) part[(size_t)m * g.N + n] = acc[c][r];
+            }
+            continue;
+        }
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+        const float al2 = g.alpha ? g.alpha[n] : 1.0f, be2 = g.alpha ? g.beta[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < g.M) {
+                float v = acc[c][r] + bias;
+                if (g.alpha) v = v * al2 + be2;
+                v = x3_act(v, g.act);
+                if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+                g.C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * ((K + 15) / 16) * 96; }
+
+hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s) {
+    const int KB = (K + 15) / 16;
+    const size_t total = (size_t)N * KB * 16;
+    hipLaunchKernelGGL(split_weights_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W,
+                       reinterpret_cast<uint16_t*>(out), N, K, KB);
+    return hipGetLastError();
+}
+
+// column blocks per workgroup: least padded width first, then the widest tile (A is re-read once per column tile)
+static int x3_pick_cb(int N) {
+    int best = 2;
+    long best_cost = -1;
+    for (int cb = 2; cb <= 6; ++cb) {
+        const long tiles = (N + 32 * cb - 1) / (32 * cb);
+        const long cost = tiles * 32 * cb * 8 - cb;            // padded width dominates, wider tile breaks ties
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cb; }
+    }
+    return best;
+}
+
+bool gemm_x3_usable(const GemmArgs& g) {
+    return g.Wx3 != nullptr && g.N >= 32 && g.K >= 32 && (g.lda % 4 == 0) &&
+           ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+}
+
+hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
+    const int cb = x3_pick_cb(g.N);
+    const int bn = 32 * cb;
+    const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
+    GemmArgs a = g;
+    a.splitk = sk;
+    dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
+    const size_t lds = 2 * (size_t)(X3_BM + bn) * X3_ROW;
+    static size_t attr_for[7] = {0};
+#define X3_LAUNCH(CBV)                                                                                             \
+    case CBV: {                                                                                                    \
+        if (lds > 64 * 1024 && lds > attr_for[CBV]) {                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<CBV>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return e;                                                                         \
+            attr_for[CBV] = lds;                                                                                   \
+        }                                                                                                          \
+        hipLaunchKernelGGL((gemm_x3_kernel<CBV>), grid, dim3(256), lds, s, a);                                     \
+        break;                                                                                                     \
+    }
+    switch (cb) {
+        X3_LAUNCH(2) X3_LAUNCH(3) X3_LAUNCH(4) X3_LAUNCH(5) X3_LAUNCH(6)
+        default: return hipErrorInvalidValue;
+    }
+#undef X3_LAUNCH
+    return hipGetLastError();
+}

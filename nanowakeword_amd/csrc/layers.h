@@ -20,7 +20,14 @@ struct GemmArgs {
     // deterministic split-K: when splitk > 1, partial[z][M][N] go to splitk_ws and a second kernel adds them
     // in z order before the epilogue (bit-reproducible, unlike atomics). 0/1 = off.
     int splitk = 0; float* splitk_ws = nullptr;
+    // W pre-split into three bf16 terms ([N][ceil(K/16)][3][16], gemm_x3.hip); when set the contraction runs on the
+    // bf16 matrix cores with exact operand splitting (float32-equivalent), else on v_mfma_f32_32x32x2_f32
+    const void* Wx3 = nullptr;
 };
+size_t gemm_x3_weight_bytes(int N, int K);
+hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);
+bool gemm_x3_usable(const GemmArgs& g);
+hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s);
 // rows(M) x N x K -> recommended split (1 = none); workspace floats needed = split*M*N
 int gemm_recommended_splitk(long long M, int N, int K, int cu_count);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);

@@ -276,6 +276,15 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    if (gemm_x3_usable(g)) {
+        hipError_t e = launch_gemm_x3(g, s);
+        if (e != hipSuccess) return e;
+        if (g.splitk > 1 && g.splitk_ws) {
+            const size_t total = (size_t)g.M * g.N;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
+        }
+        return hipGetLastError();
+    }
     if (aligned) {
         const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
         GemmArgs a = g;

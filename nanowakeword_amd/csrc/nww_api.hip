@@ -70,6 +70,7 @@ struct nww_handle {
     int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
+    std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
     bool profiling = false;
@@ -311,6 +312,7 @@ extern "C" int nww_destroy(nww_handle* h) {
     free_ws(h);
     nww_stream_close(h);
     if (h->d_weights) (void)hipFree(h->d_weights);
+    for (auto& kv : h->x3_weights) (void)hipFree(kv.second);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (auto& run : h->prof_runs) for (auto e : run) (void)hipEventDestroy(e);
@@ -387,12 +389,28 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
+    // NWW_GEMM_X3=1: contractions on the bf16 matrix cores by exact operand splitting (gemm_x3.hip; experimental, slower
+    // than the float32 MFMA kernel until its load pipeline is deepened)
+    static const int x3_enabled = [] { const char* e = getenv("NWW_GEMM_X3"); return e ? atoi(e) : 0; }();
+    const void* wx3 = nullptr;
+    if (x3_enabled && N >= 32 && K >= 32) {
+        auto it = p.h->x3_weights.find(W);
+        if (it == p.h->x3_weights.end()) {
+            void* d = nullptr;
+            if (hipMalloc(&d, gemm_x3_weight_bytes(N, K)) == hipSuccess &&
+                launch_split_weights_x3(W, d, N, K, p.h->own_stream) == hipSuccess)
+                it = p.h->x3_weights.emplace(W, d).first;
+            else if (d) (void)hipFree(d);
+        }
+        if (it != p.h->x3_weights.end()) wx3 = it->second;
+    }
     if (K >= 2048 && (size_t)16 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)16 * rows_per_clip * N;
     p.add("gemm:" + name, [=](Run& r) {
         GemmArgs g;
         g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;
         g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
+        g.Wx3 = wx3;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
         g.splitk_ws = r.splitk_ws;
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
@@ -420,6 +438,15 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
     const int max_grid = p.h->cu_count;
+    // NWW_TRUNK_X3 = 9 | 6: conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip); 0: float32 MFMA
+    static const int x3 = [] { const char* e = getenv("NWW_TRUNK_X3"); return e ? atoi(e) : 0; }();
+    if ((x3 == 6 || x3 == 9) && trunk_x3_pick_strips(H, W) > 0) {
+        p.add("trunk_x3:" + name, [=](Run& r) {
+            TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
+            return launch_cnn_trunk_x3(a, x3, max_grid, r.stream);
+        });
+        return true;
+    }
     p.add("trunk:" + name, [=](Run& r) {
         TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
         return launch_cnn_trunk(a, C1, C2, max_grid, r.stream);

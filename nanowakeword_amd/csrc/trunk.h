@@ -12,10 +12,36 @@ struct TrunkArgs {
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
     int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
 };
+struct TrunkStrip {
+    int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
+};
+__host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
+    const int H1 = H / 2, H2 = H1 / 2;
+    TrunkStrip g;
+    g.R2a = (s * H2 + S - 1) / S;
+    g.R2b = ((s + 1) * H2 + S - 1) / S;
+    g.a1_base = 2 * g.R2a - 1;                                  // A1 row kept at local row 0
+    g.a1_lo = g.a1_base < 0 ? 0 : g.a1_base;
+    g.a1_hi = 2 * g.R2b < H1 - 1 ? 2 * g.R2b : H1 - 1;
+    g.a1_rows = 2 * (g.R2b - g.R2a) + 2;
+    g.iy0 = 2 * g.a1_lo - 1;                                    // input row kept at local row 0
+    const int iy1 = 2 * g.a1_hi + 2;
+    g.in_rows = iy1 - g.iy0 + 1;
+    g.y_lo = g.iy0 < 0 ? 0 : g.iy0;
+    g.y_hi = iy1 < H - 1 ? iy1 : H - 1;
+    return g;
+}
 size_t trunk_lds_bytes(int C1, int H, int W, int strips);
 // strips needed for a workgroup to fit in LDS (0 = does not fit at all); *wgs_per_cu = 2 when two workgroups share a CU
 int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu);
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s);
+
+// Same trunk with conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip): conv1's output is kept in
+// LDS as three bf16 terms per value, channels last, and every float32 product is formed from `products` = 9 (all
+// partial products, exact) or 6 (the terms below 2^-23 of the product dropped) v_mfma_f32_32x32x16_bf16.
+size_t trunk_x3_lds_bytes(int H, int W, int strips);
+int trunk_x3_pick_strips(int H, int W);
+hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, hipStream_t s);
 
 // standalone 3x3 conv (pad 1, stride 1) + bias/BN + act (+ MaxPool2) on MFMA f32 for C1 = 32 input channels and
 // Cout a multiple of 32: in [B][32][H][W] -> out [B][Cout][H or H/2][W or W/2]; one workgroup per clip, input staged in LDS.

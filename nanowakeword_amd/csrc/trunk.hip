@@ -42,25 +42,6 @@ __device__ __forceinline__ float trunk_act(float v) {
 // 2*R2a-1 .. 2*R2b (one halo row each side, recomputed by both neighbours at a seam) and for those the input rows
 // 2*a1_lo-1 .. 2*a1_hi+2.  Rows outside the image are the zero halo.  With S = 2 a (101,64) strip takes 76 KB of LDS,
 // so two workgroups share a CU and one's conv1 / epilogue gaps are filled by the other's conv2 MFMAs.
-struct TrunkStrip {
-    int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
-};
-__host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
-    const int H1 = H / 2, H2 = H1 / 2;
-    TrunkStrip g;
-    g.R2a = (s * H2 + S - 1) / S;
-    g.R2b = ((s + 1) * H2 + S - 1) / S;
-    g.a1_base = 2 * g.R2a - 1;                                  // A1 row kept at local row 0
-    g.a1_lo = g.a1_base < 0 ? 0 : g.a1_base;
-    g.a1_hi = 2 * g.R2b < H1 - 1 ? 2 * g.R2b : H1 - 1;
-    g.a1_rows = 2 * (g.R2b - g.R2a) + 2;
-    g.iy0 = 2 * g.a1_lo - 1;                                    // input row kept at local row 0
-    const int iy1 = 2 * g.a1_hi + 2;
-    g.in_rows = iy1 - g.iy0 + 1;
-    g.y_lo = g.iy0 < 0 ? 0 : g.iy0;
-    g.y_hi = iy1 < H - 1 ? iy1 : H - 1;
-    return g;
-}
 size_t trunk_lds_bytes(int C1, int H, int W, int S) {
     const int W1 = W / 2;
     if (S == 1) {                                   // whole-clip instance: planes of H+2 and H/2+2 rows

@@ -215,7 +215,7 @@ def test_cnn_trunk_row_strips_for_large_inputs(hip, shape):
     cfg = HeadConfig("cnn", shape, embedding_dim=16)
     sd = synth_state_dict(cfg)
     m = HipModel(cfg, FrontendConfig(), state_dict=sd)
-    assert "trunk:" in m.describe_plan()
+    assert "trunk" in m.describe_plan()
     feats = synth_features(3, shape, seed=shape[0])
     logits, _, emb = m.forward_features(feats, return_embedding=True)
     e_or = oracle.head_forward(feats, sd, cfg)

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
 PEAK_F32_TFLOPS = 157.3        # dense f32 peak, MFMA f32 == vector rate (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 16 * 157.3  # dense bf16 MFMA peak = 16 x the f32 MFMA rate (same guide; 2495 TF measured)
 
 
 def parse():
@@ -37,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
     ap.add_argument("--head", default="cnn")
+    ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6"],
+                    help="arithmetic of the fused conv trunk's conv2 (all float32-grade; nww_config.conv_arith)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--debug-single-gpu", action="store_true",
@@ -118,7 +121,8 @@ def main():
     cfg = HeadConfig(a.head, shape)
     sd = synth_state_dict(cfg)
     window, fb = torchaudio_tables(fe)
-    model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb)
+    arith = a.conv_arith
+    model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb, conv_arith=arith)
     B, N = a.batch, 16000
     pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
     pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
@@ -182,6 +186,13 @@ def main():
             algo["gemm:fc1"] = ("mfma", B * 2 * 32 * (T // 4) * (n_mels // 4) * 128 / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
             # fused trunk: conv1 on the 2*H1 x 2*W1 positions that survive the floor pooling + conv2 on 2*H2 x 2*W2
             algo["trunk:conv1+pool+conv2+pool"] = ("mfma", algo["conv3x3:conv1"][1] + algo["conv3x3:conv2"][1], "TFLOP/s", PEAK_F32_TFLOPS)
+            # trunk_x3: conv1 on the f32 MFMA, conv2's float32 products as P bf16 partial products on the bf16 MFMA.
+            # Its matrix-pipe speed of light is conv1/f32_peak + conv2/(bf16_peak/P); `peak` is the algorithmic
+            # (float32-equivalent) rate that corresponds to it.
+            P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
+            f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
+            peak_x3 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
+            algo["trunk_x3:conv1+pool+conv2+pool"] = ("mfma", f1 + f2, "TFLOP/s", round(peak_x3, 1))
         name = dom[0]
         if name in algo:
             bound, work, unit, peak = algo[name]
@@ -216,7 +227,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.model_type} head on (101,64) log-mel, batch={B}/GPU, 1 s 16 kHz mono int16 "
                                    "clips, 64-mel 25 ms/10 ms center frontend, fused STFT+mel HIP kernel, fp32",
-                       "clips_per_gpu": B, "n_samples": N, "parallelism": f"batch-split x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
+                       "clips_per_gpu": B, "n_samples": N,
+                       "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
+                                      "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
+                                      "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)"}[arith],
+                       "parallelism": f"batch-split x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "roofline": roofline,
             "kernel_ms": kernel_ms,
         }

@@ -74,8 +74,20 @@ typedef struct nww_config {
     /* how nww_forward_pcm feeds the head: 0 = log-mel transposed to (frames, n_mels) =
        Model(input_shape=(frames, n_mels)); 1 = (n_mels, frames) as E2E_MelSpectrogram_CNN.   */
     int32_t mel_major_features;
-    int32_t reserved[7];
+    /* arithmetic of the fused conv trunk (conv1+pool+conv2+pool of the CNN / CRNN / E2E heads); every mode computes
+       float32 results from float32 data, they differ in how conv2's products are formed:
+         NWW_ARITH_F32    v_mfma_f32_32x32x2_f32, one fmaf chain per output
+         NWW_ARITH_BF16X9 each float32 operand split into three bf16 terms (exact), all nine partial products on
+                          v_mfma_f32_32x32x16_bf16 - exact products, float32 accumulation
+         NWW_ARITH_BF16X6 the six largest partial products; the dropped ones are < 2^-23 of a product
+         NWW_ARITH_DEFAULT lets the library choose (environment NWW_TRUNK_X3 = 0 | 9 | 6 overrides)              */
+    int32_t conv_arith;
+    int32_t reserved[6];
 } nww_config;
+#define NWW_ARITH_DEFAULT 0
+#define NWW_ARITH_F32 1
+#define NWW_ARITH_BF16X6 6
+#define NWW_ARITH_BF16X9 9
 
 /* Fill *cfg with the reference defaults (16 kHz, 400/400/160, 64 mel, center, DNN (16,96)). */
 void nww_default_config(nww_config* cfg);

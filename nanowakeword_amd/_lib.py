@@ -25,7 +25,8 @@ class NwwConfig(C.Structure):
         ("n_crnn_channels", C.c_int32), ("crnn_channels", C.c_int32 * 4),
         ("conformer_d_model", C.c_int32), ("conformer_n_head", C.c_int32),
         ("mel_major_features", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("conv_arith", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -89,7 +90,11 @@ def load_library():
     return lib
 
 
-def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major_features: bool | None = None) -> NwwConfig:
+ARITH_CODE = {None: 0, "default": 0, "f32": 1, "bf16x6": 6, "bf16x9": 9}
+
+
+def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major_features: bool | None = None,
+                conv_arith: str | None = None) -> NwwConfig:
     lib = load_library()
     c = NwwConfig()
     lib.nww_default_config(C.byref(c))
@@ -111,4 +116,7 @@ def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major
     if mel_major_features is None:
         mel_major_features = head.model_type == "e2e_dnn"
     c.mel_major_features = int(bool(mel_major_features))
+    if conv_arith not in ARITH_CODE:
+        raise ValueError(f"conv_arith must be one of {sorted(k for k in ARITH_CODE if k)}")
+    c.conv_arith = ARITH_CODE[conv_arith]
     return c

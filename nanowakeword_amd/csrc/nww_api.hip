@@ -71,6 +71,7 @@ struct nww_handle {
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
+    int conv_products = 0;                         // fused trunk: 0 = float32 MFMA, 6 | 9 = bf16 split products
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
     bool profiling = false;
@@ -238,6 +239,8 @@ size_t numel(const Shape& s) { size_t n = 1; for (auto v : s) n *= (size_t)v; re
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ create / load
+// bf16x6 is float32-grade (tools/x3_accuracy.py: max |dlogit| vs float64 5.2e-6, the float32 MFMA path 5.0e-6) and 1.7x faster
+#define NWW_DEFAULT_CONV_ARITH NWW_ARITH_BF16X6
 extern "C" void nww_default_config(nww_config* c) {
     std::memset(c, 0, sizeof(*c));
     c->sample_rate = 16000; c->n_fft = 400; c->win_length = 400; c->hop_length = 160; c->n_mels = 64; c->center = 1;
@@ -258,6 +261,8 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     const nww_config& c = *cfg;
     if (c.head_type < 0 || c.head_type > NWW_HEAD_E2E_DNN) return fail(nullptr, NWW_ERR_INVALID, "Unsupported model_type code %d", c.head_type);
     if (c.activation < 0 || c.activation > 2) return fail(nullptr, NWW_ERR_INVALID, "bad activation code %d", c.activation);
+    if (c.conv_arith != NWW_ARITH_DEFAULT && c.conv_arith != NWW_ARITH_F32 && c.conv_arith != NWW_ARITH_BF16X6 && c.conv_arith != NWW_ARITH_BF16X9)
+        return fail(nullptr, NWW_ERR_INVALID, "bad conv_arith code %d", c.conv_arith);
     if (c.in_rows <= 0 || c.in_cols <= 0 || c.embedding_dim < 2 || c.layer_dim <= 0 || c.n_blocks < 0)
         return fail(nullptr, NWW_ERR_INVALID, "bad head dimensions");
     if (c.n_fft != 400) return fail(nullptr, NWW_ERR_UNSUPPORTED, "only n_fft=400 is implemented (got %d)", c.n_fft);
@@ -281,6 +286,14 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     if (c.device < 0 || c.device >= ndev) return fail(nullptr, NWW_ERR_INVALID, "device %d out of range (0..%d)", c.device, ndev - 1);
     nww_handle* h = new nww_handle();
     h->cfg = c;
+    {   // conv_arith: explicit config > environment > library default
+        int mode = c.conv_arith;
+        if (mode == NWW_ARITH_DEFAULT) {
+            const char* e = getenv("NWW_TRUNK_X3");
+            mode = e ? (atoi(e) == 6 ? NWW_ARITH_BF16X6 : atoi(e) == 9 ? NWW_ARITH_BF16X9 : NWW_ARITH_F32) : NWW_DEFAULT_CONV_ARITH;
+        }
+        h->conv_products = mode == NWW_ARITH_BF16X6 ? 6 : mode == NWW_ARITH_BF16X9 ? 9 : 0;
+    }
     h->fe.sample_rate = c.sample_rate; h->fe.n_fft = c.n_fft; h->fe.win_length = c.win_length; h->fe.hop = c.hop_length;
     h->fe.n_mels = c.n_mels; h->fe.center = c.center; h->fe.f_min = c.f_min; h->fe.f_max = c.f_max;
     h->fe.amin = c.amin; h->fe.db_mult = c.db_multiplier;
@@ -438,8 +451,8 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
     const int max_grid = p.h->cu_count;
-    // NWW_TRUNK_X3 = 9 | 6: conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip); 0: float32 MFMA
-    static const int x3 = [] { const char* e = getenv("NWW_TRUNK_X3"); return e ? atoi(e) : 0; }();
+    // conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip) or on the float32 MFMA (nww_config.conv_arith)
+    const int x3 = p.h->conv_products;
     if ((x3 == 6 || x3 == 9) && trunk_x3_pick_strips(H, W) > 0) {
         p.add("trunk_x3:" + name, [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};

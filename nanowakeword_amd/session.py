@@ -61,13 +61,14 @@ class HipModel:
     """One finalized head (+ frontend) on one GPU behind the C-ABI."""
 
     def __init__(self, head: HeadConfig, frontend: Optional[FrontendConfig] = None, device: int = 0,
-                 state_dict: Optional[Mapping] = None, window=None, mel_fb=None, tables: str = "torchaudio"):
+                 state_dict: Optional[Mapping] = None, window=None, mel_fb=None, tables: str = "torchaudio",
+                 conv_arith: Optional[str] = None):
         self.lib = _lib.load_library()      # ImportError if the HIP extension is missing - no fallback
         self.head = head
         self.fe = frontend or FrontendConfig()
         self.device = device
         self._h = C.c_void_p()
-        cfg = _lib.make_config(head, self.fe, device)
+        cfg = _lib.make_config(head, self.fe, device, conv_arith=conv_arith)      # None: library default
         rc = self.lib.nww_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             msg = self.lib.nww_last_error(None).decode()

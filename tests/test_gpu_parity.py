@@ -222,3 +222,33 @@ def test_cnn_trunk_row_strips_for_large_inputs(hip, shape):
     assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max())
     assert np.abs(logits - oracle.model_forward(feats, sd, cfg).ravel()).max() <= FEAT_LOGIT_ATOL
     m.close()
+
+
+def test_conv_arithmetic_modes_agree(hip, golden_frontend):
+    """conv2 of the fused trunk on the float32 MFMA, or on the bf16 MFMA from exactly split operands with nine (exact
+    products) or six partial products: all three are float32-grade - each sits as close to the oracle as the others,
+    and every mode is deterministic and batch invariant."""
+    HipModel, _ = hip
+    g = golden_frontend
+    cfg = HeadConfig("cnn", (101, 64))
+    sd = synth_state_dict(cfg)
+    feats = synth_features(40, cfg.input_shape, seed=77)
+    ref = oracle.model_forward(feats, sd, cfg).ravel()
+    out = {}
+    for mode in ("f32", "bf16x9", "bf16x6"):
+        m = HipModel(cfg, _fe_cfg(64, True), state_dict=sd, window=g["window"], mel_fb=g["fb64"], conv_arith=mode)
+        assert ("trunk_x3:" in m.describe_plan()) == (mode != "f32")
+        lg, _ = m.forward_features(feats)
+        lg2, _ = m.forward_features(feats[::-1].copy())
+        assert np.array_equal(lg, lg2[::-1]), mode                     # batch position does not matter, bit for bit
+        lg3, _ = m.forward_features(feats[:7])
+        assert np.array_equal(lg[:7], lg3), mode
+        out[mode] = lg
+        m.close()
+    err = {k: float(np.abs(v - ref).max()) for k, v in out.items()}
+    print("max |dlogit| vs oracle:", err)
+    assert max(err.values()) <= 2e-5                                   # 5x tighter than the 1e-4 parity bar
+    assert max(err.values()) <= 3 * min(err.values()) + 2e-6           # no mode is meaningfully worse than another
+    assert np.abs(out["bf16x6"] - out["f32"]).max() <= 2e-5 and np.abs(out["bf16x9"] - out["f32"]).max() <= 2e-5
+    with pytest.raises(ValueError):
+        HipModel(cfg, _fe_cfg(64, True), conv_arith="fp8")

@@ -76,6 +76,44 @@ __global__ void __launch_bounds__(256) k_mix(float* out, int iters, uint32_t see
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// 6 products per tap (the bf16x6 ratio: 3 fragment reads per 6 MFMAs and tile), row stride WP pixels
+template <int PS, int WP>
+__global__ void __launch_bounds__(512) k_mix6(float* out, int iters, uint32_t seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    for (int k = threadIdx.x; k < 100 * 1024 / 4; k += 512) reinterpret_cast<uint32_t*>(lds)[k] = seed + k;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int x = 2 * (i >> 2) + (i & 1), dy = (i >> 1) & 1;
+    const unsigned char* base = lds + ((dy + 2 * (wave & 3)) * WP + x) * PS + 16 * h;
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    uint4 bv = make_uint4(seed, seed * 3, seed * 5, seed * 7);
+    bf16x8 B0 = __builtin_bit_cast(bf16x8, bv), B1 = B0, B2 = B0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned char* p = base + (it % 3) * PS + ((it / 3) % 3) * WP * PS;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(p), a1 = *reinterpret_cast<const bf16x8*>(p + 32),
+                     a2 = *reinterpret_cast<const bf16x8*>(p + 64);
+        const unsigned char* q = p + 16 * PS;
+        const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(q), c1 = *reinterpret_cast<const bf16x8*>(q + 32),
+                     c2 = *reinterpret_cast<const bf16x8*>(q + 64);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, B1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, B0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, B0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B0, acc1, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <typename F>
 static float time_ms(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -96,5 +134,13 @@ int main() {
     printf("mix PS=112     : %.3f ms  %.1f TFLOP/s (bf16 flops)\n", ms, 2.0 * 32 * 32 * 16 * 18 * (iters / 4) * 4.0 * grid / ms / 1e9);
     ms = time_ms([&] { hipLaunchKernelGGL(k_mix<96>, dim3(grid), dim3(256), 65536, 0, out, iters / 4, 7u); });
     printf("mix PS=96      : %.3f ms  %.1f TFLOP/s (bf16 flops)\n", ms, 2.0 * 32 * 32 * 16 * 18 * (iters / 4) * 4.0 * grid / ms / 1e9);
+#define MIX6(PSV, WPV)                                                                                              \
+    {                                                                                                               \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_mix6<PSV, WPV>), hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024); \
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mix6<PSV, WPV>), dim3(256), dim3(512), 110 * 1024, 0, out, iters / 4, 7u); });       \
+        printf("mix6 PS=%d WP=%d (1 WG x 8 waves per CU): %.3f ms  %.1f TFLOP/s (bf16 flops)\n", PSV, WPV, ms,        \
+               2.0 * 32 * 32 * 16 * 12 * (iters / 4) * 8.0 * 256 / ms / 1e9);                                       \
+    }
+    MIX6(96, 34) MIX6(112, 34) MIX6(112, 40) MIX6(96, 36) MIX6(128, 34)
     return 0;
 }

@@ -74,8 +74,9 @@ typedef struct nww_config {
     /* how nww_forward_pcm feeds the head: 0 = log-mel transposed to (frames, n_mels) =
        Model(input_shape=(frames, n_mels)); 1 = (n_mels, frames) as E2E_MelSpectrogram_CNN.   */
     int32_t mel_major_features;
-    /* arithmetic of the fused conv trunk (conv1+pool+conv2+pool of the CNN / CRNN / E2E heads); every mode computes
-       float32 results from float32 data, they differ in how conv2's products are formed:
+    /* arithmetic of the large MFMA contractions - conv2 of the fused conv trunk (CNN / CRNN / E2E heads) and Linear
+       layers with K >= 4096 (fc1 of the CNN head); every mode computes float32 results from float32 data, they differ
+       in how the products are formed:
          NWW_ARITH_F32    v_mfma_f32_32x32x2_f32, one fmaf chain per output
          NWW_ARITH_BF16X9 each float32 operand split into three bf16 terms (exact), all nine partial products on
                           v_mfma_f32_32x32x16_bf16 - exact products, float32 accumulation

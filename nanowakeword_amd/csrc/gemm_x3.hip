@@ -10,8 +10,9 @@
 // head) at 16/6 = 2.7x the float32 MFMA rate.  Determinism and batch invariance are unchanged: fixed K order per
 // output, split-K chunks depend on (N, K) only.
 //
-// Tiling: workgroup = 4 waves stacked along M, BM = 128 rows x BN = 32*CB columns, BK = 16 (one MFMA K).  LDS rows are
-// [3 terms][16 k] bf16 + 16 B pad = 112 B, which makes the per-lane 16-byte fragment reads conflict-free.  A is split
+// Tiling: workgroup = 4 waves stacked along M, BM = 128 rows x BN = 32*CB columns, BK = 32 (two MFMA K blocks).  LDS
+// rows are [3 terms][32 k] bf16 + 16 B pad = 208 B, which makes the per-lane 16-byte fragment reads conflict-free; two
+// workgroups share a CU; the next k-tile's global loads travel in registers during the multiplication.  A is split
 // while it is staged into LDS (5.5 VALU ops per element, amortised over 32*CB columns); W is split once at
 // nww_finalize into the same [N][K/16][3][16] layout so its tiles are plain 16-byte copies.
 #include <hip/hip_runtime.h>
@@ -23,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int X3_ROW = 112;                      // bytes per LDS row
+constexpr int X3_ROW = 208;                      // bytes per LDS row: 3 terms x 32 k x bf16 + 16 pad (conflict-free b128 reads)
 constexpr int X3_BM = 128;
 
 __device__ __forceinline__ float x3_act(float v, int act) {
@@ -68,67 +69,70 @@ __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __re
 template <int CB>
 __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
     constexpr int BN = 32 * CB;
-    constexpr int WPIECES = BN * 6;                            // 16-byte pieces of a W tile
+    constexpr int WPIECES = BN * 12;                           // 16-byte pieces of a W tile (32 k x 3 terms per row)
     constexpr int WLD = (WPIECES + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    auto As = [&](int buf) { return smem + buf * (X3_BM * X3_ROW); };
-    auto Ws = [&](int buf) { return smem + 2 * X3_BM * X3_ROW + buf * (BN * X3_ROW); };
+    auto As = [&](int) { return smem; };
+    auto Ws = [&](int) { return smem + X3_BM * X3_ROW; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int bm = blockIdx.x * X3_BM, bn = blockIdx.y * BN;
-    const int KB = (g.K + 15) >> 4;
-    int kb_begin = 0, kb_end = KB;
+    const int KB = (g.K + 15) >> 4, KT = (g.K + 31) >> 5;      // 16-k blocks of the split weights, 32-k tiles
+    int kt_begin = 0, kt_end = KT;
     if (g.splitk > 1) {
-        const int kc = (KB + g.splitk - 1) / g.splitk;
-        kb_begin = blockIdx.z * kc;
-        kb_end = min(KB, kb_begin + kc);
+        const int kc = (KT + g.splitk - 1) / g.splitk;
+        kt_begin = blockIdx.z * kc;
+        kt_end = min(KT, kt_begin + kc);
     }
     const uint4* Wx = reinterpret_cast<const uint4*>(g.Wx3);
 
-    // A loader: thread -> rows (tid>>2) and (tid>>2)+64, floats 4*(tid&3) .. +3 of the 16-k block
-    const int lr = tid >> 2, lq = tid & 3;
-    const float* arow[2];
+    // A loader: thread -> rows (tid>>3) + 32q, floats 4*(tid&7) .. +3 of the 32-k tile
+    const int lr = tid >> 3, lq = tid & 7;
+    const float* arow[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) arow[q] = g.A + (size_t)min(bm + lr + 64 * q, g.M - 1) * g.lda + 4 * lq;
-    auto gload = [&](int kb, float4 (&ra)[2], uint4 (&rw)[WLD]) {
-        const int k = kb * 16 + 4 * lq;
+    for (int q = 0; q < 4; ++q) arow[q] = g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
+    struct Stage { float4 a[4]; uint4 w[WLD]; };
+    auto gload = [&](int kt, Stage& st) {
+        const int k = kt * 32 + 4 * lq;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             if (k + 4 <= g.K) {
-                ra[q] = *reinterpret_cast<const float4*>(arow[q] + kb * 16);
-            } else {                                           // K tail (K % 16 != 0): element-wise, zero beyond K
-                const float* p = arow[q] + kb * 16;
-                ra[q].x = k + 0 < g.K ? p[0] : 0.0f; ra[q].y = k + 1 < g.K ? p[1] : 0.0f;
-                ra[q].z = k + 2 < g.K ? p[2] : 0.0f; ra[q].w = k + 3 < g.K ? p[3] : 0.0f;
+                st.a[q] = *reinterpret_cast<const float4*>(arow[q] + kt * 32);
+            } else {                                           // K tail: element-wise, zero beyond K
+                const float* p = arow[q] + kt * 32;
+                st.a[q].x = k + 0 < g.K ? p[0] : 0.0f; st.a[q].y = k + 1 < g.K ? p[1] : 0.0f;
+                st.a[q].z = k + 2 < g.K ? p[2] : 0.0f; st.a[q].w = k + 3 < g.K ? p[3] : 0.0f;
             }
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) {
             const int p = tid + 256 * j;
             if (WPIECES % 256 == 0 || p < WPIECES) {
-                const int row = p / 6, c = p - row * 6;
+                const int row = p / 12, c = p - row * 12;
                 const int n = min(bn + row, g.N - 1);
-                rw[j] = Wx[((size_t)n * KB + kb) * 6 + c];
+                const int kb = 2 * kt + c / 6;                 // 16-k block of this piece
+                st.w[j] = kb < KB ? Wx[((size_t)n * KB + kb) * 6 + (c % 6)] : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto lstore = [&](int buf, const float4 (&ra)[2], const uint4 (&rw)[WLD]) {
+    auto lstore = [&](int buf, const Stage& st) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             uint32_t hi[4], mid[4], lo[4];
-            split3(ra[q].x, hi[0], mid[0], lo[0]); split3(ra[q].y, hi[1], mid[1], lo[1]);
-            split3(ra[q].z, hi[2], mid[2], lo[2]); split3(ra[q].w, hi[3], mid[3], lo[3]);
-            unsigned char* d = As(buf) + (lr + 64 * q) * X3_ROW + 8 * lq;
+            split3(st.a[q].x, hi[0], mid[0], lo[0]); split3(st.a[q].y, hi[1], mid[1], lo[1]);
+            split3(st.a[q].z, hi[2], mid[2], lo[2]); split3(st.a[q].w, hi[3], mid[3], lo[3]);
+            unsigned char* d = As(buf) + (lr + 32 * q) * X3_ROW + 8 * lq;
             *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
-            *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
-            *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+            *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+            *reinterpret_cast<uint2*>(d + 128) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) {
             const int p = tid + 256 * j;
             if (WPIECES % 256 == 0 || p < WPIECES) {
-                const int row = p / 6, c = p - row * 6;
-                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + 16 * c) = rw[j];
+                const int row = p / 12, c = p - row * 12;
+                const int c6 = c % 6;                          // (term, half) inside the 16-k block
+                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + (c6 >> 1) * 64 + (c / 6) * 32 + (c6 & 1) * 16) = st.w[j];
             }
         }
     };
@@ -139,37 +143,35 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
-    float4 ra[2];
-    uint4 rw[WLD];
-    int cur = 0;
-    if (kb_begin < kb_end) {
-        gload(kb_begin, ra, rw);
-        lstore(0, ra, rw);
-    }
-    __syncthreads();
+    // One LDS stage per workgroup (53 KB for BN = 128, so two workgroups share a CU and cover each other's staging
+    // phases); the next k-tile's global loads travel in registers while the current one is multiplied.
+    Stage st;
+    if (kt_begin < kt_end) gload(kt_begin, st);
     const int a_off = (wave * 32 + i) * X3_ROW + 16 * h, w_off = i * X3_ROW + 16 * h;
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-        const bool more = kb + 1 < kb_end;
-        if (more) gload(kb + 1, ra, rw);
-        const unsigned char* ap = As(cur) + a_off;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + 32),
-                     al = *reinterpret_cast<const bf16x8*>(ap + 64);
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const unsigned char* wp = Ws(cur) + w_off + c * 32 * X3_ROW;
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wp), wm = *reinterpret_cast<const bf16x8*>(wp + 32),
-                         wl = *reinterpret_cast<const bf16x8*>(wp + 64);
-            // small terms first, the dominant hi*hi last
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[c], 0, 0, 0);
-        }
-        if (more) lstore(cur ^ 1, ra, rw);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();                                       // everyone is done reading the previous tile
+        lstore(0, st);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 < kt_end) gload(kt + 1, st);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned char* ap = As(0) + a_off + 32 * kk;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + 64),
+                         al = *reinterpret_cast<const bf16x8*>(ap + 128);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const unsigned char* wp = Ws(0) + w_off + c * 32 * X3_ROW + 32 * kk;
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wp), wm = *reinterpret_cast<const bf16x8*>(wp + 64),
+                             wl = *reinterpret_cast<const bf16x8*>(wp + 128);
+                // small terms first, the dominant hi*hi last
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[c], 0, 0, 0);
+            }
+        }
     }
 
     const int m0 = bm + wave * 32;
@@ -237,7 +239,7 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     GemmArgs a = g;
     a.splitk = sk;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
-    const size_t lds = 2 * (size_t)(X3_BM + bn) * X3_ROW;
+    const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;
     static size_t attr_for[7] = {0};
 #define X3_LAUNCH(CBV)                                                                                             \
     case CBV: {                                                                                                    \

@@ -402,11 +402,14 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
-    // NWW_GEMM_X3=1: contractions on the bf16 matrix cores by exact operand splitting (gemm_x3.hip; experimental, slower
-    // than the float32 MFMA kernel until its load pipeline is deepened)
-    static const int x3_enabled = [] { const char* e = getenv("NWW_GEMM_X3"); return e ? atoi(e) : 0; }();
+    // Long-K contractions (fc1 of the CNN head: K = 12 800) run on the bf16 matrix cores by exact operand splitting
+    // (gemm_x3.hip) with a fine split-K; short-K shapes stay on the float32 MFMA kernel, which hides its load latency
+    // better with its smaller tiles.  The choice depends on (N, K) only, so batch invariance is kept.
+    // NWW_GEMM_X3 = 0: never, 2: every shape with N, K >= 32 (experiments).
+    static const int x3_mode = [] { const char* e = getenv("NWW_GEMM_X3"); return e ? atoi(e) : 1; }();
+    const bool use_x3 = x3_mode == 2 ? (N >= 32 && K >= 32) : (x3_mode == 1 && p.h->conv_products != 0 && K >= 4096 && N >= 64 && N <= 256);
     const void* wx3 = nullptr;
-    if (x3_enabled && N >= 32 && K >= 32) {
+    if (use_x3) {
         auto it = p.h->x3_weights.find(W);
         if (it == p.h->x3_weights.end()) {
             void* d = nullptr;
@@ -425,6 +428,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
         g.Wx3 = wx3;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
+        if (wx3 && x3_mode == 1) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
         g.splitk_ws = r.splitk_ws;
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
         return launch_gemm(g, r.stream);

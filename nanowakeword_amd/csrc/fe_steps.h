@@ -152,19 +152,25 @@ NWW_HD void fe_s2(int f, int k1, nww_c32* yz) {
     dft25([&](int i) { return row[i]; }, [&](int i, nww_c32 v) { row[i] = v; });
 }
 
+// S3 arithmetic: Z[k] = A, Z[200-k] = B of the 200-point complex FFT -> power of bins k and 200-k of the 400-point
+// real FFT (tw = exp(-2 pi i k / 400)).
+NWW_HD void fe_s3_core(nww_c32 A, nww_c32 B, nww_c32 tw, float* pa, float* pb) {
+    const nww_c32 E = c_make(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+    const nww_c32 O = c_make(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
+    const nww_c32 wO = c_mul(tw, O);
+    const nww_c32 Xa = c_add(E, wO), Xb = c_sub(E, wO);
+    *pa = Xa.x * Xa.x + Xa.y * Xa.y;
+    *pb = Xb.x * Xb.x + Xb.y * Xb.y;
+}
+// position of Z[k] in the S2 output order
+NWW_HD int fe_zpos(int k) { return (k & 7) * 25 + (k >> 3); }
+
 // S3: task (frame f, bin k in 0..100): power of bins k and 200-k into pw[f*FE_PSTRIDE + ...].
 NWW_HD void fe_s3(int f, int k, const FeTables* tb, const nww_c32* yz, float* pw) {
     const nww_c32* zf = yz + f * 200;
     const int kb = (k == 0) ? 0 : 200 - k;
-    const nww_c32 A = zf[(k & 7) * 25 + (k >> 3)];
-    const nww_c32 B = zf[(kb & 7) * 25 + (kb >> 3)];
-    const nww_c32 E = c_make(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-    const nww_c32 O = c_make(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
-    const nww_c32 wO = c_mul(tb->tw400[k], O);
-    const nww_c32 Xa = c_add(E, wO), Xb = c_sub(E, wO);
     float* p = pw + f * FE_PSTRIDE;
-    p[k] = Xa.x * Xa.x + Xa.y * Xa.y;
-    p[200 - k] = Xb.x * Xb.x + Xb.y * Xb.y;
+    fe_s3_core(zf[fe_zpos(k)], zf[fe_zpos(kb)], tb->tw400[k], &p[k], &p[200 - k]);
 }
 
 // S4: task (frame f, mel j): sparse triangular contraction; returns mel power.

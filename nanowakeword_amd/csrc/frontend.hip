@@ -102,9 +102,24 @@ fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B,
         for (int task = (dbg & 2) ? nf * 8 : tid; task < nf * 8; task += nthr) fe_s2(task >> 3, task & 7, yz);
         __syncthreads();
         // ---- S3
-        for (int task = (dbg & 4) ? nf * 101 : tid; task < nf * 101; task += nthr) {
-            const int f = task / 101;
-            fe_s3(f, task - f * 101, tb, yz, pw);
+        if ((nthr & 127) == 0) {
+            // lane -> bin k (fixed for the whole chunk: positions and twiddle live in registers), frames strided over
+            // the nthr/128 lane groups; 101 of 128 lanes busy, ~20 VALU per (frame, bin) instead of 46
+            const int k3 = tid & 127;
+            if (k3 <= 100 && !(dbg & 4)) {
+                const int ia = fe_zpos(k3), ib = fe_zpos(k3 ? 200 - k3 : 0);
+                const nww_c32 tw = tb->tw400[k3];
+                for (int f = tid >> 7; f < nf; f += nthr >> 7) {
+                    const nww_c32* zf = yz + f * 200;
+                    float* p = pw + f * FE_PSTRIDE;
+                    fe_s3_core(zf[ia], zf[ib], tw, &p[k3], &p[200 - k3]);
+                }
+            }
+        } else {
+            for (int task = (dbg & 4) ? nf * 101 : tid; task < nf * 101; task += nthr) {
+                const int f = task / 101;
+                fe_s3(f, task - f * 101, tb, yz, pw);
+            }
         }
         __syncthreads();
         // ---- S4: sparse mel + dB.  Tasks are filter-major (lane = frame of one filter) so all lanes of a wave run
@@ -113,11 +128,24 @@ fe_stft_mel_db_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B,
         if (frames_major) {          // out[b][t][j]: stage [f][j] in LDS (yz is free after S3), then store coalesced
             float* stage = reinterpret_cast<float*>(yz);
             float* stage_m = stage + fc * n_mels;
-            for (int task = tid; task < ntask; task += nthr) {
-                const int j = task / nf, f = task - j * nf;
-                const float m = fe_s4(f, j, tb, pw);
-                stage[f * n_mels + j] = fe_db(m, amin, db_mult);
-                if (out_mel) stage_m[f * n_mels + j] = m;
+            if (fc <= 16) {
+                // lane -> (filter slot jj = lane>>4, frame f = lane&15): the frame's row pointer is fixed, a wave walks
+                // filter quads 4*(wave + nw*it) .. +3 - no division, 4 filters (similar tap counts) per wave instruction
+                const int f = tid & 15, jj = (tid >> 4) & 3, wv = tid >> 6, nwv = nthr >> 6;
+                if (f < nf && ntask) {
+                    for (int j = 4 * wv + jj; j < n_mels; j += 4 * nwv) {
+                        const float m = fe_s4(f, j, tb, pw);
+                        stage[f * n_mels + j] = fe_db(m, amin, db_mult);
+                        if (out_mel) stage_m[f * n_mels + j] = m;
+                    }
+                }
+            } else {
+                for (int task = tid; task < ntask; task += nthr) {
+                    const int j = task / nf, f = task - j * nf;
+                    const float m = fe_s4(f, j, tb, pw);
+                    stage[f * n_mels + j] = fe_db(m, amin, db_mult);
+                    if (out_mel) stage_m[f * n_mels + j] = m;
+                }
             }
             __syncthreads();
             float* ob = out_db ? out_db + ((size_t)b * T + t0) * n_mels : nullptr;

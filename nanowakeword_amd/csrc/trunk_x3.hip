@@ -36,7 +36,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int PS = 96;                  // bytes per A1 pixel: 3 terms x 16 channels x bf16
-constexpr int C1 = 16, C2 = 32, NW = 8, NTHR = 64 * NW;
+constexpr int C1 = 16, C2 = 32;
 
 template <int ACT>
 __device__ __forceinline__ float x3_trunk_act(float v) {
@@ -154,8 +154,9 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
 // BN: either conv carries a folded BatchNorm (a missing one is alpha = 1, beta = 0, which is exact).
 // A workgroup keeps ONE strip index for its whole life, so the zero halos written once stay valid.  (Walking whole clips
 // strip by strip instead - equal work per workgroup, halo rows re-zeroed per item - measured 0.417 vs 0.406 ms.)
-template <int ACT, int PRODUCTS, bool BN>
-__global__ void __launch_bounds__(NTHR, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
+template <int ACT, int PRODUCTS, bool BN, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
+    constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
     const int S = a.strips;
@@ -359,25 +360,31 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     if (S < 1) return hipErrorInvalidValue;
     aa.strips = S;
     const size_t lds = trunk_x3_lds_bytes(a.H, a.W, S);
-    long want = (long)a.B * S;
-    int grid = (int)(want < max_grid ? want : max_grid);
+    // experiments: NWW_X3_WAVES=4 runs 4-wave workgroups, two per CU when the strip fits 80 KB
+    static const int force_nw = [] { const char* e = getenv("NWW_X3_WAVES"); return e ? atoi(e) : 0; }();
+    const int nw = force_nw == 4 ? 4 : 8;
+    const int per_cu = (nw == 4 && lds <= 80 * 1024) ? 2 : 1;
+    long want = (long)a.B * S, cap = (long)max_grid * per_cu;
+    int grid = (int)(want < cap ? want : cap);
     grid -= grid % S;
     if (grid < S) grid = S;
     const bool bn = a.al1 != nullptr || a.al2 != nullptr;
-    static size_t attr_for[12] = {0};
-#define X3T_LAUNCH(ACTV, PRODV, BNV, SLOT)                                                                         \
+    static size_t attr_for[24] = {0};
+#define X3T_LAUNCH(ACTV, PRODV, BNV, NWV, SLOT)                                                                    \
     {                                                                                                              \
         if (lds > attr_for[SLOT]) {                                                                                \
             hipError_t e = hipFuncSetAttribute(                                                                    \
-                reinterpret_cast<const void*>(cnn_trunk_x3_kernel<ACTV, PRODV, BNV>),                              \
+                reinterpret_cast<const void*>(cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>),                         \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
             if (e != hipSuccess) return e;                                                                         \
             attr_for[SLOT] = lds;                                                                                  \
         }                                                                                                          \
-        hipLaunchKernelGGL((cnn_trunk_x3_kernel<ACTV, PRODV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa);           \
+        hipLaunchKernelGGL((cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);  \
     }
+#define X3T_NW(ACTV, PRODV, BNV, SLOT)                                                                             \
+    if (nw == 4) X3T_LAUNCH(ACTV, PRODV, BNV, 4, SLOT) else X3T_LAUNCH(ACTV, PRODV, BNV, 8, SLOT + 12)
 #define X3T_BN(ACTV, PRODV, SLOT)                                                                                  \
-    if (bn) X3T_LAUNCH(ACTV, PRODV, true, SLOT) else X3T_LAUNCH(ACTV, PRODV, false, SLOT + 6)
+    if (bn) X3T_NW(ACTV, PRODV, true, SLOT) else X3T_NW(ACTV, PRODV, false, SLOT + 6)
 #define X3T_ACT(ACTV, SLOT)                                                                                        \
     if (products == 6) X3T_BN(ACTV, 6, SLOT) else X3T_BN(ACTV, 9, SLOT + 3)
     switch (a.act) {
@@ -387,6 +394,7 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
         default: return hipErrorInvalidValue;
     }
 #undef X3T_LAUNCH
+#undef X3T_NW
 #undef X3T_BN
 #undef X3T_ACT
     return hipGetLastError();

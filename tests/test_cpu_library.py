@@ -29,6 +29,27 @@ def test_header_symbols_exported():
     assert b"gfx950" in lib.nww_version()
 
 
+def test_config_struct_mirrors_header():
+    """ctypes NwwConfig vs struct nww_config: same field names in the same order, and the arithmetic codes."""
+    from nanowakeword_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nww.h")).read()
+    body = hdr[hdr.index("typedef struct nww_config {") + len("typedef struct nww_config {"):hdr.index("} nww_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(?:int32_t|float)\s+(.*)", decl.strip(), flags=re.S)
+        if m:
+            names += [re.sub(r"\[.*\]", "", n).strip() for n in m.group(1).split(",")]
+    assert names == [f[0] for f in _lib.NwwConfig._fields_]
+    assert ctypes.sizeof(_lib.NwwConfig) == 4 * (len(names) + 3 + 5)      # crnn_channels[4] and reserved[6] arrays
+    for key, code in (("f32", "NWW_ARITH_F32"), ("bf16x6", "NWW_ARITH_BF16X6"), ("bf16x9", "NWW_ARITH_BF16X9")):
+        assert int(re.search(rf"#define {code} (\d+)", hdr).group(1)) == _lib.ARITH_CODE[key]
+    cfg = _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="bf16x9")
+    assert cfg.conv_arith == 9 and _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig()).conv_arith == 0
+    with pytest.raises(ValueError):
+        _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="fp8")
+
+
 def test_no_gpu_means_loud_failure():
     """Without a HIP device the product must raise, never fall back to a CPU path."""
     import torch

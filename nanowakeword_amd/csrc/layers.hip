@@ -250,9 +250,11 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmArgs g) {
 // batch or shard it is computed in (the K-chunk boundaries and the z-order of the reduction are fixed).
 int gemm_recommended_splitk(long long M, int N, int K, int cu_count) {
     (void)M; (void)cu_count;
-    if (K < 4096 || N > 256) return 1;
-    static const int div = [] { const char* e = getenv("NWW_SPLITK_DIV"); return e ? atoi(e) : 3072; }();
-    int s = K / div;
+    if (K < 2048 || N > 256) return 1;
+    // K >= 4096 (fc1-like): chunks of ~3072; 2048 <= K < 4096 (DNN layer1 on (98,40): K = 3920, two column tiles
+    // only): chunks of ~1024 so that small batches still spread over a few dozen CUs
+    static const int div = [] { const char* e = getenv("NWW_SPLITK_DIV"); return e ? atoi(e) : 0; }();
+    int s = K / (div > 0 ? div : (K >= 4096 ? 3072 : 1024));
     return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 

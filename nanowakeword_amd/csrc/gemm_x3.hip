@@ -233,7 +233,8 @@ bool gemm_x3_usable(const GemmArgs& g) {
 }
 
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
-    const int cb = x3_pick_cb(g.N);
+    static const int force_cb = [] { const char* e = getenv("NWW_X3_CB"); return e ? atoi(e) : 0; }();
+    const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);
     const int bn = 32 * cb;
     const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
     GemmArgs a = g;

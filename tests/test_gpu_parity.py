@@ -252,3 +252,20 @@ def test_conv_arithmetic_modes_agree(hip, golden_frontend):
     assert np.abs(out["bf16x6"] - out["f32"]).max() <= 2e-5 and np.abs(out["bf16x9"] - out["f32"]).max() <= 2e-5
     with pytest.raises(ValueError):
         HipModel(cfg, _fe_cfg(64, True), conv_arith="fp8")
+
+
+@pytest.mark.parametrize("shape", [(37, 28), (64, 64), (100, 100), (17, 130), (12, 12), (41, 18), (256, 32)])
+@pytest.mark.parametrize("arith", ["bf16x6", "f32"])
+def test_cnn_trunk_odd_shapes(hip, shape, arith):
+    """Edge geometry of the fused trunk: odd sizes (floor pooling drops a row/column), widths that leave partial
+    MFMA tiles, strips of unequal height, tiny and tall inputs - in both arithmetics."""
+    HipModel, _ = hip
+    cfg = HeadConfig("cnn", shape, embedding_dim=16, activation="silu" if shape[0] % 2 else "relu")
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith=arith)
+    feats = synth_features(5, shape, seed=shape[0] * 7 + shape[1])
+    logits, _, emb = m.forward_features(feats, return_embedding=True)
+    e_or = oracle.head_forward(feats, sd, cfg)
+    assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max()), (shape, arith)
+    assert np.abs(logits - oracle.model_forward(feats, sd, cfg).ravel()).max() <= FEAT_LOGIT_ATOL
+    m.close()

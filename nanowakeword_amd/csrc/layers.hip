@@ -762,8 +762,51 @@ dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     float v = (acc + bias[d]) * alpha[d] + beta[d];
     y[idx] = v / (1.0f + expf(-v));
 }
+// Register-blocked version for the Conformer's kernel_size 31: a lane owns channel d of TB consecutive frames, loads the
+// TB + K - 1 inputs it needs once (coalesced along d) and keeps the K weights in registers: 38 loads per 248 FMAs instead
+// of one load per FMA.  Same fmaf order per output as the generic kernel (a zero-padded tap adds exactly nothing).
+template <int K, int TB>
+__global__ void __launch_bounds__(256)
+dwconv1d_blocked_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                        const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ y, int T,
+                        int D, int nTB, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = (b*nTB + tb)*D + d
+    if (idx >= total) return;
+    const int d = (int)(idx % D);
+    const size_t r = idx / D;
+    const int tb = (int)(r % nTB);
+    const size_t b = r / nTB;
+    const int t0 = tb * TB, left = K / 2;
+    const float* xb = x + b * (size_t)T * D + d;
+    float wv[K], xin[TB + K - 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wv[k] = w[(size_t)d * K + k];
+#pragma unroll
+    for (int j = 0; j < TB + K - 1; ++j) {
+        const int tt = t0 - left + j;
+        xin[j] = (tt >= 0 && tt < T) ? xb[(size_t)tt * D] : 0.0f;
+    }
+    const float bs = bias[d], al = alpha[d], be = beta[d];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = fmaf(xin[j + k], wv[k], acc);
+        const float v = (acc + bs) * al + be;
+        if (t0 + j < T) y[(b * T + t0 + j) * (size_t)D + d] = v / (1.0f + expf(-v));
+    }
+}
+
 hipError_t launch_dwconv1d_bn_swish(const float* x, const float* w, const float* bias, const float* alpha,
                                     const float* beta, float* y, int B, int T, int D, int K, hipStream_t s) {
+    if (K == 31) {
+        constexpr int TB = 8;
+        const int nTB = (T + TB - 1) / TB;
+        const size_t lanes = (size_t)B * nTB * D;
+        hipLaunchKernelGGL((dwconv1d_blocked_kernel<31, TB>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, x, w,
+                           bias, alpha, beta, y, T, D, nTB, lanes);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * T * D;
     hipLaunchKernelGGL(dwconv1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha,
                        beta, y, T, D, K, total);

@@ -937,14 +937,34 @@ __global__ void __launch_bounds__(512) gru_kernel(GruArgs a) {
         f32x16 ar, az, an;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ar[r] = 0.0f; az[r] = 0.0f; an[r] = 0.0f; }
+        // the input-side gate pre-activations of this step do not depend on h: fetch them (HBM, one row per clip)
+        // before the recurrent product so their latency hides under the MFMA loop
+        float xr[16], xz[16], xn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            xr[r] = xz[r] = xn[r] = 0.0f;
+            if (b < a.B && jok) {
+                const float* xg = a.xg + ((size_t)b * a.T + t) * 3 * H;
+                xr[r] = xg[j]; xz[r] = xg[H + j]; xn[r] = xg[2 * H + j];
+            }
+        }
         if (step > 0) {                                       // h == 0 on the first step
+            // W_hh streams from L2 every step; the next 8-k slice is requested before the current one is multiplied
+            float4 nbr = make_float4(0, 0, 0, 0), nbz = nbr, nbn = nbr;
+            if (4 * hh + 4 <= H) {
+                nbr = *reinterpret_cast<const float4*>(wr); nbz = *reinterpret_cast<const float4*>(wz);
+                nbn = *reinterpret_cast<const float4*>(wn);
+            }
             for (int k = 0; k < H; k += 8) {
-                float4 av = make_float4(0, 0, 0, 0), br = av, bz = av, bn = av;
-                if (k + 4 * hh + 4 <= H) {
-                    av = *reinterpret_cast<const float4*>(arow + k);
-                    br = *reinterpret_cast<const float4*>(wr + k);
-                    bz = *reinterpret_cast<const float4*>(wz + k);
-                    bn = *reinterpret_cast<const float4*>(wn + k);
+                float4 av = make_float4(0, 0, 0, 0);
+                const float4 br = nbr, bz = nbz, bn = nbn;
+                if (k + 4 * hh + 4 <= H) av = *reinterpret_cast<const float4*>(arow + k);
+                nbr = nbz = nbn = make_float4(0, 0, 0, 0);
+                if (k + 8 + 4 * hh + 4 <= H) {
+                    nbr = *reinterpret_cast<const float4*>(wr + k + 8);
+                    nbz = *reinterpret_cast<const float4*>(wz + k + 8);
+                    nbn = *reinterpret_cast<const float4*>(wn + k + 8);
                 }
                 ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, br.x, ar, 0, 0, 0);
                 az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bz.x, az, 0, 0, 0);
@@ -967,10 +987,9 @@ __global__ void __launch_bounds__(512) gru_kernel(GruArgs a) {
             const int b = b0 + c;
             float hn = 0.0f;
             if (b < a.B && jok) {
-                const float* xg = a.xg + ((size_t)b * a.T + t) * 3 * H;
-                const float rg = 1.0f / (1.0f + expf(-(xg[j] + ar[r] + bhr)));
-                const float zg = 1.0f / (1.0f + expf(-(xg[H + j] + az[r] + bhz)));
-                const float ng = tanhf(xg[2 * H + j] + rg * (an[r] + bhn));
+                const float rg = 1.0f / (1.0f + expf(-(xr[r] + ar[r] + bhr)));
+                const float zg = 1.0f / (1.0f + expf(-(xz[r] + az[r] + bhz)));
+                const float ng = tanhf(xn[r] + rg * (an[r] + bhn));
                 hn = (1.0f - zg) * ng + zg * hprev[r];
                 if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                 if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;

@@ -15,6 +15,7 @@
 #include "layers.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -1001,8 +1002,112 @@ __global__ void __launch_bounds__(512) gru_kernel(GruArgs a) {
     }
 }
 
+// Register-resident variant for H in {32, 64, 128} (H = 256 would need 384 weight registers at two waves per SIMD): one workgroup = 16 clips, wave w owns hidden units [32w, 32w+32)
+// as two 16-wide column blocks per gate on v_mfma_f32_16x16x4_f32.  Lane (n = l&15, g = l>>4) feeds k = g*H/4 + s at MFMA
+// step s, so its slice of every W_hh row it needs is H/4 CONTIGUOUS floats, loaded once and kept in 6*H/4 VGPRs for
+// all steps (one wave per SIMD: the 512-register budget is there) - the 32-clip kernel above re-streams W_hh (3*H*H
+// floats) from L2 on every step.  Half the clips per workgroup also means twice the workgroups (256 at B = 4096) and half
+// the MFMA chain per step.  C layout: column = hidden unit, rows 4g..4g+3 = clips, so xg loads / h stores stay coalesced
+// along the hidden dimension.
+template <int H>
+__global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
+    constexpr int KS = H / 4, LDH = H + 4;                    // MFMA steps per product, LDS row stride
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hs = reinterpret_cast<float*>(smem_raw);           // [16][H+4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    for (int idx = threadIdx.x; idx < 16 * LDH; idx += blockDim.x) hs[idx] = 0.0f;
+    // W_hh -> registers: gate q (r, z, n), column block bl, k slice g
+    float wreg[3][2][KS];
+    float bh[3][2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+            const int j = 32 * wave + 16 * bl + n;
+            const float4* src = reinterpret_cast<const float4*>(a.w_hh + (size_t)(q * H + j) * H + g * KS);
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4) {
+                const float4 v = src[s4];
+                wreg[q][bl][4 * s4] = v.x; wreg[q][bl][4 * s4 + 1] = v.y; wreg[q][bl][4 * s4 + 2] = v.z; wreg[q][bl][4 * s4 + 3] = v.w;
+            }
+            bh[q][bl] = a.b_hh[q * H + j];
+        }
+    float hprev[2][4];
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hprev[bl][r] = 0.0f;
+    const float* arow = hs + n * LDH + g * KS;                // A operand: clip n, k slice g
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl) acc[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // input-side pre-activations of this step (independent of h): in flight during the recurrent product
+        float xq[3][2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 3 * H + 32 * wave + n;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { xq[q][0][r] = xg[q * H]; xq[q][1][r] = xg[q * H + 16]; }
+        }
+        if (step > 0) {                                       // h == 0 on the first step
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + 4 * s4);
+                const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int bl = 0; bl < 2; ++bl)
+                            acc[q][bl] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wreg[q][bl][4 * s4 + e], acc[q][bl], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                      // every wave has finished reading hs
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+            const int j = 32 * wave + 16 * bl + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * g + r, b = b0 + c;
+                float hn = 0.0f;
+                if (b < a.B) {
+                    const float rg = 1.0f / (1.0f + expf(-(xq[0][bl][r] + acc[0][bl][r] + bh[0][bl])));
+                    const float zg = 1.0f / (1.0f + expf(-(xq[1][bl][r] + acc[1][bl][r] + bh[1][bl])));
+                    const float ng = tanhf(xq[2][bl][r] + rg * (acc[2][bl][r] + bh[2][bl]));
+                    hn = (1.0f - zg) * ng + zg * hprev[bl][r];
+                    if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                    if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+                }
+                hprev[bl][r] = hn;
+                hs[c * LDH + j] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
+    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
+        const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
+        const dim3 grid((a.B + 15) / 16);
+        switch (a.H) {
+            case 32: hipLaunchKernelGGL(gru16_kernel<32>, grid, dim3(64), lds16, s, a); break;
+            case 64: hipLaunchKernelGGL(gru16_kernel<64>, grid, dim3(128), lds16, s, a); break;
+            default: hipLaunchKernelGGL(gru16_kernel<128>, grid, dim3(256), lds16, s, a); break;
+        }
+        return hipGetLastError();
+    }
     const int waves = (a.H + 31) / 32;
     const size_t lds = (size_t)32 * (a.H + 4) * sizeof(float);
     if (lds > 64 * 1024)

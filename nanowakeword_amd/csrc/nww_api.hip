@@ -506,7 +506,21 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
             const float* whh = p.W(prefix + ".weight_hh" + sfx);
             const float* bih = p.W(prefix + ".bias_ih" + sfx);
             const float* bhh = p.W(prefix + ".bias_hh" + sfx);
-            add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, 3 * H, cur_I, wih, bih, ACT_NONE);
+            if (last && dir) {
+                // rnn_out[:, -1] needs ONE step of the reverse direction, hence the input projection of frame T-1 only:
+                // a strided GEMM over M = B rows instead of B*T
+                const int Iin = cur_I, in_buf = cur_in;
+                p.add("gemm:" + prefix + ".ih" + sfx + "(last frame)", [=](Run& r) {
+                    GemmArgs g;
+                    g.A = src(r, in_buf) + (size_t)(T - 1) * Iin; g.lda = T * Iin; g.W = wih;
+                    g.C = r.buf[xg_id] + (size_t)(T - 1) * 3 * H; g.ldc = T * 3 * H;
+                    g.M = r.B; g.N = 3 * H; g.K = Iin; g.bias = bih; g.alpha = nullptr; g.beta = nullptr; g.act = ACT_NONE;
+                    g.res = nullptr; g.ldres = 0; g.rscale = 1.f;
+                    return launch_gemm(g, r.stream);
+                });
+            } else {
+                add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, 3 * H, cur_I, wih, bih, ACT_NONE);
+            }
             const int in_T = T;
             p.add("gru:" + prefix + sfx, [=](Run& r) {
                 GruArgs a;

@@ -41,28 +41,15 @@ struct Conv3Args {
 };
 hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
 
-// depthwise 3x3, pad 1, stride (sh, sw), no bias: in [B][C][H][W] -> out [B][C][Ho][Wo]
-hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, int C, int H, int W, int sh, int sw,
-                            hipStream_t s);
 // depthwise 3x3, pad 1, stride (sh, sw) on channels-last data: in [B][H][W][C], wt [9][C] (tap-major weights)
 // -> d_out [B][Ho][Wo][C]; xs_out (may be null) receives in[b][oy*sh][ox*sw][c], the input of a strided 1x1 conv.
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
                                  int W, int sh, int sw, hipStream_t s);
-// pointwise 1x1 conv with input stride (sh, sw) on NCHW + (alpha,beta) + act + residual add:
-// out[b][co][y][x] = res + act( (sum_ci w[co][ci] in[b][ci][y*sh][x*sw]) * alpha[co] + beta[co] )
-struct PwArgs {
-    const float* in; const float* w; const float* alpha; const float* beta; const float* res; float* out;
-    int B, Cin, Cout, Hin, Win, sh, sw; int act;
-};
-hipError_t launch_pwconv(const PwArgs& a, hipStream_t s);
-
 // rows [R][D]: y = act(LayerNorm(x)*w + b), eps 1e-5, biased variance; in place allowed (y == x)
 hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
                             hipStream_t s);
 // mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)
 hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s);
-// mean over the last axis: in [R][L] -> out [R]
-hipError_t launch_mean_last(const float* in, float* out, int R, int L, hipStream_t s);
 // AvgPool2d(kernel (kh,kw), stride (sh,sw)) on [B*C][H][W] -> [B*C][oh][ow]  (export form of AdaptiveAvgPool2d)
 hipError_t launch_avgpool(const float* in, float* out, int BC, int H, int W, int kh, int kw, int sh, int sw, int oh,
                           int ow, hipStream_t s);

@@ -1,11 +1,11 @@
 // layers.hip - gfx950 kernels of the classifier heads (float32 end to end, MFMA f32 for dense contractions).
 //
-// Dense contractions (Linear layers, GRU gate GEMMs) run on v_mfma_f32_32x32x2_f32: exact float32
-// products/accumulation (an fmaf chain per output), 157 TF peak.  Operand fragments are fetched as
-// 16-byte loads along K straight from global/L2 (each lane owns one row): lane l = (i = l&31, h = l>>5)
-// holds A[m0+i][k0+4h .. +3]; MFMA step s of a group of four consumes element s, i.e. k = k0 + 4h + s -
-// the k <-> (step, half-wave) assignment is a bijection shared by both operands, which is all the
-// contraction needs.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Dense contractions (Linear layers, 1x1 convs, GRU input projections) run on v_mfma_f32_32x32x2_f32: exact float32
+// products/accumulation (an fmaf chain per output), 157 TF peak; tiles are staged through LDS with coalesced 16-byte
+// loads.  Lane l = (i = l&31, h = l>>5) feeds A[m0+i][k0+4h .. +3]; MFMA step s of a group of four consumes element s,
+// i.e. k = k0 + 4h + s - the k <-> (step, half-wave) assignment is a bijection shared by both operands, which is all
+// the contraction needs.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Long-K layers go to the
+// split-operand kernel in gemm_x3.hip (bf16 matrix cores, float32-grade results).
 //
 // Convolutions are register-blocked direct convs on the VALU: one lane = one output position x COB
 // output channels, weights wave-uniform (scalar loads), so the FMA:load ratio is 36:1 (pooled 3x3).
@@ -45,103 +45,10 @@ __device__ __forceinline__ float act_ct(float v) {
     }
 
 // ------------------------------------------------------------------------------------------ GEMM
-// block = 256 threads = 4 waves as 2(M) x 2(N), each wave one 32x32 tile -> 64x64 per block.
-__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 64 + (wave >> 1) * 32;
-    const int n0 = blockIdx.y * 64 + (wave & 1) * 32;
-    if (m0 >= g.M || n0 >= g.N) return;                    // wave-uniform
-    const int i = lane & 31, h = lane >> 5;
-    const int arow = min(m0 + i, g.M - 1), wrow = min(n0 + i, g.N - 1);
-    const float* ap = g.A + (size_t)arow * g.lda + 4 * h;
-    const float* wp = g.W + (size_t)wrow * g.K + 4 * h;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    int K = g.K;
-    int k = 0;
-    if (g.splitk > 1) {                                        // this block's K range (multiples of 32)
-        const int kc = (((g.K + g.splitk - 1) / g.splitk) + 31) & ~31;
-        k = blockIdx.z * kc;
-        K = min(g.K, k + kc);
-    }
-    // main loop, 32 k per iteration, operands of the NEXT iteration are in flight while this one's 16 MFMAs run
-    if (k + 32 <= K) {
-        float4 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const float4*>(ap + k + 8 * u);
-            b[u] = *reinterpret_cast<const float4*>(wp + k + 8 * u);
-        }
-        for (; k + 64 <= K; k += 32) {
-            float4 na[4], nb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                na[u] = *reinterpret_cast<const float4*>(ap + k + 32 + 8 * u);
-                nb[u] = *reinterpret_cast<const float4*>(wp + k + 32 + 8 * u);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = na[u]; b[u] = nb[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
-        }
-        k += 32;
-    }
-    for (; k < K; k += 8) {                                  // K % 4 == 0: the last group may be half
-        float4 a = make_float4(0, 0, 0, 0), b = a;
-        if (k + 4 * h + 4 <= K) {
-            a = *reinterpret_cast<const float4*>(ap + k);
-            b = *reinterpret_cast<const float4*>(wp + k);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-    }
-    const int n = n0 + i;
-    if (n >= g.N) return;
-    if (g.splitk > 1) {
-        float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < g.M) part[(size_t)m * g.N + n] = acc[r];
-        }
-        return;
-    }
-    const float bias = g.bias ? g.bias[n] : 0.0f;
-    const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < g.M) {
-            float v = acc[r] + bias;
-            if (g.alpha) v = v * al + be;
-            v = act_apply(v, g.act);
-            if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
-            g.C[(size_t)m * g.ldc + n] = v;
-        }
-    }
-}
-
-// LDS-staged variant (default): 64x64x32 tiles, coalesced 16-byte global loads (8 rows x 128 B per wave
-// instruction: 4x fewer cache-line requests than one row per lane, which is what bounded the direct kernel -
-// fc1 ran at 37% of peak with the texture-address unit saturated), register-staged double buffering with one
-// barrier per K-tile, operand fragments read back with conflict-free ds_read_b128 (row stride 36 floats).
-// Same k <-> (step, half-wave) map and the same per-output fmaf chain as gemm_mfma_kernel: results are
-// bit-identical between the two.
+// block = 256 threads = 4 waves as 2(M) x 2(N), each wave one 32x32 tile -> 64x64x32 tiles; coalesced 16-byte global
+// loads (8 rows x 128 B per wave instruction - a first version that fetched one row per lane straight from L2 was bound
+// by the texture-address unit: fc1 at 37% of peak), register-staged double buffering with one barrier per K-tile, operand
+// fragments read back with conflict-free ds_read_b128 (row stride 36 floats).
 #define GT_LD 36
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][64 * GT_LD];
@@ -293,9 +200,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         GemmArgs a = g;
         a.splitk = sk;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
-        static const int direct = [] { const char* e = getenv("NWW_GEMM_DIRECT"); return e ? atoi(e) : 0; }();
-        if (direct) hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(gemm_lds_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_lds_kernel, grid, dim3(256), 0, s, a);
         if (sk > 1) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
@@ -478,42 +383,6 @@ hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s) {
     return launch_conv3x3_cob<1>(a, s);
 }
 
-// ------------------------------------------------------------------------------------------ depthwise 3x3
-__global__ void __launch_bounds__(256)
-dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out, int C, int H,
-                 int W, int Ho, int Wo, int sh, int sw, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int ox = (int)(idx % Wo);
-    size_t t = idx / Wo;
-    const int oy = (int)(t % Ho);
-    t /= Ho;                                           // t = b*C + c
-    const int c = (int)(t % C);
-    const float* ip = in + t * (size_t)H * W;
-    const float* wc = w + (size_t)c * 9;
-    float acc = 0.0f;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int yy = oy * sh - 1 + dy;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int xx = ox * sw - 1 + dx;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float v = ok ? ip[yy * W + xx] : 0.0f;
-            acc = fmaf(v, wc[dy * 3 + dx], acc);
-        }
-    }
-    out[idx] = acc;
-}
-
-hipError_t launch_dwconv3x3(const float* in, const float* w, float* out, int B, int C, int H, int W, int sh, int sw,
-                            hipStream_t s) {
-    const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
-    const size_t total = (size_t)B * C * Ho * Wo;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, w, out, C, H, W,
-                       Ho, Wo, sh, sw, total);
-    return hipGetLastError();
-}
 
 __global__ void __launch_bounds__(256)
 dwconv3x3_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ d_out,
@@ -553,50 +422,6 @@ hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out,
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------ pointwise 1x1
-template <int COB>
-__global__ void __launch_bounds__(256) pwconv_kernel(PwArgs a) {
-    const int Ho = (a.Hin - 1) / a.sh + 1, Wo = (a.Win - 1) / a.sw + 1;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = p < Ho * Wo;
-    const int pc = valid ? p : 0;
-    const int oy = pc / Wo, ox = pc - oy * Wo;
-    const int co0 = blockIdx.y * COB, b = blockIdx.z;
-    const size_t plane = (size_t)a.Hin * a.Win;
-    const float* ip = a.in + (size_t)b * a.Cin * plane + (size_t)(oy * a.sh) * a.Win + ox * a.sw;
-    float acc[COB];
-#pragma unroll
-    for (int co = 0; co < COB; ++co) acc[co] = 0.0f;
-    for (int ci = 0; ci < a.Cin; ++ci) {
-        const float v = ip[(size_t)ci * plane];
-        const float* wc = a.w + (size_t)co0 * a.Cin + ci;              // wave-uniform
-#pragma unroll
-        for (int co = 0; co < COB; ++co) acc[co] = fmaf(v, wc[(size_t)co * a.Cin], acc[co]);
-    }
-    if (!valid) return;
-    const size_t o0 = ((size_t)b * a.Cout + co0) * Ho * Wo + p;
-#pragma unroll
-    for (int co = 0; co < COB; ++co) {
-        float v = acc[co];
-        if (a.alpha) v = v * a.alpha[co0 + co] + a.beta[co0 + co];
-        v = act_apply(v, a.act);
-        const size_t o = o0 + (size_t)co * Ho * Wo;
-        if (a.res) v += a.res[o];
-        a.out[o] = v;
-    }
-}
-
-hipError_t launch_pwconv(const PwArgs& a, hipStream_t s) {
-    const int Ho = (a.Hin - 1) / a.sh + 1, Wo = (a.Win - 1) / a.sw + 1;
-    if (a.Cout % 16 == 0) {
-        dim3 grid((Ho * Wo + 255) / 256, a.Cout / 16, a.B);
-        hipLaunchKernelGGL((pwconv_kernel<16>), grid, dim3(256), 0, s, a);
-    } else {
-        dim3 grid((Ho * Wo + 255) / 256, a.Cout, a.B);
-        hipLaunchKernelGGL((pwconv_kernel<1>), grid, dim3(256), 0, s, a);
-    }
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------------ LayerNorm rows
 __device__ __forceinline__ float wave_sum(float v) {
@@ -645,19 +470,6 @@ hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hip
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) mean_last_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int L) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= R) return;
-    const float* p = in + (size_t)row * L;
-    float s = 0.0f;
-    for (int i = lane; i < L; i += 64) s += p[i];
-    s = wave_sum(s);
-    if (lane == 0) out[row] = s / (float)L;
-}
-hipError_t launch_mean_last(const float* in, float* out, int R, int L, hipStream_t s) {
-    hipLaunchKernelGGL(mean_last_kernel, dim3((R + 3) / 4), dim3(256), 0, s, in, out, R, L);
-    return hipGetLastError();
-}
 
 __global__ void __launch_bounds__(256)
 avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int kh, int kw, int sh, int sw,

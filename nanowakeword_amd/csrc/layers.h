@@ -23,6 +23,10 @@ struct GemmArgs {
     // W pre-split into three bf16 terms ([N][ceil(K/16)][3][16], gemm_x3.hip); when set the contraction runs on the
     // bf16 matrix cores with exact operand splitting (float32-equivalent), else on v_mfma_f32_32x32x2_f32
     const void* Wx3 = nullptr;
+    // dual GEMM (BcResNet block): C = (A2 W2^T * alpha2 + beta2) + rscale * act((A W^T + bias) * alpha + beta), the second
+    // product (shortcut branch) computed by the same workgroup instead of a separate GEMM + a residual round trip
+    const float* A2 = nullptr; int lda2 = 0; const float* W2 = nullptr; int K2 = 0;
+    const float* alpha2 = nullptr; const float* beta2 = nullptr;
 };
 size_t gemm_x3_weight_bytes(int N, int K);
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);

@@ -56,64 +56,69 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm = blockIdx.x * 64, bn = blockIdx.y * 64;
     const int i = lane & 31, h = lane >> 5;
+    // loader mapping: thread -> (row r = tid/8 + 32*q, 16-byte column kq = tid%8)
+    const int lr = tid >> 3, lq = tid & 7;
+    const int arow_l = ((wave >> 1) * 32 + i) * GT_LD + 4 * h;
+    const int wrow_l = ((wave & 1) * 32 + i) * GT_LD + 4 * h;
+    // acc += A[bm.., k_begin..k_end) . W[bn.., k_begin..k_end)^T, K-tiles of 32 through the two LDS stages
+    auto contract = [&](const float* A, int lda, const float* W, int K, int k_begin, int k_end, f32x16& acc) {
+        const float* arow[2];
+        const float* wrow[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            arow[q] = A + (size_t)min(bm + lr + 32 * q, g.M - 1) * lda + 4 * lq;
+            wrow[q] = W + (size_t)min(bn + lr + 32 * q, g.N - 1) * K + 4 * lq;
+        }
+        auto gload = [&](int k0, float4 (&ra)[2], float4 (&rw)[2]) {
+            const bool ok = k0 + 4 * lq + 4 <= k_end;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
+                rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
+            }
+        };
+        auto lstore = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<float4*>(&As[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = ra[q];
+                *reinterpret_cast<float4*>(&Ws[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = rw[q];
+            }
+        };
+        float4 ra[2], rw[2];
+        int cur = 0;
+        if (k_begin < k_end) {
+            gload(k_begin, ra, rw);
+            lstore(0, ra, rw);
+        }
+        __syncthreads();
+        for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+            const bool more = k0 + 32 < k_end;
+            if (more) gload(k0 + 32, ra, rw);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(&As[cur][arow_l + 8 * u]);
+                const float4 b = *reinterpret_cast<const float4*>(&Ws[cur][wrow_l + 8 * u]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            if (more) lstore(cur ^ 1, ra, rw);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
     int k_begin = 0, k_end = g.K;
     if (g.splitk > 1) {
         const int kc = (((g.K + g.splitk - 1) / g.splitk) + 31) & ~31;
         k_begin = blockIdx.z * kc;
         k_end = min(g.K, k_begin + kc);
     }
-    // loader mapping: thread -> (row r = tid/8 + 32*q, 16-byte column kq = tid%8)
-    const int lr = tid >> 3, lq = tid & 7;
-    const float* arow[2];
-    const float* wrow[2];
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        arow[q] = g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
-        wrow[q] = g.W + (size_t)min(bn + lr + 32 * q, g.N - 1) * g.K + 4 * lq;
-    }
-    auto gload = [&](int k0, float4 (&ra)[2], float4 (&rw)[2]) {
-        const bool ok = k0 + 4 * lq + 4 <= k_end;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
-            rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
-        }
-    };
-    auto lstore = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<float4*>(&As[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = ra[q];
-            *reinterpret_cast<float4*>(&Ws[buf][(lr + 32 * q) * GT_LD + 4 * lq]) = rw[q];
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int arow_l = ((wave >> 1) * 32 + i) * GT_LD + 4 * h;
-    const int wrow_l = ((wave & 1) * 32 + i) * GT_LD + 4 * h;
-    float4 ra[2], rw[2];
-    int cur = 0;
-    if (k_begin < k_end) {
-        gload(k_begin, ra, rw);
-        lstore(0, ra, rw);
-    }
-    __syncthreads();
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        const bool more = k0 + 32 < k_end;
-        if (more) gload(k0 + 32, ra, rw);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[cur][arow_l + 8 * u]);
-            const float4 b = *reinterpret_cast<const float4*>(&Ws[cur][wrow_l + 8 * u]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-        }
-        if (more) lstore(cur ^ 1, ra, rw);
-        __syncthreads();
-        cur ^= 1;
-    }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+    contract(g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
+    if (g.A2) contract(g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);     // second product of a dual GEMM (never split)
     const int m0 = bm + (wave >> 1) * 32, n = bn + (wave & 1) * 32 + i;
     if (m0 >= g.M || n >= g.N) return;
     if (g.splitk > 1) {
@@ -127,6 +132,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     }
     const float bias = g.bias ? g.bias[n] : 0.0f;
     const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
+    const float al2 = (g.A2 && g.alpha2) ? g.alpha2[n] : 1.0f, be2 = (g.A2 && g.alpha2) ? g.beta2[n] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -135,6 +141,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
             if (g.alpha) v = v * al + be;
             v = act_apply(v, g.act);
             if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
+            if (g.A2) v = (acc2[r] * al2 + be2) + g.rscale * v;      // same association as res + rscale * v
             g.C[(size_t)m * g.ldc + n] = v;
         }
     }
@@ -186,7 +193,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
-    if (gemm_x3_usable(g)) {
+    if (g.A2 && !(aligned && g.K2 % 4 == 0 && g.lda2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(g.A2) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(g.W2) & 15) == 0) && g.splitk <= 1))
+        return hipErrorInvalidValue;                           // the dual form exists on the LDS kernel only
+    if (!g.A2 && gemm_x3_usable(g)) {
         hipError_t e = launch_gemm_x3(g, s);
         if (e != hipSuccess) return e;
         if (g.splitk > 1 && g.splitk_ws) {

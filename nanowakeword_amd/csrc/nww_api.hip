@@ -730,8 +730,22 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const float* dwt = p.W(q + ".depthwise.weight_t");
                 const int hin = hh, win = ww;
                 p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
-                add_gemm(p, q + ".shortcut(1x1)+bn", xsb, resb, ho * wo, co, ci, p.W(q + ".shortcut.0.weight"), nullptr, ACT_NONE, p.W(q + ".shortcut.1.alpha"), p.W(q + ".shortcut.1.beta"));
-                add_gemm(p, q + ".pointwise(1x1)+bn+act+res", dwb, outb, ho * wo, co, ci, p.W(q + ".pointwise.weight"), nullptr, act, p.W(q + ".bn1.alpha"), p.W(q + ".bn1.beta"), resb, 1.0f);
+                // one dual GEMM per block: shortcut and pointwise products in the same workgroup, no residual round trip
+                {
+                    const float *wpw = p.W(q + ".pointwise.weight"), *a1 = p.W(q + ".bn1.alpha"), *b1 = p.W(q + ".bn1.beta");
+                    const float *wsc = p.W(q + ".shortcut.0.weight"), *as = p.W(q + ".shortcut.1.alpha"), *bs = p.W(q + ".shortcut.1.beta");
+                    const int rows = ho * wo;
+                    p.need(outb, (size_t)rows * co);
+                    p.add("gemm2:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
+                        GemmArgs g;
+                        g.A = r.buf[dwb]; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;
+                        g.A2 = r.buf[xsb]; g.lda2 = ci; g.W2 = wsc; g.K2 = ci; g.alpha2 = as; g.beta2 = bs;
+                        g.C = r.buf[outb]; g.ldc = co; g.M = r.B * rows; g.N = co;
+                        g.res = nullptr; g.ldres = 0; g.rscale = 1.0f;
+                        return launch_gemm(g, r.stream);
+                    });
+                    (void)resb;
+                }
                 hh = ho; ww = wo; cur = outb;
             }
             const int hw = hh * ww;

@@ -717,7 +717,18 @@ extern "C" int nww_finalize(nww_handle* h) {
             // init conv (+BN+act+pool) writes [B][H1][W1][32]; each block: one depthwise kernel emits d = dw3x3(x) and
             // xs = x at the strided centres, then two MFMA GEMMs over M = B*Ho*Wo pixels:
             //   R = BN_s(xs . Wsc^T) ;  out = act(BN_1(d . Wpw^T)) + R      (activation BEFORE the residual add, :646-647)
-            add_conv(p, "init_conv(nhwc)", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1, 1);
+            static const int ic_mfma = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+            if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {
+                const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
+                p.need(0, (size_t)32 * (T / 2) * (F / 2));
+                const int max_grid = p.h->cu_count;
+                p.add("conv1_mfma:init_conv(nhwc)", [=](Run& r) {
+                    Conv1NhwcArgs a{src(r, -1), w0, nullptr, a0, b0, r.buf[0], r.B, T, F, act};
+                    return launch_conv1_pool_nhwc_mfma(a, max_grid, r.stream);
+                });
+            } else {
+                add_conv(p, "init_conv(nhwc)", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1, 1);
+            }
             int hh = T / 2, ww = F / 2, cur = 0;
             const int ch[4] = {32, 64, 128, 256};
             const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};

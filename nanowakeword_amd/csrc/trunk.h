@@ -53,3 +53,11 @@ struct ConvMfmaArgs {
 };
 size_t conv_mfma_lds_bytes(int C1, int H, int W);
 hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);
+
+// Conv2d(1, 32, 3, p1) + bias/BN + act + MaxPool2 on MFMA, channels-last output [B][H/2][W/2][32] (BcResNet init conv)
+struct Conv1NhwcArgs {
+    const float* in; const float* w; const float* bias; const float* alpha; const float* beta; float* out;
+    int B, H, W, act;
+};
+bool conv1_pool_nhwc_mfma_fits(int H, int W);
+hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s);

@@ -547,3 +547,142 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
 #undef TRUNK_LAUNCH
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// First conv of BcResNet (architectures.py:655-660): Conv2d(1, 32, 3, p1, bias=False) + BN + act + MaxPool2, written
+// channels-last [B][H/2][W/2][32] for the depthwise / 1x1 stages.  Same MFMA scheme as the trunk's conv1 - tile = 16
+// conv pixels (2 rows x 8 columns, a lane's 4 accumulator registers are one pooling window) x 16 channels on
+// v_mfma_f32_16x16x4_f32, K = 9 taps padded to 12 - with two channel blocks per tile; the pooled values go straight to
+// HBM (lanes = channels -> 64-byte runs).  One workgroup walks clips; the next clip's plane is prefetched into
+// registers while the current one is convolved.  (The VALU version of this stage took 0.95 ms per 8192 clips.)
+template <int ACT, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) conv1_pool_nhwc_mfma_kernel(Conv1NhwcArgs a) {
+    constexpr int NTHR = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, Wp0 = W + 2;
+    const int in_f = ((H + 2) * Wp0 + 3) & ~3;
+    float* In = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < in_f; k += NTHR) In[k] = 0.0f;
+    const int i1 = lane & 15, g1 = lane >> 4;
+    float wreg[2][3];
+    int tap_off[3];
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int tap = 4 * st + g1;
+        wreg[0][st] = tap < 9 ? a.w[(size_t)i1 * 9 + tap] : 0.0f;
+        wreg[1][st] = tap < 9 ? a.w[(size_t)(16 + i1) * 9 + tap] : 0.0f;
+        tap_off[st] = tap < 9 ? (tap / 3) * Wp0 + (tap % 3) : 0;
+    }
+    float bias[2], al[2], be[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        bias[cb] = a.bias ? a.bias[16 * cb + i1] : 0.0f;
+        al[cb] = a.alpha ? a.alpha[16 * cb + i1] : 1.0f;
+        be[cb] = a.alpha ? a.beta[16 * cb + i1] : 0.0f;
+    }
+    const bool bn = a.alpha != nullptr;
+    const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4, nG = H1 * ngx;
+    const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
+    const int dR = NW / ngx, dX = NW - dR * ngx;
+    const int R_first = wave / ngx, X_first = wave - R_first * ngx;
+    const bool vec_in = (W & 3) == 0 && H * W <= 16 * NTHR;
+    auto load_sync = [&](const float* xin) {
+        for (int idx = tid; idx < H * W; idx += NTHR) {
+            const int y = idx / W, x = idx - y * W;
+            In[(y + 1) * Wp0 + x + 1] = xin[idx];
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < a.B) load_sync(a.in + (size_t)blockIdx.x * H * W);
+    __syncthreads();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int bnext = b + gridDim.x;
+        float4 pre[4];
+        const bool fetch = bnext < a.B;
+        if (fetch && vec_in) {
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx4 = tid + q * NTHR;
+                if (idx4 < H * W / 4) pre[q] = xin4[idx4];
+            }
+        }
+        float* outb = a.out + (size_t)b * H1 * W1 * 32;
+        int R = R_first, X = X_first;
+        for (int g = wave; g < nG; g += NW) {
+            const int X0 = 4 * X;
+            const float* rowp = In + (2 * R) * Wp0 + 8 * X0 + pix_off;
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[cb][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const float* q = rowp + tap_off[st];
+                float av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = q[8 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wreg[0][st], acc[0][u], 0, 0, 0);
+                    acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wreg[1][st], acc[1][u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = 4 * (X0 + u) + g1;
+                if (X0 + u < nX1 && col < W1) {
+                    float* dst = outb + ((size_t)R * W1 + col) * 32 + i1;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v = acc[cb][u][q] + bias[cb];
+                            if (bn) v = v * al[cb] + be[cb];
+                            m = fmaxf(m, trunk_act<ACT>(v));
+                        }
+                        dst[16 * cb] = m;
+                    }
+                }
+            }
+            R += dR; X += dX;
+            if (X >= ngx) { X -= ngx; ++R; }
+        }
+        __syncthreads();                                       // everyone is done with this clip's plane
+        if (fetch) {
+            if (vec_in) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx4 = tid + q * NTHR;
+                    if (idx4 < H * W / 4) {
+                        const int idx = idx4 * 4, y = idx / W, x = idx - y * W;
+                        float* d = In + (y + 1) * Wp0 + x + 1;
+                        d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+                    }
+                }
+            } else {
+                load_sync(a.in + (size_t)bnext * H * W);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool conv1_pool_nhwc_mfma_fits(int H, int W) { return H >= 4 && W >= 4 && (size_t)(H + 2) * (W + 2) * 4 + 64 <= 64 * 1024; }
+
+hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s) {
+    if (!conv1_pool_nhwc_mfma_fits(a.H, a.W)) return hipErrorInvalidValue;
+    const size_t lds = ((((size_t)(a.H + 2) * (a.W + 2) + 3) & ~(size_t)3) + 16) * sizeof(float);
+    int grid = a.B < 2 * max_grid ? a.B : 2 * max_grid;        // 27 KB of LDS, 8 waves: two workgroups per CU
+    if (grid < 1) grid = 1;
+    switch (a.act) {
+        case ACT_RELU: hipLaunchKernelGGL((conv1_pool_nhwc_mfma_kernel<ACT_RELU, 8>), dim3(grid), dim3(512), lds, s, a); break;
+        case ACT_GELU: hipLaunchKernelGGL((conv1_pool_nhwc_mfma_kernel<ACT_GELU, 8>), dim3(grid), dim3(512), lds, s, a); break;
+        case ACT_SILU: hipLaunchKernelGGL((conv1_pool_nhwc_mfma_kernel<ACT_SILU, 8>), dim3(grid), dim3(512), lds, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

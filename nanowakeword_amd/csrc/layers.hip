@@ -50,6 +50,9 @@ __device__ __forceinline__ float act_ct(float v) {
 // by the texture-address unit: fc1 at 37% of peak), register-staged double buffering with one barrier per K-tile, operand
 // fragments read back with conflict-free ds_read_b128 (row stride 36 floats).
 #define GT_LD 36
+// ACT is a template parameter: the run-time switch costs several scalar branches per output element, and for short-K
+// layers (Conformer: 4.5 K-tiles) the epilogue is a third of a workgroup's time.
+template <int ACT>
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][64 * GT_LD];
     __shared__ __attribute__((aligned(16))) float Ws[2][64 * GT_LD];
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
         if (m < g.M) {
             float v = acc[r] + bias;
             if (g.alpha) v = v * al + be;
-            v = act_apply(v, g.act);
+            v = act_ct<ACT>(v);
             if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
             if (g.A2) v = (acc2[r] * al2 + be2) + g.rscale * v;      // same association as res + rscale * v
             g.C[(size_t)m * g.ldc + n] = v;
@@ -210,7 +213,13 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         GemmArgs a = g;
         a.splitk = sk;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
-        hipLaunchKernelGGL(gemm_lds_kernel, grid, dim3(256), 0, s, a);
+        switch (a.act) {
+            case ACT_RELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_RELU>, grid, dim3(256), 0, s, a); break;
+            case ACT_GELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_GELU>, grid, dim3(256), 0, s, a); break;
+            case ACT_SILU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SILU>, grid, dim3(256), 0, s, a); break;
+            case ACT_SIGMOID: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SIGMOID>, grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(gemm_lds_kernel<ACT_NONE>, grid, dim3(256), 0, s, a); break;
+        }
         if (sk > 1) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);

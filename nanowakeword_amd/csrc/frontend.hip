@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include "fe_steps.h"
 #include "frontend.h"
+#include "layers.h"
 
 #define FE_TB_BYTES ((int)((sizeof(FeTables) + 15) & ~15))
 
@@ -186,12 +187,9 @@ hipError_t fe_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int 
     while (fc > 1 && (p.hop * (fc - 1) + FE_NFFT + 7) / 8 > FE_MAXG * block) { --fc; nchunks = (T + fc - 1) / fc; }
     if ((p.hop * (fc - 1) + FE_NFFT + 7) / 8 > FE_MAXG * block) return hipErrorInvalidValue;
     const int lds = fe_lds_bytes(fc, p.hop);
-    static int attr_set_for = 0;
-    if (lds > attr_set_for) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_stft_mel_db_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(fe_stft_mel_db_kernel), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set_for = lds;
     }
     static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
     long long total = (long long)B * nchunks;

@@ -241,15 +241,10 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     a.splitk = sk;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
     const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;
-    static size_t attr_for[7] = {0};
 #define X3_LAUNCH(CBV)                                                                                             \
     case CBV: {                                                                                                    \
-        if (lds > 64 * 1024 && lds > attr_for[CBV]) {                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<CBV>),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-            if (e != hipSuccess) return e;                                                                         \
-            attr_for[CBV] = lds;                                                                                   \
-        }                                                                                                          \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV>), lds);                     \
+        if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((gemm_x3_kernel<CBV>), grid, dim3(256), lds, s, a);                                     \
         break;                                                                                                     \
     }

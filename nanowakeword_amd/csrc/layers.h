@@ -3,6 +3,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Raise a kernel's dynamic-LDS limit once per (device, kernel).  The attribute is per device: a process that creates
+// handles on several GPUs must set it on each of them, so the cache is keyed by the current device as well.
+#include <map>
+#include <mutex>
+#include <utility>
+inline hipError_t nww_allow_lds(const void* func, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& cur = done[std::make_pair(dev, func)];
+    if (bytes > cur) {
+        e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        cur = bytes;
+    }
+    return hipSuccess;
+}
+
 enum NwwAct { ACT_RELU = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_NONE = 3, ACT_SIGMOID = 4, ACT_SWISH = 2 };
 
 // C[M,N] = post( A[M,K] * W[N,K]^T ) with

@@ -715,9 +715,8 @@ hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, in
     dim3 grid(n_head, B);
 #define MHA_CASE(DHV)                                                                                              \
     case DHV: {                                                                                                    \
-        if (lds > 64 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_kernel<DHV>),                             \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipError_t ea = nww_allow_lds(reinterpret_cast<const void*>(mha_core_kernel<DHV>), lds);                   \
+        if (ea != hipSuccess) return ea;                                                                           \
         hipLaunchKernelGGL((mha_core_kernel<DHV>), grid, dim3(128), lds, s, qkv, out, T, D, scale);                \
         break;                                                                                                     \
     }
@@ -941,8 +940,10 @@ hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     }
     const int waves = (a.H + 31) / 32;
     const size_t lds = (size_t)32 * (a.H + 4) * sizeof(float);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t ea = nww_allow_lds(reinterpret_cast<const void*>(gru_kernel), lds);
+        if (ea != hipSuccess) return ea;
+    }
     hipLaunchKernelGGL(gru_kernel, dim3((a.B + 31) / 32), dim3(waves * 64), lds, s, a);
     return hipGetLastError();
 }

@@ -458,34 +458,25 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int grid = a.B < max_grid ? a.B : max_grid;
     if (grid < 1) grid = 1;
-    static size_t attr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (a.avg_ow > 0 && (a.pool || a.avg_ow > 4 || (size_t)8 * 64 * 4 * sizeof(float) > lds)) return hipErrorInvalidValue;
-#define CM_LAUNCH(ACTV, POOLV, SLOT)                                                                                   \
+#define CM_LAUNCH(ACTV, POOLV)                                                                                         \
     {                                                                                                                  \
-        if (lds > attr[SLOT]) {                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-            if (e != hipSuccess) return e;                                                                             \
-            attr[SLOT] = lds;                                                                                          \
-        }                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), lds);      \
+        if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, ACTV, POOLV, 8>), dim3(grid), dim3(512), lds, s, a);               \
     }
-#define CM_LAUNCH_AVG(ACTV, SLOT)                                                                                      \
+#define CM_LAUNCH_AVG(ACTV)                                                                                            \
     {                                                                                                                  \
-        if (lds > attr[SLOT]) {                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, false, 8, true>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-            if (e != hipSuccess) return e;                                                                             \
-            attr[SLOT] = lds;                                                                                          \
-        }                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32, ACTV, false, 8, true>), lds); \
+        if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, ACTV, false, 8, true>), dim3(grid), dim3(512), lds, s, a);         \
     }
-#define CM_ACT(ACTV, BASE)                                   \
-    if (a.avg_ow > 0) CM_LAUNCH_AVG(ACTV, BASE + 6) else if (a.pool) CM_LAUNCH(ACTV, true, BASE) else CM_LAUNCH(ACTV, false, BASE + 3)
+#define CM_ACT(ACTV)                                         \
+    if (a.avg_ow > 0) CM_LAUNCH_AVG(ACTV) else if (a.pool) CM_LAUNCH(ACTV, true) else CM_LAUNCH(ACTV, false)
     switch (a.act) {
-        case ACT_RELU: CM_ACT(ACT_RELU, 0) break;
-        case ACT_GELU: CM_ACT(ACT_GELU, 1) break;
-        case ACT_SILU: CM_ACT(ACT_SILU, 2) break;
+        case ACT_RELU: CM_ACT(ACT_RELU) break;
+        case ACT_GELU: CM_ACT(ACT_GELU) break;
+        case ACT_SILU: CM_ACT(ACT_SILU) break;
         default: return hipErrorInvalidValue;
     }
 #undef CM_ACT
@@ -520,26 +511,20 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
     int grid = (int)(want < cap ? want : cap);
     grid -= grid % S;
     if (grid < S) grid = S;
-    static size_t attr_for[12] = {0};
-#define TRUNK_LAUNCH2(ACTV, NWV, STRIPV, SLOT)                                                                     \
+#define TRUNK_LAUNCH2(ACTV, NWV, STRIPV)                                                                           \
     {                                                                                                              \
-        if (lds > attr_for[SLOT]) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(                                                                    \
-                reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV, NWV, STRIPV>),                        \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
-            if (e != hipSuccess) return e;                                                                         \
-            attr_for[SLOT] = lds;                                                                                  \
-        }                                                                                                          \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_kernel<16, 32, ACTV, NWV, STRIPV>), lds);  \
+        if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((cnn_trunk_kernel<16, 32, ACTV, NWV, STRIPV>), dim3(grid), dim3(64 * NWV), lds, s, aa); \
     }
-#define TRUNK_LAUNCH1(ACTV, NWV, SLOT)                                                                             \
-    if (S == 1) TRUNK_LAUNCH2(ACTV, NWV, false, SLOT) else TRUNK_LAUNCH2(ACTV, NWV, true, SLOT + 6)
-#define TRUNK_LAUNCH(ACTV, SLOT)                                                                                   \
-    if (nw == 4) TRUNK_LAUNCH1(ACTV, 4, SLOT) else TRUNK_LAUNCH1(ACTV, 8, SLOT + 3)
+#define TRUNK_LAUNCH1(ACTV, NWV)                                                                                   \
+    if (S == 1) TRUNK_LAUNCH2(ACTV, NWV, false) else TRUNK_LAUNCH2(ACTV, NWV, true)
+#define TRUNK_LAUNCH(ACTV)                                                                                         \
+    if (nw == 4) TRUNK_LAUNCH1(ACTV, 4) else TRUNK_LAUNCH1(ACTV, 8)
     switch (a.act) {
-        case ACT_RELU: TRUNK_LAUNCH(ACT_RELU, 0) break;
-        case ACT_GELU: TRUNK_LAUNCH(ACT_GELU, 1) break;
-        case ACT_SILU: TRUNK_LAUNCH(ACT_SILU, 2) break;
+        case ACT_RELU: TRUNK_LAUNCH(ACT_RELU) break;
+        case ACT_GELU: TRUNK_LAUNCH(ACT_GELU) break;
+        case ACT_SILU: TRUNK_LAUNCH(ACT_SILU) break;
         default: return hipErrorInvalidValue;
     }
 #undef TRUNK_LAUNCH2

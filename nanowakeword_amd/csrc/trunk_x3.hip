@@ -369,28 +369,22 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     grid -= grid % S;
     if (grid < S) grid = S;
     const bool bn = a.al1 != nullptr || a.al2 != nullptr;
-    static size_t attr_for[24] = {0};
-#define X3T_LAUNCH(ACTV, PRODV, BNV, NWV, SLOT)                                                                    \
+#define X3T_LAUNCH(ACTV, PRODV, BNV, NWV)                                                                          \
     {                                                                                                              \
-        if (lds > attr_for[SLOT]) {                                                                                \
-            hipError_t e = hipFuncSetAttribute(                                                                    \
-                reinterpret_cast<const void*>(cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>),                         \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
-            if (e != hipSuccess) return e;                                                                         \
-            attr_for[SLOT] = lds;                                                                                  \
-        }                                                                                                          \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>), lds);   \
+        if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);  \
     }
-#define X3T_NW(ACTV, PRODV, BNV, SLOT)                                                                             \
-    if (nw == 4) X3T_LAUNCH(ACTV, PRODV, BNV, 4, SLOT) else X3T_LAUNCH(ACTV, PRODV, BNV, 8, SLOT + 12)
-#define X3T_BN(ACTV, PRODV, SLOT)                                                                                  \
-    if (bn) X3T_NW(ACTV, PRODV, true, SLOT) else X3T_NW(ACTV, PRODV, false, SLOT + 6)
-#define X3T_ACT(ACTV, SLOT)                                                                                        \
-    if (products == 6) X3T_BN(ACTV, 6, SLOT) else X3T_BN(ACTV, 9, SLOT + 3)
+#define X3T_NW(ACTV, PRODV, BNV)                                                                                   \
+    if (nw == 4) X3T_LAUNCH(ACTV, PRODV, BNV, 4) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
+#define X3T_BN(ACTV, PRODV)                                                                                        \
+    if (bn) X3T_NW(ACTV, PRODV, true) else X3T_NW(ACTV, PRODV, false)
+#define X3T_ACT(ACTV)                                                                                              \
+    if (products == 6) X3T_BN(ACTV, 6) else X3T_BN(ACTV, 9)
     switch (a.act) {
-        case ACT_RELU: X3T_ACT(ACT_RELU, 0) break;
-        case ACT_GELU: X3T_ACT(ACT_GELU, 1) break;
-        case ACT_SILU: X3T_ACT(ACT_SILU, 2) break;
+        case ACT_RELU: X3T_ACT(ACT_RELU) break;
+        case ACT_GELU: X3T_ACT(ACT_GELU) break;
+        case ACT_SILU: X3T_ACT(ACT_SILU) break;
         default: return hipErrorInvalidValue;
     }
 #undef X3T_LAUNCH

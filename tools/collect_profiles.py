@@ -46,10 +46,11 @@ with open(os.path.join(out, f"{rnd}_pmc_summary.csv"), "w", newline="") as f:
 traffic = {"_note": "HBM bytes per launch at batch 4096 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, median "
                     "of the full-size launches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                     "coalesced reads); WRITE_SIZE taken 1:1."}
-plan = {"cnn_trunk_x3_kernel<0, 6, false>": "trunk_x3:conv1+pool+conv2+pool", "cnn_trunk_kernel<16, 32, 0, 8, false>": "trunk:conv1+pool+conv2+pool",
+plan = {"cnn_trunk_x3_kernel": "trunk_x3:conv1+pool+conv2+pool", "cnn_trunk_kernel": "trunk:conv1+pool+conv2+pool",
         "fe_stft_mel_db_kernel": "frontend:fe_stft_mel_db_kernel"}
-for k, label in plan.items():
-    if k in fetch and k in write:
+for prefix, label in plan.items():
+    k = next((n for n in fetch if n.startswith(prefix + "<") or n == prefix), None)
+    if k is not None and k in write:
         fk, wk = big_median(fetch[k]["FETCH_SIZE"]), big_median(write[k]["WRITE_SIZE"])
         traffic[label] = {"batch": 4096, "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024), "fetch_size_kb": fk, "write_size_kb": wk}
         s = sq.get(k, {})

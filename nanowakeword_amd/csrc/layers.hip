@@ -64,20 +64,55 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     const int arow_l = ((wave >> 1) * 32 + i) * GT_LD + 4 * h;
     const int wrow_l = ((wave & 1) * 32 + i) * GT_LD + 4 * h;
     // acc += A[bm.., k_begin..k_end) . W[bn.., k_begin..k_end)^T, K-tiles of 32 through the two LDS stages
-    auto contract = [&](const float* A, int lda, const float* W, int K, int k_begin, int k_end, f32x16& acc) {
+    // mode 0: A rows from memory; 1: A = depthwise 3x3 of the channels-last input g.dw_x, computed here (same tap order
+    // and fmaf chain as dwconv3x3_nhwc_kernel); 2: A = g.dw_x at the strided centre of the output pixel
+    auto contract = [&](int mode, const float* A, int lda, const float* W, int K, int k_begin, int k_end, f32x16& acc) {
         const float* arow[2];
         const float* wrow[2];
+        int iy0[2] = {0, 0}, ix0[2] = {0, 0};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            arow[q] = A + (size_t)min(bm + lr + 32 * q, g.M - 1) * lda + 4 * lq;
+            const int m = min(bm + lr + 32 * q, g.M - 1);
+            if (mode == 0) {
+                arow[q] = A + (size_t)m * lda + 4 * lq;
+            } else {
+                const int per = g.dw_Ho * g.dw_Wo;
+                const int b = m / per, r = m - b * per, oy = r / g.dw_Wo, ox = r - oy * g.dw_Wo;
+                iy0[q] = oy * g.dw_sh; ix0[q] = ox * g.dw_sw;
+                arow[q] = g.dw_x + (size_t)b * g.dw_H * g.dw_W * K + 4 * lq;            // image base (+ channel offset)
+            }
             wrow[q] = W + (size_t)min(bn + lr + 32 * q, g.N - 1) * K + 4 * lq;
         }
         auto gload = [&](int k0, float4 (&ra)[2], float4 (&rw)[2]) {
             const bool ok = k0 + 4 * lq + 4 <= k_end;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
                 rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
+                if (mode == 0) {
+                    ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
+                } else if (mode == 2) {
+                    ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + ((size_t)iy0[q] * g.dw_W + ix0[q]) * K + k0)
+                               : make_float4(0, 0, 0, 0);
+                } else {
+                    float4 d = make_float4(0, 0, 0, 0);
+                    if (ok) {
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int yy = iy0[q] - 1 + dy;
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int xx = ix0[q] - 1 + dx;
+                                if (yy >= 0 && yy < g.dw_H && xx >= 0 && xx < g.dw_W) {
+                                    const float4 v = *reinterpret_cast<const float4*>(arow[q] + ((size_t)yy * g.dw_W + xx) * K + k0);
+                                    const float4 w4 = *reinterpret_cast<const float4*>(g.dw_wt + (size_t)(dy * 3 + dx) * K + k0 + 4 * lq);
+                                    d.x = fmaf(v.x, w4.x, d.x); d.y = fmaf(v.y, w4.y, d.y);
+                                    d.z = fmaf(v.z, w4.z, d.z); d.w = fmaf(v.w, w4.w, d.w);
+                                }
+                            }
+                        }
+                    }
+                    ra[q] = d;
+                }
             }
         };
         auto lstore = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
@@ -120,8 +155,14 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
-    contract(g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
-    if (g.A2) contract(g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);     // second product of a dual GEMM (never split)
+    const bool dual = g.A2 != nullptr || g.dw_x != nullptr;
+    if (g.dw_x) {                                                     // whole BcResNet block: depthwise feeds the pointwise
+        contract(1, nullptr, 0, g.W, g.K, 0, g.K, acc);
+        contract(2, nullptr, 0, g.W2, g.K2, 0, g.K2, acc2);
+    } else {
+        contract(0, g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
+        if (g.A2) contract(0, g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);  // second product of a dual GEMM (never split)
+    }
     const int m0 = bm + (wave >> 1) * 32, n = bn + (wave & 1) * 32 + i;
     if (m0 >= g.M || n >= g.N) return;
     if (g.splitk > 1) {
@@ -135,7 +176,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     }
     const float bias = g.bias ? g.bias[n] : 0.0f;
     const float al = g.alpha ? g.alpha[n] : 1.0f, be = g.alpha ? g.beta[n] : 0.0f;
-    const float al2 = (g.A2 && g.alpha2) ? g.alpha2[n] : 1.0f, be2 = (g.A2 && g.alpha2) ? g.beta2[n] : 0.0f;
+    const float al2 = (dual && g.alpha2) ? g.alpha2[n] : 1.0f, be2 = (dual && g.alpha2) ? g.beta2[n] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -144,7 +185,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
             if (g.alpha) v = v * al + be;
             v = act_ct<ACT>(v);
             if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
-            if (g.A2) v = (acc2[r] * al2 + be2) + g.rscale * v;      // same association as res + rscale * v
+            if (dual) v = (acc2[r] * al2 + be2) + g.rscale * v;      // same association as res + rscale * v
             g.C[(size_t)m * g.ldc + n] = v;
         }
     }
@@ -199,6 +240,22 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.A2 && !(aligned && g.K2 % 4 == 0 && g.lda2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(g.A2) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(g.W2) & 15) == 0) && g.splitk <= 1))
         return hipErrorInvalidValue;                           // the dual form exists on the LDS kernel only
+    if (g.dw_x) {                                              // depthwise-fused block
+        if (g.K % 32 != 0 || g.K2 != g.K || !g.W2 || g.splitk > 1 || ((reinterpret_cast<uintptr_t>(g.dw_x) & 15) != 0) ||
+            ((reinterpret_cast<uintptr_t>(g.dw_wt) & 15) != 0) || ((reinterpret_cast<uintptr_t>(g.W) & 15) != 0) ||
+            ((reinterpret_cast<uintptr_t>(g.W2) & 15) != 0))
+            return hipErrorInvalidValue;
+        GemmArgs a = g;
+        a.splitk = 1;
+        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, 1);
+        switch (a.act) {
+            case ACT_RELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_RELU>, grid, dim3(256), 0, s, a); break;
+            case ACT_GELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_GELU>, grid, dim3(256), 0, s, a); break;
+            case ACT_SILU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SILU>, grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(gemm_lds_kernel<ACT_NONE>, grid, dim3(256), 0, s, a); break;
+        }
+        return hipGetLastError();
+    }
     if (!g.A2 && gemm_x3_usable(g)) {
         hipError_t e = launch_gemm_x3(g, s);
         if (e != hipSuccess) return e;

@@ -269,3 +269,32 @@ def test_cnn_trunk_odd_shapes(hip, shape, arith):
     assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max()), (shape, arith)
     assert np.abs(logits - oracle.model_forward(feats, sd, cfg).ravel()).max() <= FEAT_LOGIT_ATOL
     m.close()
+
+
+def test_split_operand_gemm_on_every_shape_subprocess():
+    """NWW_GEMM_X3=2 routes EVERY Linear / 1x1 conv with N, K >= 32 through the split-operand GEMM (normally only
+    long-K layers use it).  The knob is read once per process, hence the subprocess.  Heads with many different
+    (M, N, K): DNN (K = 6464), Conformer (K = 144 / 576, N = 144 .. 576), GRU (K = 64, N = 384), BcResNet (1x1 convs)."""
+    import os, subprocess, sys
+    script = r'''
+import numpy as np, oracle
+from nanowakeword_amd.config import FrontendConfig, HeadConfig
+from nanowakeword_amd.session import HipModel
+from nanowakeword_amd.synth import synth_features, synth_state_dict
+worst = 0.0
+for cfg in (HeadConfig("dnn", (101, 64)), HeadConfig("conformer", (40, 32), embedding_dim=16, conformer_d_model=96, conformer_n_head=4),
+            HeadConfig("gru", (30, 64), layer_dim=64), HeadConfig("bcresnet", (32, 40), embedding_dim=16)):
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    for B in (3, 70):
+        x = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(x)
+        worst = max(worst, float(np.abs(lg - oracle.model_forward(x, sd, cfg).ravel()).max()))
+    m.close()
+print("WORST", worst)
+assert worst <= 1e-4, worst
+'''
+    env = dict(os.environ, NWW_GEMM_X3="2", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "WORST" in r.stdout

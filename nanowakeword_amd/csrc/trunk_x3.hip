@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
             const float m = pool_quad<ACT, BN>(acc[u][0], acc[u][1], acc[u][2], acc[u][3], bias1, al1, be1);
             uint32_t vh, vm, vl;
             split3(m, vh, vm, vl);
-            if (FULL || (X0 + u < nX1 && 4 * (X0 + u) + g1 < W1)) {
+            if (!(a.dbg & 4) && (FULL || (X0 + u < nX1 && 4 * (X0 + u) + g1 < W1))) {
                 unsigned char* wp = wr + 4 * u * PS;
                 *reinterpret_cast<uint16_t*>(wp) = (uint16_t)(vh >> 16);
                 *reinterpret_cast<uint16_t*>(wp + 32) = (uint16_t)(vm >> 16);

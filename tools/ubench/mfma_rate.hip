@@ -114,6 +114,47 @@ __global__ void __launch_bounds__(512) k_mix6(float* out, int iters, uint32_t se
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// 6 products per tap with the three WEIGHT fragments also read from LDS (9 reads per 12 MFMAs), NWAVES waves per workgroup
+template <int NWAVES>
+__global__ void __launch_bounds__(64 * NWAVES) k_mix6w(float* out, int iters, uint32_t seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    for (int k = threadIdx.x; k < 130 * 1024 / 4; k += 64 * NWAVES) reinterpret_cast<uint32_t*>(lds)[k] = seed + k;
+    __syncthreads();
+    constexpr int PS = 96, WP = 34;
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int x = 2 * (i >> 2) + (i & 1), dy = (i >> 1) & 1;
+    const unsigned char* base = lds + ((dy + 2 * (wave & 3)) * WP + x) * PS + 16 * h;
+    const unsigned char* wbase = lds + 100 * 1024 + lane * 16;
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        const unsigned char* p = base + (it % 3) * PS + ((it / 3) % 3) * WP * PS;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(p), a1 = *reinterpret_cast<const bf16x8*>(p + 32),
+                     a2 = *reinterpret_cast<const bf16x8*>(p + 64);
+        const unsigned char* q = p + 16 * PS;
+        const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(q), c1 = *reinterpret_cast<const bf16x8*>(q + 32),
+                     c2 = *reinterpret_cast<const bf16x8*>(q + 64);
+        const unsigned char* w = wbase + (it % 9) * 3 * 1024;
+        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(w), B1 = *reinterpret_cast<const bf16x8*>(w + 1024),
+                     B2 = *reinterpret_cast<const bf16x8*>(w + 2048);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, B1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, B0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, B0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, B0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, B0, acc1, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    out[blockIdx.x * 64 * NWAVES + threadIdx.x] = s;
+}
+
 template <typename F>
 static float time_ms(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -142,5 +183,13 @@ int main() {
                2.0 * 32 * 32 * 16 * 12 * (iters / 4) * 8.0 * 256 / ms / 1e9);                                       \
     }
     MIX6(96, 34) MIX6(112, 34) MIX6(112, 40) MIX6(96, 36) MIX6(128, 34)
+#define MIX6W(NWV)                                                                                                  \
+    {                                                                                                               \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_mix6w<NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 135 * 1024); \
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mix6w<NWV>), dim3(256), dim3(64 * NWV), 135 * 1024, 0, out, iters / 4, 7u); });   \
+        printf("mix6 + weights from LDS, %d waves per CU: %.3f ms  %.1f TFLOP/s (bf16 flops)\n", NWV, ms,              \
+               2.0 * 32 * 32 * 16 * 12 * (iters / 4) * (double)NWV * 256 / ms / 1e9);                                \
+    }
+    MIX6W(8) MIX6W(12) MIX6W(16)
     return 0;
 }

@@ -108,3 +108,16 @@ struct GruArgs {
     int B, T, H, reverse, steps;
 };
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
+
+// Tail of every head in ONE launch: emb = x We^T + be  (the head's last Linear, written to `emb`),
+// hid = act(emb W0^T + b0), logit = hid . w3 + b3, prob = sigmoid(logit) when `probs` is set
+// (Model.classifier, model.py:291-296; InferenceWrapper sigmoid, _export/onnx.py:164-172).  x [B][Kin], Kin <= 512, E <= 256.
+struct TailArgs {
+    const float* x; int Kin;
+    const float *We, *be; int E;
+    const float *W0, *b0, *w3, *b3;
+    float *emb, *logits, *probs;
+    int B, act;
+};
+bool tail_supported(int Kin, int E);
+hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s);

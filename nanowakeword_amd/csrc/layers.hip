@@ -1004,3 +1004,99 @@ hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gru_kernel, dim3((a.B + 31) / 32), dim3(waves * 64), lds, s, a);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------ classifier tail
+// 16 clips per workgroup pass; x, emb and hid tiles in LDS, weights through L1 (lanes of a 16-lane group share a weight
+// row -> broadcast loads).  ~10 k MACs per clip: this replaces three tiny GEMM launches and the sigmoid launch, whose
+// cost was their launch-to-launch latency, not their arithmetic.  Every output is one fmaf chain in ascending k.
+// up to four outputs of one clip at once: four independent fmaf chains (ascending k) sharing the x fragment, operands
+// fetched 16 bytes at a time so that loads of the next k block are in flight while this one is multiplied
+__device__ __forceinline__ void tail_dot4(const float* __restrict__ xr, const float* __restrict__ w0, const float* __restrict__ w1,
+                                          const float* __restrict__ w2, const float* __restrict__ w3, int K, bool vec, float (&acc)[4]) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+    int k = 0;
+    if (vec) {
+#pragma unroll 2
+        for (; k + 4 <= K; k += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(xr + k);
+            const float4 a = *reinterpret_cast<const float4*>(w0 + k), b = *reinterpret_cast<const float4*>(w1 + k);
+            const float4 c = *reinterpret_cast<const float4*>(w2 + k), d = *reinterpret_cast<const float4*>(w3 + k);
+            acc[0] = fmaf(x.x, a.x, acc[0]); acc[1] = fmaf(x.x, b.x, acc[1]); acc[2] = fmaf(x.x, c.x, acc[2]); acc[3] = fmaf(x.x, d.x, acc[3]);
+            acc[0] = fmaf(x.y, a.y, acc[0]); acc[1] = fmaf(x.y, b.y, acc[1]); acc[2] = fmaf(x.y, c.y, acc[2]); acc[3] = fmaf(x.y, d.y, acc[3]);
+            acc[0] = fmaf(x.z, a.z, acc[0]); acc[1] = fmaf(x.z, b.z, acc[1]); acc[2] = fmaf(x.z, c.z, acc[2]); acc[3] = fmaf(x.z, d.z, acc[3]);
+            acc[0] = fmaf(x.w, a.w, acc[0]); acc[1] = fmaf(x.w, b.w, acc[1]); acc[2] = fmaf(x.w, c.w, acc[2]); acc[3] = fmaf(x.w, d.w, acc[3]);
+        }
+    }
+    for (; k < K; ++k) {
+        const float x = xr[k];
+        acc[0] = fmaf(x, w0[k], acc[0]); acc[1] = fmaf(x, w1[k], acc[1]); acc[2] = fmaf(x, w2[k], acc[2]); acc[3] = fmaf(x, w3[k], acc[3]);
+    }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    const int Kin = a.Kin, E = a.E, Hd = E / 2;
+    const int ldx = ((Kin + 3) & ~3) + 4, lde = ((E + 3) & ~3) + 4, ldh = Hd + 1;      // 16-byte aligned rows, +4: conflict-free
+    float* xs = tsm;                      // [16][ldx]
+    float* es = xs + 16 * ldx;            // [16][lde]
+    float* hs = es + 16 * lde;            // [16][ldh]
+    const int tid = threadIdx.x, c = tid & 15, g = tid >> 4;                          // clip slot, output group (16 groups)
+    const bool vx = (Kin & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.We) & 15) == 0);
+    const bool ve = (E & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.W0) & 15) == 0);
+    for (int b0 = blockIdx.x * 16; b0 < a.B; b0 += gridDim.x * 16) {
+        for (int idx = tid; idx < 16 * Kin; idx += 256) {
+            const int cc = idx / Kin, k = idx - cc * Kin;
+            xs[cc * ldx + k] = (b0 + cc < a.B) ? a.x[(size_t)(b0 + cc) * Kin + k] : 0.0f;
+        }
+        __syncthreads();
+        // embedding: outputs e = g, g+16, ...; four at a time
+        for (int e0 = g; e0 < E; e0 += 64) {
+            const int e1 = min(e0 + 16, E - 1), e2 = min(e0 + 32, E - 1), e3 = min(e0 + 48, E - 1);
+            float acc[4];
+            tail_dot4(xs + c * ldx, a.We + (size_t)e0 * Kin, a.We + (size_t)e1 * Kin, a.We + (size_t)e2 * Kin, a.We + (size_t)e3 * Kin, Kin, vx, acc);
+            const int es_[4] = {e0, e0 + 16, e0 + 32, e0 + 48};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (es_[r] < E) {
+                    const float v = acc[r] + (a.be ? a.be[es_[r]] : 0.0f);
+                    es[c * lde + es_[r]] = v;
+                    if (b0 + c < a.B) a.emb[(size_t)(b0 + c) * E + es_[r]] = v;
+                }
+        }
+        __syncthreads();
+        for (int j0 = g; j0 < Hd; j0 += 64) {
+            const int j1 = min(j0 + 16, Hd - 1), j2 = min(j0 + 32, Hd - 1), j3 = min(j0 + 48, Hd - 1);
+            float acc[4];
+            tail_dot4(es + c * lde, a.W0 + (size_t)j0 * E, a.W0 + (size_t)j1 * E, a.W0 + (size_t)j2 * E, a.W0 + (size_t)j3 * E, E, ve, acc);
+            const int js[4] = {j0, j0 + 16, j0 + 32, j0 + 48};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (js[r] < Hd) hs[c * ldh + js[r]] = act_ct<ACT>(acc[r] + a.b0[js[r]]);
+        }
+        __syncthreads();
+        if (tid < 16 && b0 + tid < a.B) {
+            const float* hr = hs + tid * ldh;
+            float acc = 0.0f;
+            for (int j = 0; j < Hd; ++j) acc = fmaf(hr[j], a.w3[j], acc);
+            const float l = acc + a.b3[0];
+            a.logits[b0 + tid] = l;
+            if (a.probs) a.probs[b0 + tid] = 1.0f / (1.0f + expf(-l));
+        }
+        __syncthreads();
+    }
+}
+
+bool tail_supported(int Kin, int E) { return Kin >= 1 && Kin <= 512 && E >= 2 && E <= 256 && (E % 2) == 0; }
+
+hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s) {
+    if (!tail_supported(a.Kin, a.E)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)16 * ((((a.Kin + 3) & ~3) + 4) + (((a.E + 3) & ~3) + 4) + (a.E / 2 + 1)) * sizeof(float);
+    int grid = (a.B + 15) / 16;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+#define TAIL_CALL(A) hipLaunchKernelGGL((classifier_tail_kernel<A>), dim3(grid), dim3(256), lds, s, a)
+    NWW_DISPATCH_ACT(a.act, TAIL_CALL)
+#undef TAIL_CALL
+    return hipGetLastError();
+}

@@ -38,6 +38,8 @@ struct Run {
     float* emb = nullptr;       // [B][E]
     float* hid = nullptr;       // [B][E/2]
     float* logits = nullptr;    // [B]
+    float* probs = nullptr;     // [B] or null; a plan step that writes it clears `need_sigmoid`
+    bool need_sigmoid = true;
     float* splitk_ws = nullptr; size_t splitk_floats = 0; int cu_count = 256;
 };
 
@@ -391,6 +393,8 @@ struct PlanCtx {
         if (h->buf_per_clip[buf] < floats_per_clip) h->buf_per_clip[buf] = floats_per_clip;
     }
     void add(const std::string& name, std::function<hipError_t(Run&)> fn) { h->plan.push_back({name, std::move(fn)}); }
+    // the head's last Linear (-> embedding), deferred so that it can be fused with the classifier into one launch
+    std::string tail_name; int tail_in = 99, tail_K = 0; const float *tail_W = nullptr, *tail_b = nullptr;
 };
 
 // source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
@@ -433,6 +437,10 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
         return launch_gemm(g, r.stream);
     });
+}
+
+void set_tail(PlanCtx& p, const std::string& name, int in_id, int K, const float* W, const float* b) {
+    p.tail_name = name; p.tail_in = in_id; p.tail_K = K; p.tail_W = W; p.tail_b = b;
 }
 
 void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
@@ -628,7 +636,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[nxt], r.buf[nxt], lw, lb, r.B, L, act, r.stream); });
                 cur = nxt;
             }
-            add_gemm(p, "last_layer", cur, -2, 1, E, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"), ACT_NONE);
+            set_tail(p, "last_layer", cur, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
             break;
         }
         case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
@@ -638,7 +646,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
             }
             add_gemm(p, "fc1", 1, 0, 1, 128, 32 * (T / 4) * (F / 4), p.W("model.fc1.weight"), p.W("model.fc1.bias"), act);
-            add_gemm(p, "fc2", 0, -2, 1, E, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"), ACT_NONE);
+            set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
             break;
         }
         case NWW_HEAD_E2E_DNN: {                  // E2E_MelSpectrogram_CNN body: architectures.py:840-865,877-889
@@ -681,7 +689,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             }
             const int fc_out = fc_in ^ 1;
             add_gemm(p, "fc1+bn1", fc_in, fc_out, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
-            add_gemm(p, "out", fc_out, -2, 1, E, 128, p.W("model.out.weight"), p.W("model.out.bias"), ACT_NONE);
+            set_tail(p, "out", fc_out, 128, p.W("model.out.weight"), p.W("model.out.bias"));
             break;
         }
         case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287
@@ -705,12 +713,12 @@ extern "C" int nww_finalize(nww_handle* h) {
             p.need(seq, (size_t)C * Hc * Wc);
             p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
             add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, cur, 3, 4);
-            add_gemm(p, "fc", 4, -2, 1, E, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }
         case NWW_HEAD_GRU: {                      // GRUModel: architectures.py:129-145
             add_bigru_last(p, "model.gru", -1, T, F, L, nb, 2, 0, 1, 4);
-            add_gemm(p, "fc", 4, -2, 1, E, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }
         case NWW_HEAD_BCRESNET: {                 // BcResNetModel: architectures.py:620-687, channels-last on the GPU
@@ -783,7 +791,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int hw = hh * ww;
             p.need(2, 256);
             p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream); });
-            add_gemm(p, "fc", 2, -2, 1, E, 256, p.W("model.fc.weight"), p.W("model.fc.bias"), ACT_NONE);
+            set_tail(p, "fc", 2, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }
         case NWW_HEAD_CONFORMER: {                // ConformerModel: architectures.py:441-543
@@ -819,13 +827,26 @@ extern "C" int nww_finalize(nww_handle* h) {
                 p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[hb], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
             }
             p.add("mean:time", [=](Run& r) { return launch_mean_mid(r.buf[hb], r.buf[t1], r.B, T, D, r.stream); });
-            add_gemm(p, "output_proj", t1, -2, 1, E, D, p.W("model.output_proj.weight"), p.W("model.output_proj.bias"), ACT_NONE);
+            set_tail(p, "output_proj", t1, D, p.W("model.output_proj.weight"), p.W("model.output_proj.bias"));
             break;
         }
     }
-    // Model.classifier (model.py:291-296) -> logits [B]
-    add_gemm(p, "classifier.0", -2, -3, 1, E / 2, E, p.W("classifier.0.weight"), p.W("classifier.0.bias"), act);
-    add_gemm(p, "classifier.3", -3, -4, 1, 1, E / 2, p.W("classifier.3.weight"), p.W("classifier.3.bias"), ACT_NONE);
+    // embedding Linear + Model.classifier (model.py:291-296) (+ sigmoid) -> emb [B][E], logits [B] (, probs [B])
+    static const int tail_fused = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
+    if (tail_fused && tail_supported(p.tail_K, E)) {
+        const float *We = p.tail_W, *be = p.tail_b, *W0 = p.W("classifier.0.weight"), *b0 = p.W("classifier.0.bias"),
+                    *w3 = p.W("classifier.3.weight"), *b3 = p.W("classifier.3.bias");
+        const int tin = p.tail_in, tK = p.tail_K;
+        p.add("tail:" + p.tail_name + "+classifier", [=](Run& r) {
+            TailArgs t{src(r, tin), tK, We, be, E, W0, b0, w3, b3, r.emb, r.logits, r.probs, r.B, act};
+            r.need_sigmoid = false;
+            return launch_classifier_tail(t, r.stream);
+        });
+    } else {
+        add_gemm(p, p.tail_name, p.tail_in, -2, 1, E, p.tail_K, p.tail_W, p.tail_b, ACT_NONE);
+        add_gemm(p, "classifier.0", -2, -3, 1, E / 2, E, p.W("classifier.0.weight"), p.W("classifier.0.bias"), act);
+        add_gemm(p, "classifier.3", -3, -4, 1, 1, E / 2, p.W("classifier.3.weight"), p.W("classifier.3.bias"), ACT_NONE);
+    }
     h->finalized = true;
     return NWW_OK;
 }
@@ -909,6 +930,7 @@ extern "C" int nww_reserve(nww_handle* h, int32_t B, int32_t N) {
 static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s) {
     Run r;
     r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
+    r.probs = d_probs;
     r.splitk_ws = h->d_splitk; r.splitk_floats = h->splitk_per_clip * (size_t)h->cap_B; r.cu_count = h->cu_count;
     size_t off = 0;
     for (int i = 0; i < 6; ++i) {
@@ -921,7 +943,7 @@ static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, flo
         hipError_t e = st.fn(r);
         if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch '%s' failed: %s", st.name.c_str(), hipGetErrorString(e));
     }
-    if (d_probs) {
+    if (d_probs && r.need_sigmoid) {
         prof_mark(h, s, id);
         hipError_t e = launch_unary(r.logits, d_probs, (size_t)B, ACT_SIGMOID, s);
         if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch 'sigmoid' failed: %s", hipGetErrorString(e));

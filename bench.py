@@ -236,7 +236,7 @@ def main():
             "kernel_ms": kernel_ms,
         }
         out.update(extra)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0, the GPU box's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, sd, window, fb, a.cpu_seconds)
         print(json.dumps(out))
     model.close()

@@ -47,15 +47,16 @@ __device__ __forceinline__ float act_ct(float v) {
 // ------------------------------------------------------------------------------------------ GEMM
 // block = 256 threads = 4 waves as 2(M) x 2(N), each wave one 32x32 tile -> 64x64x32 tiles; coalesced 16-byte global
 // loads (8 rows x 128 B per wave instruction - a first version that fetched one row per lane straight from L2 was bound
-// by the texture-address unit: fc1 at 37% of peak), register-staged double buffering with one barrier per K-tile, operand
-// fragments read back with conflict-free ds_read_b128 (row stride 36 floats).
+// by the texture-address unit: fc1 at 37% of peak), next K-tile prefetched into registers during the multiplication, operand
+// fragments read back with conflict-free ds_read_b128 (row stride 36 floats).  ONE LDS stage (18 KB): the kernel is bound
+// by per-workgroup load latency, and twice the resident workgroups hide it better than a second stage did (+2-4 %).
 #define GT_LD 36
 // ACT is a template parameter: the run-time switch costs several scalar branches per output element, and for short-K
 // layers (Conformer: 4.5 K-tiles) the epilogue is a third of a workgroup's time.
 template <int ACT>
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][64 * GT_LD];
-    __shared__ __attribute__((aligned(16))) float Ws[2][64 * GT_LD];
+    __shared__ __attribute__((aligned(16))) float As[1][64 * GT_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[1][64 * GT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm = blockIdx.x * 64, bn = blockIdx.y * 64;
     const int i = lane & 31, h = lane >> 5;
@@ -123,14 +124,13 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
             }
         };
         float4 ra[2], rw[2];
-        int cur = 0;
-        if (k_begin < k_end) {
-            gload(k_begin, ra, rw);
-            lstore(0, ra, rw);
-        }
-        __syncthreads();
+        constexpr int cur = 0;
+        if (k_begin < k_end) gload(k_begin, ra, rw);
         for (int k0 = k_begin; k0 < k_end; k0 += 32) {
             const bool more = k0 + 32 < k_end;
+            __syncthreads();
+            lstore(0, ra, rw);
+            __syncthreads();
             if (more) gload(k0 + 32, ra, rw);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -141,10 +141,8 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
             }
-            if (more) lstore(cur ^ 1, ra, rw);
-            __syncthreads();
-            cur ^= 1;
         }
+        __syncthreads();
     };
     int k_begin = 0, k_end = g.K;
     if (g.splitk > 1) {

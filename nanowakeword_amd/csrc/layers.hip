@@ -53,7 +53,7 @@ __device__ __forceinline__ float act_ct(float v) {
 #define GT_LD 36
 // ACT is a template parameter: the run-time switch costs several scalar branches per output element, and for short-K
 // layers (Conformer: 4.5 K-tiles) the epilogue is a third of a workgroup's time.
-template <int ACT>
+template <int ACT, bool DUAL = false>
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[1][64 * GT_LD];
     __shared__ __attribute__((aligned(16))) float Ws[1][64 * GT_LD];
@@ -152,14 +152,14 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     }
     f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
-    const bool dual = g.A2 != nullptr || g.dw_x != nullptr;
-    if (g.dw_x) {                                                     // whole BcResNet block: depthwise feeds the pointwise
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; if (DUAL) acc2[r] = 0.0f; }
+    const bool dual = DUAL;
+    if (DUAL && g.dw_x) {                                                     // whole BcResNet block: depthwise feeds the pointwise
         contract(1, nullptr, 0, g.W, g.K, 0, g.K, acc);
         contract(2, nullptr, 0, g.W2, g.K2, 0, g.K2, acc2);
     } else {
         contract(0, g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
-        if (g.A2) contract(0, g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);  // second product of a dual GEMM (never split)
+        if (DUAL) contract(0, g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);  // second product of a dual GEMM (never split)
     }
     const int m0 = bm + (wave >> 1) * 32, n = bn + (wave & 1) * 32 + i;
     if (m0 >= g.M || n >= g.N) return;
@@ -247,10 +247,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         a.splitk = 1;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, 1);
         switch (a.act) {
-            case ACT_RELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_RELU>, grid, dim3(256), 0, s, a); break;
-            case ACT_GELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_GELU>, grid, dim3(256), 0, s, a); break;
-            case ACT_SILU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SILU>, grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL(gemm_lds_kernel<ACT_NONE>, grid, dim3(256), 0, s, a); break;
+            case ACT_RELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_RELU, true>), grid, dim3(256), 0, s, a); break;
+            case ACT_GELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_GELU, true>), grid, dim3(256), 0, s, a); break;
+            case ACT_SILU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_SILU, true>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_lds_kernel<ACT_NONE, true>), grid, dim3(256), 0, s, a); break;
         }
         return hipGetLastError();
     }
@@ -268,13 +268,17 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         GemmArgs a = g;
         a.splitk = sk;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
+#define GL_CALL(A)                                                                                         \
+    if (a.A2) hipLaunchKernelGGL((gemm_lds_kernel<A, true>), grid, dim3(256), 0, s, a);                    \
+    else hipLaunchKernelGGL((gemm_lds_kernel<A, false>), grid, dim3(256), 0, s, a);
         switch (a.act) {
-            case ACT_RELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_RELU>, grid, dim3(256), 0, s, a); break;
-            case ACT_GELU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_GELU>, grid, dim3(256), 0, s, a); break;
-            case ACT_SILU: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SILU>, grid, dim3(256), 0, s, a); break;
-            case ACT_SIGMOID: hipLaunchKernelGGL(gemm_lds_kernel<ACT_SIGMOID>, grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL(gemm_lds_kernel<ACT_NONE>, grid, dim3(256), 0, s, a); break;
+            case ACT_RELU: GL_CALL(ACT_RELU) break;
+            case ACT_GELU: GL_CALL(ACT_GELU) break;
+            case ACT_SILU: GL_CALL(ACT_SILU) break;
+            case ACT_SIGMOID: GL_CALL(ACT_SIGMOID) break;
+            default: GL_CALL(ACT_NONE) break;
         }
+#undef GL_CALL
         if (sk > 1) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);

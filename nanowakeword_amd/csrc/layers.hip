@@ -53,8 +53,10 @@ __device__ __forceinline__ float act_ct(float v) {
 #define GT_LD 36
 // ACT is a template parameter: the run-time switch costs several scalar branches per output element, and for short-K
 // layers (Conformer: 4.5 K-tiles) the epilogue is a third of a workgroup's time.
-template <int ACT, bool DUAL = false>
+// KIND 0: plain GEMM; 1: dual product (BcResNet block); 2: dual product with the depthwise conv computed by the loader
+template <int ACT, int KIND = 0>
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
+    constexpr bool DUAL = KIND != 0;
     __shared__ __attribute__((aligned(16))) float As[1][64 * GT_LD];
     __shared__ __attribute__((aligned(16))) float Ws[1][64 * GT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = min(bm + lr + 32 * q, g.M - 1);
-            if (mode == 0) {
+            if (KIND != 2 || mode == 0) {
                 arow[q] = A + (size_t)m * lda + 4 * lq;
             } else {
                 const int per = g.dw_Ho * g.dw_Wo;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
-                if (mode == 0) {
+                if (KIND != 2 || mode == 0) {
                     ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
                 } else if (mode == 2) {
                     ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + ((size_t)iy0[q] * g.dw_W + ix0[q]) * K + k0)
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; if (DUAL) acc2[r] = 0.0f; }
     const bool dual = DUAL;
-    if (DUAL && g.dw_x) {                                                     // whole BcResNet block: depthwise feeds the pointwise
+    if (KIND == 2) {                                                     // whole BcResNet block: depthwise feeds the pointwise
         contract(1, nullptr, 0, g.W, g.K, 0, g.K, acc);
         contract(2, nullptr, 0, g.W2, g.K2, 0, g.K2, acc2);
     } else {
@@ -247,10 +249,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         a.splitk = 1;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, 1);
         switch (a.act) {
-            case ACT_RELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_RELU, true>), grid, dim3(256), 0, s, a); break;
-            case ACT_GELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_GELU, true>), grid, dim3(256), 0, s, a); break;
-            case ACT_SILU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_SILU, true>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((gemm_lds_kernel<ACT_NONE, true>), grid, dim3(256), 0, s, a); break;
+            case ACT_RELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_RELU, 2>), grid, dim3(256), 0, s, a); break;
+            case ACT_GELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_GELU, 2>), grid, dim3(256), 0, s, a); break;
+            case ACT_SILU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_SILU, 2>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_lds_kernel<ACT_NONE, 2>), grid, dim3(256), 0, s, a); break;
         }
         return hipGetLastError();
     }
@@ -269,8 +271,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         a.splitk = sk;
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, sk);
 #define GL_CALL(A)                                                                                         \
-    if (a.A2) hipLaunchKernelGGL((gemm_lds_kernel<A, true>), grid, dim3(256), 0, s, a);                    \
-    else hipLaunchKernelGGL((gemm_lds_kernel<A, false>), grid, dim3(256), 0, s, a);
+    if (a.A2) hipLaunchKernelGGL((gemm_lds_kernel<A, 1>), grid, dim3(256), 0, s, a);                       \
+    else hipLaunchKernelGGL((gemm_lds_kernel<A, 0>), grid, dim3(256), 0, s, a);
         switch (a.act) {
             case ACT_RELU: GL_CALL(ACT_RELU) break;
             case ACT_GELU: GL_CALL(ACT_GELU) break;

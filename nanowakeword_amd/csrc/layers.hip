@@ -516,13 +516,30 @@ layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const float* xr = x + (size_t)row * D;
+    float* yr = y + (size_t)row * D;
+    if (D <= 256) {                       // the row lives in four registers per lane: one HBM read instead of three passes
+        float v[4];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = lane + 64 * j; v[j] = i < D ? xr[i] : 0.0f; s += v[j]; }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; if (lane + 64 * j < D) q = fmaf(d, d, q); }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            if (i < D) yr[i] = act_apply((v[j] - mu) * rstd * w[i] + b[i], act);
+        }
+        return;
+    }
     float s = 0.0f;
     for (int i = lane; i < D; i += 64) s += xr[i];
     const float mu = wave_sum(s) / (float)D;
     float q = 0.0f;
     for (int i = lane; i < D; i += 64) { const float d = xr[i] - mu; q = fmaf(d, d, q); }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
-    float* yr = y + (size_t)row * D;
     for (int i = lane; i < D; i += 64) yr[i] = act_apply((xr[i] - mu) * rstd * w[i] + b[i], act);
 }
 

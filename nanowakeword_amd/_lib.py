@@ -8,7 +8,7 @@ import os
 from .config import FrontendConfig, HeadConfig, HEAD_CODE, ACT_CODE
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnwwhip.so")
+LIB_PATH = os.environ.get("NWW_LIB_PATH") or os.path.join(_PKG, "libnwwhip.so")   # override: A/B builds only
 
 NWW_OK = 0
 ERR_NAMES = {1: "INVALID", 2: "MISSING", 3: "SHAPE", 4: "HIP", 5: "STATE", 6: "UNSUPPORTED"}

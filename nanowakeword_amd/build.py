@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "libnwwhip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
 EMU_LIB = os.path.join(EMU_DIR, "libfe_emu.so")
 
-HIP_SOURCES = ["nww_api.hip", "frontend.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_x3.hip", "fe_tables.cpp"]
+HIP_SOURCES = ["nww_api.hip", "frontend.hip", "frontend2.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_x3.hip", "fe_tables.cpp"]
 
 
 def _hipcc() -> str:
@@ -39,24 +39,34 @@ def _all_deps():
     return deps
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _newer(LIB, _all_deps()):
-        return LIB
+# hipcc's SLP pass pairs adjacent scalar f32 ops into v_pk_* instructions, which issue at half rate on gfx950 (no
+# gain) and cost a v_mov per operand to build the register pairs - measured on the 25-point DFT body: 532 VALU /
+# 120 VGPRs with it, 432 VALU / 62 VGPRs without.  Disabled for the VALU-bound files; NWW_SLP="all" / "none"
+# overrides for A/B builds (together with NWW_LIB_PATH to keep two libraries side by side).
+NO_SLP = {"frontend.hip", "frontend2.hip"}
+
+
+def build_hip(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
+    if not force and not _newer(out, _all_deps()):
+        return out
     objs = []
-    odir = os.path.join(PKG, "build")
+    tag = "" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]
+    odir = os.path.join(PKG, "build" + tag)
     os.makedirs(odir, exist_ok=True)
+    mode = os.environ.get("NWW_SLP", "")
     for src in HIP_SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I",
-               os.path.join(ROOT, "include"), "-x", "hip", "-c", sp, "-o", obj]
+        no_slp = mode == "none" or (mode != "all" and src in NO_SLP)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-fno-slp-vectorize"] if no_slp else []) + \
+              ["-I", CSRC, "-I", os.path.join(ROOT, "include"), "-x", "hip", "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
 
 
 def build_emu(force: bool = False) -> str:

@@ -105,13 +105,24 @@ NWW_HD nww_c32 w25(int p) {
 
 // ---- 25-point forward DFT in registers: n = 5a + b, k = c + 5d.
 //   U[b][c] = W25^(b c) sum_a y[5a+b] W5^(a c);  Z[c+5d] = sum_b U[b][c] W5^(b d)
-template <typename LoadF, typename StoreF>
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NWW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NWW_SCHED_FENCE() ((void)0)
+#endif
+// SEQ: keep the five row transforms (and the five column transforms) in program order on the GPU - without it the
+// scheduler interleaves them for ILP and the 25-point transform alone takes ~170 VGPRs; in order it needs the 50 of
+// the data plus one radix-5 butterfly's temporaries (same arithmetic either way).
+template <bool SEQ = false, typename LoadF, typename StoreF>
 NWW_HD void dft25(LoadF load, StoreF store) {
     nww_c32 u[5][5];   // u[b][a] then u[b][c]
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < 5; ++b)
 #pragma unroll
         for (int a = 0; a < 5; ++a) u[b][a] = load(5 * a + b);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        if (SEQ) NWW_SCHED_FENCE();
         dft5(u[b][0], u[b][1], u[b][2], u[b][3], u[b][4]);
         if (b > 0) {
 #pragma unroll
@@ -120,10 +131,12 @@ NWW_HD void dft25(LoadF load, StoreF store) {
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
+        if (SEQ) NWW_SCHED_FENCE();
         dft5(u[0][c], u[1][c], u[2][c], u[3][c], u[4][c]);   // over b -> index d
 #pragma unroll
         for (int d = 0; d < 5; ++d) store(c + 5 * d, u[d][c]);
     }
+    if (SEQ) NWW_SCHED_FENCE();
 }
 
 // S1: task (frame f, column n2).  span = int16 samples of this chunk (frame f starts at hop*f),
@@ -192,4 +205,59 @@ NWW_HD int fe_reflect(int s, int N) {
     if (s < 0) s = -s;
     if (s >= N) s = 2 * (N - 1) - s;
     return s;
+}
+
+// =====================================================================================================================
+// v2 "wave-private" schedule (frontend2.hip): one wave owns FE2_G consecutive frames of a clip and runs S1..S4 on
+// them without any workgroup barrier.  The arithmetic is the same 8 x 25 factorisation; what changes is where the
+// data lives: the lane's window/twiddle factors stay in registers for the whole launch, samples come straight from
+// global memory (L1/L2), and one 400-dword LDS region per frame is reused in place by every stage:
+//   S1 writes Y[k1][n2] (complex, [k1*25+n2]);  S2 reads its row and writes Z in natural order (Z[k] at complex k);
+//   S3 reads Z[k], Z[200-k] and writes the 201 powers as floats at dword FE2_PSHIFT(f) + k of the same region;
+//   S4 contracts them with the mel filterbank and stages the dB values at dword FE2_STAGE_OFF + FE2_PSHIFT(f) + j.
+#define FE2_G 8                       // frames per wave item
+#define FE2_FRAME_DW 400              // dwords of LDS per frame
+#define FE2_PSHIFT(f) (4 * ((f) >> 1))   // per-frame shift of the power row: spreads the 8 frames over distinct LDS banks
+#define FE2_STAGE_OFF 216
+#define FE2_MAX_TILES 8               // 16-filter tiles (n_mels <= 128)
+#define FE2_MAX_STEPS 512             // >= total MFMA steps of the mel plan (dense worst case 8 * 56)
+
+// Mel contraction plan for v_mfma_f32_16x16x4_f32: D[frame][filter] += P[frame][k] * fb[k][filter], one 16-filter tile at
+// a time over the tile's own bin range [k0, k0 + 4 nsteps).  Steps come in chunks of FE2_CHUNK (operands of the next
+// chunk are fetched while the current one is on the matrix pipe), so every tile is padded to whole chunks with
+// all-zero B rows.  b holds the B operand of every step in lane order; chunk_meta[c] = first bin of the chunk |
+// tile << 12 | (last chunk of its tile) << 16.
+#define FE2_CHUNK 8
+#define FE2_MAX_CHUNKS 64
+struct Fe2MelPlan {
+    int32_t ntiles;
+    int32_t total_steps;
+    int32_t nchunks;
+    int32_t tile_k0[FE2_MAX_TILES];
+    int32_t tile_nsteps[FE2_MAX_TILES];   // multiple of FE2_CHUNK (two accumulator chains: even / odd steps)
+    int32_t tile_first[FE2_MAX_TILES];
+    uint32_t chunk_meta[FE2_MAX_CHUNKS];
+    float b[FE2_MAX_STEPS * 64];          // [step][lane]: fb[k0 + 4 s + lane/16][16 tile + lane%16] (0 outside the table)
+};
+
+// S1 body: 8 (even, odd) int16 sample pairs of column n2 -> windowed radix-8 DFT -> twiddled Y[k1][n2], k1 = 0..7
+NWW_HD void fe2_s1(const uint32_t s[8], const nww_c32 win[8], const nww_c32 tw[7], nww_c32 z[8]) {
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+        z[n1] = c_make((float)(int16_t)(s[n1] & 0xffffu) * win[n1].x, (float)(int16_t)(s[n1] >> 16) * win[n1].y);
+    dft8(z);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) z[k1] = c_mul(z[k1], tw[k1 - 1]);
+}
+
+// mel power of (frame, filter j) in the summation order of the MFMA plan: two fmaf chains (even / odd steps, 4 bins per
+// step in ascending order), added at the end.  p = the frame's power row indexed by FFT bin (readable up to k0+4*nsteps).
+NWW_HD float fe2_mel_planned(const Fe2MelPlan* pl, const float* p, int j) {
+    const int t = j >> 4, n = j & 15;
+    const int k0 = pl->tile_k0[t], ns = pl->tile_nsteps[t];
+    const float* b = pl->b + (size_t)pl->tile_first[t] * 64 + n;
+    float acc[2] = {0.0f, 0.0f};
+    for (int s = 0; s < ns; ++s)
+        for (int kk = 0; kk < 4; ++kk) acc[s & 1] = fmaf(p[k0 + 4 * s + kk], b[s * 64 + kk * 16], acc[s & 1]);
+    return acc[0] + acc[1];
 }

@@ -81,3 +81,36 @@ int fe_num_frames(const FeParams& p, int n) {
     if (n < p.n_fft) return -1;
     return 1 + (n - p.n_fft) / p.hop;
 }
+
+std::string fe2_build_mel_plan(const FeParams& p, const float* fb, Fe2MelPlan* pl) {
+    std::memset(pl, 0, sizeof(*pl));
+    const int ntiles = (p.n_mels + 15) / 16;
+    if (ntiles > FE2_MAX_TILES) return "n_mels must be <= 128";
+    pl->ntiles = ntiles;
+    int first = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        int lo = FE_BINS, hi = -1;
+        for (int k = 0; k < FE_BINS; ++k)
+            for (int n = 0; n < 16; ++n) {
+                const int j = 16 * t + n;
+                if (j < p.n_mels && fb[(size_t)k * p.n_mels + j] != 0.f) { if (k < lo) lo = k; if (k > hi) hi = k; }
+            }
+        if (hi < 0) { lo = 0; hi = 0; }                      // a tile of empty filters: one all-zero pair of steps
+        int ns = (hi - lo + 1 + 3) / 4;
+        ns = (ns + FE2_CHUNK - 1) / FE2_CHUNK * FE2_CHUNK;    // whole chunks (even: two accumulator chains)
+        if (first + ns > FE2_MAX_STEPS || (first + ns) / FE2_CHUNK > FE2_MAX_CHUNKS) return "mel filterbank is too dense for the MFMA plan";
+        for (int c = 0; c < ns / FE2_CHUNK; ++c)
+            pl->chunk_meta[first / FE2_CHUNK + c] =
+                (uint32_t)(lo + 4 * FE2_CHUNK * c) | ((uint32_t)t << 12) | ((c == ns / FE2_CHUNK - 1) ? 1u << 16 : 0u);
+        pl->tile_k0[t] = lo; pl->tile_nsteps[t] = ns; pl->tile_first[t] = first;
+        for (int s = 0; s < ns; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int k = lo + 4 * s + (l >> 4), j = 16 * t + (l & 15);
+                pl->b[(size_t)(first + s) * 64 + l] = (k < FE_BINS && j < p.n_mels) ? fb[(size_t)k * p.n_mels + j] : 0.f;
+            }
+        first += ns;
+    }
+    pl->total_steps = first;
+    pl->nchunks = first / FE2_CHUNK;
+    return "";
+}

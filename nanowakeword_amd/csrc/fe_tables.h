@@ -17,5 +17,8 @@ void fe_default_melfb(const FeParams& p, std::vector<float>& fb);
 // Build LDS tables from a window [win_length] and filterbank [201][n_mels]. Returns "" or an error.
 std::string fe_build_tables(const FeParams& p, const float* window, const float* fb, FeTables* out);
 
+// MFMA mel-contraction plan of the wave-private kernel (frontend2.hip) from the same filterbank
+std::string fe2_build_mel_plan(const FeParams& p, const float* fb, Fe2MelPlan* out);
+
 // frame law; -1 if the clip is too short
 int fe_num_frames(const FeParams& p, int n_samples);

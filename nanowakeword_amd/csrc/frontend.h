@@ -9,3 +9,10 @@ void fe_plan(int T, int fc_max, int* fc, int* nchunks);
 hipError_t fe_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
                      float* d_db, float* d_mel, int frames_major, int fc_max, int block, int max_grid,
                      hipStream_t stream);
+
+// Wave-private kernel (frontend2.hip, the default): same contract.  mfma_mel = 1: mel contraction on the matrix cores
+// (d_plan from fe2_build_mel_plan), 0: sparse VALU loop.  block = 256 (4 waves); max_grid workgroups.
+int fe2_lds_bytes(int waves, int mfma_mel);
+hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p,
+                      const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
+                      int mfma_mel, int block, int max_grid, hipStream_t stream);

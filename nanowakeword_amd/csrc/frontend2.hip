@@ -1,0 +1,344 @@
+// frontend2.hip - wave-private fused framing / Hann / 400-point real FFT / power / mel / dB kernel for gfx950.
+//
+// Same arithmetic as frontend.hip (fe_steps.h: 400 real -> 200 complex = 8 x 25), different execution structure:
+// every WAVE owns FE2_G = 8 consecutive frames of one clip and runs all stages on them by itself, so the main loop
+// has no workgroup barrier at all - the 12 waves of a CU drift apart and cover each other's LDS / global latency.
+//   S1  lane = (frame slot 0..1, column n2 0..24): 8 sample pairs straight from global memory (4-byte loads, L1/L2
+//       hits: frames overlap 60 %), window + radix-8 + twiddle with the lane's 8 window pairs and 7 twiddles held in
+//       registers for the whole launch; next item's samples are prefetched into registers during S3/S4
+//   S2  lane = (frame 0..7, row k1 0..7): 25-point DFT in registers, written back in natural bin order
+//   S3  lane = bin (k and 64 + k): split + |X|^2, twiddles in registers, powers written in place
+//   S4  mel contraction on v_mfma_f32_16x16x4_f32 (M = frames, N = 16 filters, K = the tile's own bin range; the
+//       matrix pipe is otherwise idle in this kernel and runs beside the other waves' VALU work) or, for A/B
+//       measurements, the sparse VALU loop of the first kernel; 10 log10 on the accumulator layout
+//   out the wave's 8 x n_mels block leaves through a small LDS stage as 16-byte coalesced stores
+// LDS: 12.8 KB per wave (400 dwords per frame, reused in place by every stage) -> 12 waves per CU.
+// HBM traffic per clip: 2*N bytes read + 4*n_mels*frames written; nothing else leaves the CU.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "fe_steps.h"
+#include "frontend.h"
+#include "layers.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Fe2MelLds {                 // sparse-mel tables of the VALU variant (packed: 3 KB)
+    uint32_t desc[FE_MAX_MELS];    // lo | cnt << 8 | off << 16
+    float w[FE_MAX_MELW];
+};
+
+// LDS traffic inside one wave is ordered by the hardware; these fences only stop the compiler from moving LDS
+// accesses across a stage boundary (no instruction is emitted for wavefront scope).
+__device__ __forceinline__ void fe2_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 8 (even, odd) sample pairs of column n2 of an interior frame starting at sample `base` (even): aligned 4-byte loads
+__device__ __forceinline__ void fe2_load_column(const int16_t* __restrict__ x, int base, int n2, uint32_t v[8]) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(x + base) + n2;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) v[n1] = p[25 * n1];
+}
+
+// 10 log10 on the hardware log2 (v_log_f32, 1 ulp): |error| <= 2e-5 dB down to the -100 dB floor, against ~25 VALU
+// instructions for the correctly rounded log10f - and S4 evaluates it 16 times per item on the accumulator layout.
+__device__ __forceinline__ float fe2_db(float mel, float amin, float mult, float floor_db) {
+    const float db = (mult * 0.30102999566398120f) * __log2f(fmaxf(mel, amin));
+    return mel > amin ? db : floor_db;      // the clamp floor exactly as the reference computes it (-100 dB)
+}
+
+// FAST_OUT: frames-major log-mel only (the PCM -> logit path): branch-free S4 epilogue
+template <int MFMA_MEL, int FAST_OUT>
+__global__ void __launch_bounds__(256, 3)
+fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad,
+                int n_mels, float amin, float db_mult, float floor_db, const FeTables* __restrict__ gtb,
+                const Fe2MelPlan* __restrict__ plan, float* __restrict__ out_db, float* __restrict__ out_mel,
+                int frames_major, int dbg, int skew_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwv = blockDim.x >> 6;
+    const int tb_bytes = MFMA_MEL ? 0 : (int)sizeof(Fe2MelLds);
+    Fe2MelLds* mt = reinterpret_cast<Fe2MelLds*>(smem);
+    float* slab = reinterpret_cast<float*>(smem + tb_bytes) + wv * (FE2_G * FE2_FRAME_DW);
+    if (!MFMA_MEL) {      // the only workgroup barrier of the kernel: sparse-mel tables -> LDS, once
+        for (int i = threadIdx.x; i < FE_MAX_MELS; i += blockDim.x)
+            mt->desc[i] = (uint32_t)gtb->mel_lo[i] | ((uint32_t)gtb->mel_cnt[i] << 8) | ((uint32_t)gtb->mel_off[i] << 16);
+        for (int i = threadIdx.x; i < FE_MAX_MELW; i += blockDim.x) mt->w[i] = gtb->melw[i];
+        __syncthreads();
+    }
+    // ---- per-lane constants, resident in registers for the whole launch
+    const int n2 = lane % 25, slot = lane / 25;             // S1: lanes 50..63 idle
+    nww_c32 win[8], tw[7];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) win[n1] = gtb->win2[25 * n1 + n2];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw[k1 - 1] = gtb->tw200[k1 * 25 + n2];
+    const int k3a = lane, k3b = 64 + lane;                   // S3: bins k3a (all lanes) and k3b (lanes 0..36)
+    const bool has_b = k3b <= 100;
+    const nww_c32 twa = gtb->tw400[k3a], twb = gtb->tw400[has_b ? k3b : 100];
+    const int ia2 = k3a ? FE_M - k3a : 0;                    // partner bin of k3a (Z[200] = Z[0])
+    const int f2 = lane >> 3, k1_2 = lane & 7;               // S2: frame, row
+    // copy-out: stage offsets of the lane's four 16-byte pieces of the (frames x n_mels) block (index division done once)
+    int co_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * lane + 256 * r, f = i / n_mels, j = i - f * n_mels;
+        co_off[r] = f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j;
+    }
+    // S4 (MFMA): per-chunk metadata, lane c of one register = chunk c (read back with v_readlane)
+    const int mel_nchunks = MFMA_MEL ? plan->nchunks : 0;
+    const uint32_t mel_meta = MFMA_MEL ? plan->chunk_meta[lane] : 0u;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(pcm) | (row_stride * sizeof(int16_t))) & 3) == 0;
+
+    const int total = B * ngroups;
+    const int stride = gridDim.x * nwv;
+    uint32_t cur[8];                                         // samples of the S1 iteration about to run (lane's column)
+    auto geom = [&](int item, int& b, int& t0, int& nf) {
+        b = item / ngroups;
+        t0 = (item - b * ngroups) * FE2_G;
+        nf = min(FE2_G, T - t0);
+    };
+    // An item is "interior" when all its frames lie inside the clip and the clip is 4-byte aligned: S1 reads its
+    // samples straight from global memory, one iteration ahead (and the first iteration of the NEXT item during
+    // S3/S4).  Edge items (first / last group of a centred clip; odd alignment) stage their reflect-padded span in
+    // LDS first - in the regions of frames 6 and 7, which S1 overwrites last.
+    auto interior = [&](int t0, int nf) {
+        const int s0 = t0 * hop - pad;
+        return aligned && s0 >= 0 && s0 + (nf - 1) * hop + FE_NFFT <= N;
+    };
+    auto prefetch_first = [&](int item) {
+        int b, t0, nf;
+        geom(item, b, t0, nf);
+        if (interior(t0, nf) && slot < nf && slot < 2)
+            fe2_load_column(pcm + (size_t)b * row_stride, (t0 + slot) * hop - pad, n2, cur);
+    };
+    int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * nwv + wv));
+    // All waves run identical items, so without help the three waves of a SIMD stay in the same stage forever and the
+    // matrix-pipe stage (S4) of one never overlaps the VALU stages of the others.  Skew them once by their hardware
+    // wave slot: a third of an item each (skew_units x 64 clocks per slot step).
+    if (skew_units > 0) {
+        const int slot_id = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)) % 3;
+        for (int i = 0; i < slot_id * skew_units; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    if (item < total) prefetch_first(item);
+    for (; item < total; item += stride) {
+        int b, t0, nf;
+        geom(item, b, t0, nf);
+        const int16_t* x = pcm + (size_t)b * row_stride;
+        const bool inner = interior(t0, nf);
+        const uint32_t* span = reinterpret_cast<const uint32_t*>(slab + 6 * FE2_FRAME_DW);
+        if (!inner) {      // edge item: reflect-padded span -> LDS
+            const int s0 = t0 * hop - pad, npairs = ((nf - 1) * hop + FE_NFFT) >> 1;
+            uint32_t* sp = reinterpret_cast<uint32_t*>(slab + 6 * FE2_FRAME_DW);
+            for (int i = lane; i < npairs; i += 64) {
+                const int q = s0 + 2 * i;
+                sp[i] = (uint32_t)(uint16_t)x[fe_reflect(q, N)] | ((uint32_t)(uint16_t)x[fe_reflect(q + 1, N)] << 16);
+            }
+            fe2_wave_sync();
+            if (slot < nf && slot < 2) {
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) cur[n1] = span[((slot * hop) >> 1) + n2 + 25 * n1];
+            }
+        }
+        // ---- S1: window + radix-8 + twiddle -> Y[f][k1][n2]; two frames per iteration, next iteration's samples in flight
+#pragma unroll 1
+        for (int it = 0; it < FE2_G / 2; ++it) {
+            const int f = 2 * it + slot, fn = f + 2;
+            uint32_t nxt[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) nxt[n1] = 0u;
+            if (slot < 2 && fn < nf && it + 1 < FE2_G / 2) {
+                if (inner) {
+                    fe2_load_column(x, (t0 + fn) * hop - pad, n2, nxt);
+                } else {
+#pragma unroll
+                    for (int n1 = 0; n1 < 8; ++n1) nxt[n1] = span[((fn * hop) >> 1) + n2 + 25 * n1];
+                }
+            }
+            if (slot < 2 && f < nf && !(dbg & 1)) {
+                nww_c32 z[8];
+                fe2_s1(cur, win, tw, z);
+                nww_c32* y = reinterpret_cast<nww_c32*>(slab + f * FE2_FRAME_DW) + n2;
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1) y[k1 * 25] = z[k1];
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) cur[n1] = nxt[n1];
+        }
+        fe2_wave_sync();
+        // ---- S2: 25-point DFT of row k1, in place, output in natural bin order Z[k1 + 8 k2]
+        if (f2 < nf && !(dbg & 2)) {
+            nww_c32* zf = reinterpret_cast<nww_c32*>(slab + f2 * FE2_FRAME_DW);
+            const nww_c32* row = zf + k1_2 * 25;
+            nww_c32* dst = zf + k1_2;
+            dft25<true>([&](int i) { return row[i]; }, [&](int i, nww_c32 v) { dst[8 * i] = v; });
+        }
+        fe2_wave_sync();
+        // next item's samples: in flight during S3/S4 (S2, the register-hungry stage, is behind us)
+        if (item + stride < total) prefetch_first(item + stride);
+        // ---- S3: split + power, in place.  All of a frame's reads precede its writes (one wave, LDS in order).
+        if (!(dbg & 4)) {
+            const nww_c32* z0 = reinterpret_cast<const nww_c32*>(slab);
+            nww_c32 a1 = z0[k3a], b1 = z0[ia2], a2 = z0[has_b ? k3b : 0], b2 = z0[has_b ? FE_M - k3b : 0];
+            for (int f = 0; f < nf; ++f) {
+                nww_c32 na1 = a1, nb1 = b1, na2 = a2, nb2 = b2;
+                if (f + 1 < nf) {
+                    const nww_c32* zn = reinterpret_cast<const nww_c32*>(slab + (f + 1) * FE2_FRAME_DW);
+                    na1 = zn[k3a]; nb1 = zn[ia2]; na2 = zn[has_b ? k3b : 0]; nb2 = zn[has_b ? FE_M - k3b : 0];
+                }
+                float pa1, pb1, pa2, pb2;
+                fe_s3_core(a1, b1, twa, &pa1, &pb1);
+                fe_s3_core(a2, b2, twb, &pa2, &pb2);
+                float* p = slab + f * FE2_FRAME_DW + FE2_PSHIFT(f);
+                p[k3a] = pa1;
+                p[FE_M - k3a] = pb1;
+                if (has_b) { p[k3b] = pa2; p[FE_M - k3b] = pb2; }
+                a1 = na1; b1 = nb1; a2 = na2; b2 = nb2;
+            }
+        }
+        fe2_wave_sync();
+        // ---- S4: mel + dB
+        if (!(dbg & 8)) {
+            if (MFMA_MEL) {
+                // A: lane -> (frame = lane % 16 (rows 8..15 mirror 0..7 and are discarded), k = lane / 16);
+                // D: lane -> rows 4 (lane / 16) + i (valid for lanes 0..31), filter 16 t + lane % 16.
+                // Chunks of FE2_CHUNK steps; the next chunk's operands (A from LDS, B from the L1-resident plan) are
+                // fetched before the current chunk's MFMAs so the matrix pipe never waits on a load.
+                const int fa = lane & 7;
+                const float* arow = slab + fa * FE2_FRAME_DW + FE2_PSHIFT(fa) + (lane >> 4);
+                const float* bp = plan->b + lane;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                auto load_chunk = [&](int c, float (&av)[FE2_CHUNK], float (&bv)[FE2_CHUNK]) {
+                    const float* ap = arow + (__builtin_amdgcn_readlane(mel_meta, c) & 0xfff);
+                    const float* bq = bp + (size_t)((dbg & 16) ? 0 : c) * (FE2_CHUNK * 64);
+#pragma unroll
+                    for (int s = 0; s < FE2_CHUNK; ++s) { av[s] = ap[4 * s]; bv[s] = bq[64 * s]; }
+                };
+                auto run_chunk = [&](int c, const float (&av)[FE2_CHUNK], const float (&bv)[FE2_CHUNK]) {
+#pragma unroll
+                    for (int s = 0; s < FE2_CHUNK; s += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s + 1], bv[s + 1], acc1, 0, 0, 0);
+                    }
+                    const uint32_t meta = __builtin_amdgcn_readlane(mel_meta, c);
+                    if (meta & 0x10000u) {          // last chunk of its tile: dB + stage, then start the next tile
+                        const int j = 16 * ((meta >> 12) & 0xf) + (lane & 15);
+                        if (lane < 32 && j < n_mels) {
+                            if (FAST_OUT) {
+                                // rows of frames >= nf hold garbage: they are staged too and never copied out
+                                float* st = slab + (4 * (lane >> 4)) * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(4 * (lane >> 4)) + j;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    st[i * FE2_FRAME_DW + FE2_PSHIFT(i)] = fe2_db(acc0[i] + acc1[i], amin, db_mult, floor_db);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int f = 4 * (lane >> 4) + i;
+                                    const float m = acc0[i] + acc1[i];
+                                    const float db = fe2_db(m, amin, db_mult, floor_db);
+                                    if (f < nf) {
+                                        if (frames_major) {
+                                            slab[f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j] = db;
+                                            if (out_mel) out_mel[((size_t)b * T + t0 + f) * n_mels + j] = m;
+                                        } else {
+                                            const size_t o = ((size_t)b * n_mels + j) * T + t0 + f;
+                                            if (out_db) out_db[o] = db;
+                                            if (out_mel) out_mel[o] = m;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                };
+                // two operand buffers, two chunks per trip: a chunk's MFMAs run while the next chunk's loads are in flight
+                float a0[FE2_CHUNK], b0[FE2_CHUNK], a1[FE2_CHUNK], b1[FE2_CHUNK];
+                const int last = mel_nchunks - 1;
+                load_chunk(0, a0, b0);
+#pragma unroll 1
+                for (int c = 0; c < mel_nchunks; c += 2) {
+                    load_chunk(min(c + 1, last), a1, b1);
+                    run_chunk(c, a0, b0);
+                    load_chunk(min(c + 2, last), a0, b0);
+                    if (c + 1 < mel_nchunks) run_chunk(c + 1, a1, b1);
+                }
+            } else {
+                const int f = lane & 7;
+                if (f < nf) {
+                    const float* prow = slab + f * FE2_FRAME_DW + FE2_PSHIFT(f);
+                    for (int j = lane >> 3; j < n_mels; j += 8) {
+                        const uint32_t d = mt->desc[j];
+                        const float* p = prow + (d & 0xffu);
+                        const float* w = mt->w + (d >> 16);
+                        const int n = (d >> 8) & 0xffu;
+                        float m = 0.0f;
+                        for (int i = 0; i < n; ++i) m = fmaf(p[i], w[i], m);
+                        const float db = fe2_db(m, amin, db_mult, floor_db);
+                        if (frames_major) {
+                            slab[f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j] = db;
+                            if (out_mel) out_mel[((size_t)b * T + t0 + f) * n_mels + j] = m;
+                        } else {
+                            const size_t o = ((size_t)b * n_mels + j) * T + t0 + f;
+                            if (out_db) out_db[o] = db;
+                            if (out_mel) out_mel[o] = m;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- out (frames-major): the wave's nf x n_mels block is contiguous in HBM
+        if (frames_major && out_db) {
+            fe2_wave_sync();
+            float* dst = out_db + ((size_t)b * T + t0) * n_mels;
+            const int cnt = nf * n_mels;
+            if ((n_mels & 3) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * lane + 256 * r;
+                    if (i < cnt) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(slab + co_off[r]);
+                }
+            } else {
+                for (int i = lane; i < cnt; i += 64) {
+                    const int f = i / n_mels, j = i - f * n_mels;
+                    dst[i] = slab[f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j];
+                }
+            }
+        }
+        fe2_wave_sync();      // the next item's S1 overwrites the stage
+    }
+}
+
+int fe2_lds_bytes(int waves, int mfma_mel) {
+    return waves * FE2_G * FE2_FRAME_DW * 4 + (mfma_mel ? 0 : (int)sizeof(Fe2MelLds));
+}
+
+hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p,
+                      const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
+                      int mfma_mel, int block, int max_grid, hipStream_t stream) {
+    if (block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
+    const int nwv = block / 64;
+    const int ngroups = (T + FE2_G - 1) / FE2_G;
+    const int lds = fe2_lds_bytes(nwv, mfma_mel);
+    const int fast = (frames_major && d_db && !d_mel) ? 1 : 0;
+    auto kern = mfma_mel ? (fast ? fe2_wave_kernel<1, 1> : fe2_wave_kernel<1, 0>) : fe2_wave_kernel<0, 0>;
+    const void* fn = reinterpret_cast<const void*>(kern);
+    {
+        hipError_t e = nww_allow_lds(fn, (size_t)lds);
+        if (e != hipSuccess) return e;
+    }
+    static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
+    static const int skew = [] { const char* e = getenv("NWW_FE_SKEW"); return e ? atoi(e) : 2; }();   // x 4096 clocks per wave slot
+    const long long total = (long long)B * ngroups;
+    long long need = (total + nwv - 1) / nwv;
+    int grid = (int)(need < max_grid ? need : max_grid);
+    if (grid < 1) grid = 1;
+    const int pad = p.center ? FE_NFFT / 2 : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, d_pcm, row_stride, B, N, T, ngroups, p.hop, pad, p.n_mels,
+                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, skew);
+    return hipGetLastError();
+}

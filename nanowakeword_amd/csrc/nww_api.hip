@@ -54,6 +54,7 @@ struct nww_handle {
     bool finalized = false;
     float* d_weights = nullptr;
     FeTables* d_tables = nullptr;
+    Fe2MelPlan* d_melplan = nullptr;
     hipStream_t own_stream = nullptr;
     std::vector<Step> plan;
     size_t buf_per_clip[6] = {0, 0, 0, 0, 0, 0};   // floats per clip of each workspace buffer
@@ -104,7 +105,7 @@ static void prof_begin(nww_handle* h) {
     h->prof_ids.emplace_back();
 }
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;   // nww_create errors: per thread, so concurrent creates do not race
 
 static int fail(nww_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -329,6 +330,7 @@ extern "C" int nww_destroy(nww_handle* h) {
     if (h->d_weights) (void)hipFree(h->d_weights);
     for (auto& kv : h->x3_weights) (void)hipFree(kv.second);
     if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_melplan) (void)hipFree(h->d_melplan);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (auto& run : h->prof_runs) for (auto e : run) (void)hipEventDestroy(e);
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -617,6 +619,11 @@ extern "C" int nww_finalize(nww_handle* h) {
         HIP_TRY(h, hipMalloc(&h->d_tables, tbytes));
         HIP_TRY(h, hipMemset(h->d_tables, 0, tbytes));
         HIP_TRY(h, hipMemcpy(h->d_tables, &tb, sizeof(FeTables), hipMemcpyHostToDevice));
+        std::vector<Fe2MelPlan> plan(1);
+        const std::string e2 = fe2_build_mel_plan(h->fe, fb.data(), plan.data());
+        if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
+        HIP_TRY(h, hipMalloc(&h->d_melplan, sizeof(Fe2MelPlan)));
+        HIP_TRY(h, hipMemcpy(h->d_melplan, plan.data(), sizeof(Fe2MelPlan), hipMemcpyHostToDevice));
     }
     // ---- plan
     PlanCtx p{h};
@@ -967,7 +974,11 @@ static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float
     static const int fc_env = [] { const char* e = getenv("NWW_FE_FC"); return e ? atoi(e) : 16; }();
     static const int blk_env = [] { const char* e = getenv("NWW_FE_BLOCK"); return e ? atoi(e) : 256; }();
     static const int wg_env = [] { const char* e = getenv("NWW_FE_WGS_PER_CU"); return e ? atoi(e) : 3; }();
-    hipError_t e = fe_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s);
+    static const int ver_env = [] { const char* e = getenv("NWW_FE_V"); return e ? atoi(e) : 2; }();      // 1: barrier-per-stage kernel
+    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 1; }();    // 0: sparse VALU mel
+    hipError_t e = ver_env == 1
+        ? fe_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s)
+        : fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, 256, h->cu_count * wg_env, s);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }
@@ -1033,15 +1044,17 @@ extern "C" int nww_frontend_ex(nww_handle* h, const int16_t* pcm, int32_t B, int
     if (rc) return rc;
     hipStream_t s = h->own_stream;
     const size_t n_out = (size_t)B * T * h->cfg.n_mels;
-    float* d_mel = nullptr;
-    if (melpower_out) HIP_TRY(h, hipMalloc(&d_mel, n_out * sizeof(float)));
+    struct DevScratch {            // frees the optional mel-power scratch on every exit path
+        float* p = nullptr;
+        ~DevScratch() { if (p) (void)hipFree(p); }
+    } mel;
+    if (melpower_out) HIP_TRY(h, hipMalloc(&mel.p, n_out * sizeof(float)));
     HIP_TRY(h, hipMemcpyAsync(h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), hipMemcpyHostToDevice, s));
-    rc = frontend_dev(h, h->d_pcm, B, N, h->d_logmel, d_mel, 0, s, frames_out);
-    if (rc) { if (d_mel) (void)hipFree(d_mel); return rc; }
+    rc = frontend_dev(h, h->d_pcm, B, N, h->d_logmel, mel.p, 0, s, frames_out);
+    if (rc) return rc;
     if (logmel_out) HIP_TRY(h, hipMemcpyAsync(logmel_out, h->d_logmel, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (melpower_out) HIP_TRY(h, hipMemcpyAsync(melpower_out, d_mel, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (melpower_out) HIP_TRY(h, hipMemcpyAsync(melpower_out, mel.p, n_out * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (d_mel) (void)hipFree(d_mel);
     return NWW_OK;
 }
 

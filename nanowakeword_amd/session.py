@@ -76,7 +76,10 @@ class HipModel:
             raise _EXC.get(rc, NwwError)(msg)
         self.finalized = False
         if window is None and mel_fb is None and tables == "torchaudio":
-            window, mel_fb = torchaudio_tables(self.fe)
+            try:
+                window, mel_fb = torchaudio_tables(self.fe)
+            except ImportError:       # no torch on this host: the C library's double-precision tables (<= 1e-5 per coefficient away)
+                window = mel_fb = None
         if window is not None:
             self._load("frontend.window", _as_f32(window))
         if mel_fb is not None:

@@ -246,7 +246,8 @@ def state_dict_from_onnx(path_or_bytes):
         cfg.conformer_n_head = cfg.conformer_d_model // dh
     if g.metadata.get("mode") == "e2e" and mode != "e2e":
         raise ValueError("ONNX metadata says mode=e2e but the graph has no mel front end")
-    info = {"mode": mode, "clip_samples": clip_samples, "frontend": fe, "opset": g.opset, "producer": g.producer}
+    info = {"mode": mode, "clip_samples": clip_samples, "frontend": fe, "opset": g.opset, "producer": g.producer,
+            "input_ndim": len(in_shape)}
     return cfg, sd, info
 
 
@@ -293,19 +294,28 @@ def load_bundle(path: str):
 def load_session(path: str, device: int = 0):
     """Bundle or reference .onnx -> finalized HipModel -> HipSession (raises if the HIP library or a GPU is missing)."""
     from .session import HipModel, HipSession
+    if path.endswith((".pt", ".pth")):
+        raise ValueError(f"{path}: a raw PyTorch state_dict carries no architecture; convert it once with "
+                         "weights.state_dict_from_pt() + infer_head_config() + save_bundle() "
+                         "and load the resulting .nww.npz")
     if path.endswith(".onnx"):                          # the reference's own artefact (nanointerpreter.py:955-959)
         head, sd, info = state_dict_from_onnx(path)
         fe = info["frontend"] or FrontendConfig()
-        extras, meta = {}, {"mode": info["mode"], "clip_samples": info["clip_samples"]}
+        extras, meta = {}, {"mode": info["mode"], "clip_samples": info["clip_samples"], "input_ndim": info["input_ndim"]}
     else:
         head, fe, sd, extras, meta = load_bundle(path)
+    # feature-mode heads never run the frontend and e2e exports carry their own tables (model.mel_spec.*): neither
+    # needs torch to rebuild torchaudio's float32 tables
+    feature_mode = meta.get("mode", "e2e") == "features"
+    own_tables = "frontend.window" in extras or any(k.startswith("model.mel_spec.") for k in sd)
     model = HipModel(head, fe, device=device, state_dict=sd, window=extras.get("frontend.window"),
-                     mel_fb=extras.get("frontend.mel_fb"))
+                     mel_fb=extras.get("frontend.mel_fb"), tables="builtin" if (feature_mode or own_tables) else "torchaudio")
     name = path.rsplit("/", 1)[-1]
     for ext in (".nww.npz", ".npz", ".onnx"):
         if name.endswith(ext):
             name = name[:-len(ext)]
             break
-    s = HipSession(model, mode=meta.get("mode", "e2e"), clip_samples=int(meta.get("clip_samples", 16000)), name=name)
+    s = HipSession(model, mode=meta.get("mode", "e2e"), clip_samples=int(meta.get("clip_samples", 16000)),
+                   input_ndim=int(meta.get("input_ndim", 3)), name=name)
     s.name = name
     return s

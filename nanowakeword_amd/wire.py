@@ -67,16 +67,23 @@ class MicroBatcher:
 
     ``feature_session`` : session protocol object for 0x01 requests (feature mode, input (B,T,F)).
     ``audio_backend``   : object with ``forward_pcm(int16 [B,N]) -> (logits, probs)`` (a HipModel) for 0x03
-                          requests in the e2e pipeline; each client owns a window of ``clip_samples`` samples and
-                          is scored once it has received a full window (the reference server keeps the same
-                          per-connection deque, remote_verifier.py:436-452; before the window is full it replies 0.0).
+                          requests in the e2e pipeline.  Per client, the reference server's state machine
+                          (remote_verifier.py:377,436-453) is mirrored: a deque of ``clip_samples`` samples plus an
+                          ``accumulated`` counter that is reset after every scoring, so once the deque is full a
+                          client is scored once per ``clip_samples`` of NEW audio and gets 0.0 in between (a client
+                          that sends one full clip per message - the reference's own client - is scored every time).
+                          One deliberate deviation: while the deque is still filling the reference scores the
+                          partial clip it holds (``accumulated >= len(buffer)`` is true on the first message), which
+                          a fixed-length e2e model cannot run; here that case replies 0.0 and resets the counter
+                          exactly as the reference's scoring branch would.
     """
 
     def __init__(self, feature_session=None, audio_backend=None, clip_samples: int = 16000):
         self.feature_session, self.audio_backend, self.clip_samples = feature_session, audio_backend, int(clip_samples)
         self._pending: List[Tuple[int, str, str, np.ndarray]] = []
         self._windows: Dict[str, np.ndarray] = {}
-        self._seen: Dict[str, int] = {}
+        self._acc: Dict[str, int] = {}      # samples since the last scoring (reference: e2e_state["accumulated"])
+        self._fill: Dict[str, int] = {}     # len(e2e_state["buffer"])
         self._ticket = 0
 
     def submit(self, client_id: str, message: bytes) -> int:
@@ -93,7 +100,8 @@ class MicroBatcher:
 
     def drop_client(self, client_id: str):
         self._windows.pop(client_id, None)
-        self._seen.pop(client_id, None)
+        self._acc.pop(client_id, None)
+        self._fill.pop(client_id, None)
 
     def flush(self) -> Dict[int, str]:
         """Score everything submitted since the last flush; returns {ticket: reply JSON}."""
@@ -122,9 +130,14 @@ class MicroBatcher:
                 elif n:
                     w[:-n] = w[n:]
                     w[-n:] = a
-                self._seen[c] = self._seen.get(c, 0) + n
-                if self._seen[c] >= self.clip_samples:
-                    ready.append((t, w.copy()))
+                self._fill[c] = min(self._fill.get(c, 0) + n, self.clip_samples)
+                self._acc[c] = self._acc.get(c, 0) + n
+                if self._acc[c] >= self._fill[c]:          # remote_verifier.py:447-450
+                    self._acc[c] = 0
+                    if self._fill[c] == self.clip_samples:
+                        ready.append((t, w.copy()))
+                    else:
+                        replies[t] = encode_reply(0.0)     # partial clip (see class docstring)
                 else:
                     replies[t] = encode_reply(0.0)
             if ready:

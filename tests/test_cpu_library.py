@@ -90,6 +90,25 @@ def emu():
                              mel.ctypes.data_as(vp), db.ctypes.data_as(vp))
         assert r == T
         return mel, db
+
+    def run2(pcm, n_mels, center, window, fb, mfma_mel=1):
+        """the wave-private schedule of frontend2.hip (the default kernel)"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, N = pcm.shape
+        T = oracle.frame_count(N, center=bool(center))
+        mel = np.zeros((B, n_mels, T), np.float32)
+        db = np.zeros_like(mel)
+        w = None if window is None else np.ascontiguousarray(window, np.float32)
+        f = None if fb is None else np.ascontiguousarray(fb, np.float32)
+        vp = ctypes.c_void_p
+        r = lib.emu_frontend2(pcm.ctypes.data_as(vp), B, N, n_mels, int(center), 160,
+                              w.ctypes.data_as(vp) if w is not None else None,
+                              f.ctypes.data_as(vp) if f is not None else None, int(mfma_mel),
+                              mel.ctypes.data_as(vp), db.ctypes.data_as(vp))
+        assert r == T
+        return mel, db
+    lib.emu_frontend2.restype = ctypes.c_int
+    run.v2 = run2
     return run
 
 
@@ -103,6 +122,23 @@ def test_kernel_arithmetic_on_cpu_vs_reference(emu, golden_frontend, variant, fc
     else:
         mel, db = emu(g["pcm"], 40, 0, g["window"], g["fb40"], fc)
         assert_frontend_close(mel, db, g["mel40"], g["db40"], variant)
+
+
+@pytest.mark.parametrize("variant,mfma_mel", [("64c", 1), ("64c", 0), ("40n", 1), ("40n", 0)])
+def test_wave_private_schedule_on_cpu_vs_reference(emu, golden_frontend, variant, mfma_mel):
+    """frontend2.hip's schedule (8-frame wave items, in-place LDS regions, MFMA-plan mel order) with the shared bodies."""
+    g = golden_frontend
+    if variant == "64c":
+        mel, db = emu.v2(g["pcm"], 64, 1, g["window"], g["fb64"], mfma_mel)
+        assert_frontend_close(mel, db, g["mel64"], g["db64"], variant)
+        mel1, _ = emu(g["pcm"], 64, 1, g["window"], g["fb64"])
+        if not mfma_mel:                       # same bodies, same summation order: bit-identical to the first kernel
+            assert np.array_equal(mel, mel1)
+    else:
+        mel, db = emu.v2(g["pcm"], 40, 0, g["window"], g["fb40"], mfma_mel)
+        assert_frontend_close(mel, db, g["mel40"], g["db40"], variant)
+    _, dbs = emu.v2(g["short_pcm"], 64, 1, g["window"], g["fb64"], mfma_mel)
+    assert np.abs(dbs - g["short_db64"]).max() <= 1e-4
 
 
 def test_fft_path_is_closer_to_exact_than_dense_dft(emu, golden_frontend):

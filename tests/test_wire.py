@@ -62,13 +62,29 @@ def test_microbatcher_batches_clients():
     for t, f in zip(tickets, feats):
         assert abs(wire.decode_reply(rep[t]) - float(1 / (1 + np.exp(-f.mean())))) < 1e-6
     assert other in rep and all(wire.decode_reply(rep[t]) == 0.0 for t in at)               # windows not full yet
-    for k in range(1, 4):
-        at = [mb.submit(f"a{i}", wire.encode_audio(audio[i, 1280 * k:1280 * (k + 1)])) for i in range(3)]
+    # the reference's per-connection state machine (remote_verifier.py:377,445-450), restated: a deque of
+    # clip_samples + an `accumulated` counter that is reset after every scoring
+    from collections import deque
+    buf, acc, scored_at = deque(maxlen=4000), 0, []
+    for k in range(0, 9):
+        buf.extend(range(1280)); acc += 1280
+        if acc >= len(buf):
+            acc = 0
+            if len(buf) == 4000:
+                scored_at.append(k)
+    assert scored_at == [4, 8]                       # M + n samples for the first full window, then once per M new samples
+    for k in range(1, 9):
+        at = [mb.submit(f"a{i}", wire.encode_audio(audio[i % 3, (1280 * k) % 4720:(1280 * k) % 4720 + 1280])) for i in range(3)]
+        calls0 = MeanAudio.calls
         rep = mb.flush()
-    assert MeanAudio.calls == 1                                                             # 3 clients, one batched call once full
-    for i, t in enumerate(at):
-        want = float(np.clip(np.abs(audio[i, 5120 - 4000:5120].astype(np.float32) / 32768.0).mean() * 4, 0, 1))
-        assert abs(wire.decode_reply(rep[t]) - want) < 1e-6
+        if k in scored_at:
+            assert MeanAudio.calls == calls0 + 1                                            # 3 clients, one batched call
+            for i, t in enumerate(at):
+                w = np.concatenate([audio[i, (1280 * j) % 4720:(1280 * j) % 4720 + 1280] for j in range(k - 3, k + 1)])[-4000:]
+                want = float(np.clip(np.abs(w.astype(np.float32) / 32768.0).mean() * 4, 0, 1))
+                assert abs(wire.decode_reply(rep[t]) - want) < 1e-6
+        else:
+            assert MeanAudio.calls == calls0 and all(wire.decode_reply(rep[t]) == 0.0 for t in at)
     mb.drop_client("a0")
     t = mb.submit("a0", wire.encode_audio(audio[0, :1280]))
     assert wire.decode_reply(mb.flush()[t]) == 0.0

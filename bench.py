@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6"],
                     help="arithmetic of the fused conv trunk's conv2 (all float32-grade; nww_config.conv_arith)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the self-audit legs (other conv arithmetics, sustained loop, PCIe-inclusive rate); N=1 only anyway")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--debug-single-gpu", action="store_true",
                     help="control-flow check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the gather "
@@ -86,6 +89,87 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
             "sample": f"{best[2]} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
                       f"dense-DFT frontend + {cfg.model_type} head) in {best[3]:.1f} s on {best[1]} BLAS thread(s) "
                       f"(best of 1/8/{threads} threads; 1 thread = the reference interpreter's setting)"}
+
+
+def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logits):
+    """Self-audit legs of the N = 1 line (never part of `value`):
+      arith      the same step with conv2 on the plain f32 MFMA and with all nine bf16 partial products
+      sustained  the headline step repeated for >= --sustain-seconds (long enough for an outside GPU-busy sampler)
+      h2d_inclusive  PCM starting in pinned host memory: double-buffered uploads on a copy stream overlapped with the
+                 previous batch's kernels, logits copied back to the host (the PCIe-inclusive rate; Gen5 x16 ceiling
+                 = 63 GB/s / 32 kB per clip = 1.97 M clips/s)"""
+    from nanowakeword_amd.session import HipModel
+    out = {}
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    logits = torch.empty(B, dtype=torch.float32, device=dev)
+    arith = {}
+    for mode in ("f32", "bf16x9"):
+        if mode == a.conv_arith:
+            continue
+        m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=mode)
+        m.reserve(B, N)
+        for _ in range(3):
+            m.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            m.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        arith[mode] = {"value": round(B * a.steps / dt, 1), "ms_per_step": round(dt / a.steps * 1e3, 4),
+                       "max_abs_dlogit_vs_headline_arith": float(np.abs(logits.cpu().numpy() - ref_logits).max())}
+        m.close()
+    out["arith"] = arith
+    m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=a.conv_arith)
+    m.reserve(B, N)
+    # ---- sustained
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(50):
+            m.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        n += 50
+        dt = time.perf_counter() - t0
+        if dt >= a.sustain_seconds:
+            break
+    out["sustained"] = {"value": round(B * n / dt, 1), "unit": "clips/s", "seconds": round(dt, 2), "steps": n}
+    # ---- PCIe-inclusive: pinned host PCM -> (copy stream) -> device double buffer -> kernels -> host logits
+    host = [torch.from_numpy(pcm_host).pin_memory(), torch.from_numpy(np.roll(pcm_host, 1, axis=0).copy()).pin_memory()]
+    dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
+    lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2)]
+    hlog = [torch.empty(B, dtype=torch.float32).pin_memory() for _ in range(2)]
+    copy_s, comp_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    up = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+
+    def run(k):
+        for i in range(k):
+            j = i & 1
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(done[j])                # the kernels that read dbuf[j] two batches ago are finished
+                dbuf[j].copy_(host[j], non_blocking=True)
+                up[j].record(copy_s)
+            with torch.cuda.stream(comp_s):
+                comp_s.wait_event(up[j])
+                m.forward_pcm_dev(dbuf[j].data_ptr(), B, N, lbuf[j].data_ptr(), 0, comp_s.cuda_stream)
+                hlog[j].copy_(lbuf[j], non_blocking=True)
+                done[j].record(comp_s)
+        torch.cuda.synchronize(dev)
+    for e in done:
+        e.record(comp_s)
+    run(4)
+    k = max(20, a.steps)
+    t0 = time.perf_counter()
+    run(k)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(hlog[0].numpy(), ref_logits), "PCIe-inclusive path changed the logits"
+    out["h2d_inclusive"] = {"value": round(B * k / dt, 1), "unit": "clips/s", "batches": k,
+                            "pcm_gb_per_s": round(B * k * N * 2 / dt / 1e9, 2),
+                            "note": "pinned host int16 PCM, uploads double-buffered on a copy stream under the previous "
+                                    "batch's kernels, logits copied back; never the headline value"}
+    m.close()
+    return out
 
 
 def main():
@@ -236,6 +320,8 @@ def main():
             "kernel_ms": kernel_ms,
         }
         out.update(extra)
+        if world == 1 and not a.no_extras and not any(os.environ.get(k, "0") not in ("", "0") for k in ("NWW_FE_DBG", "NWW_TRUNK_DBG")):
+            out.update(audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, lg))
         if not a.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0, the GPU box's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, sd, window, fb, a.cpu_seconds)
         print(json.dumps(out))

@@ -83,7 +83,10 @@ typedef struct nww_config {
          NWW_ARITH_BF16X6 the six largest partial products; the dropped ones are < 2^-23 of a product
          NWW_ARITH_DEFAULT lets the library choose (environment NWW_TRUNK_X3 = 0 | 9 | 6 overrides)              */
     int32_t conv_arith;
-    int32_t reserved[6];
+    /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
+       CRNNModel, modules/architectures.py:238-254)                                                               */
+    int32_t crnn_rnn_lstm;
+    int32_t reserved[5];
 } nww_config;
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1

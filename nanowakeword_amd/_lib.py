@@ -26,7 +26,8 @@ class NwwConfig(C.Structure):
         ("conformer_d_model", C.c_int32), ("conformer_n_head", C.c_int32),
         ("mel_major_features", C.c_int32),
         ("conv_arith", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("crnn_rnn_lstm", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -113,6 +114,7 @@ def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major
     for i, v in enumerate(ch):
         c.crnn_channels[i] = int(v)
     c.conformer_d_model, c.conformer_n_head = head.conformer_d_model, head.conformer_n_head
+    c.crnn_rnn_lstm = int(head.model_type == "crnn" and head.crnn_rnn_type == "lstm")
     if mel_major_features is None:
         mel_major_features = head.model_type == "e2e_dnn"
     c.mel_major_features = int(bool(mel_major_features))

@@ -71,8 +71,9 @@ class HeadConfig:
         if self.activation not in ACTIVATIONS:
             # the reference silently falls back to ReLU (model.py:86-87)
             self.activation = "relu"
-        if self.model_type == "crnn" and self.crnn_rnn_type.lower() != "gru":
-            raise ValueError("only crnn_rnn_type='gru' is in scope (SURVEY.md §8a a10)")
+        # CRNNModel: 'gru' -> nn.GRU, anything else -> nn.LSTM (architectures.py:238-254); the reference's default
+        # config value is "lstm" (model.py:214), BASELINE config 4 names the GRU - HeadConfig defaults to the latter
+        self.crnn_rnn_type = "gru" if str(self.crnn_rnn_type).lower() == "gru" else "lstm"
 
     def to_dict(self):
         return asdict(self)
@@ -95,14 +96,15 @@ def _ln(spec, prefix, d):
     spec[prefix + ".bias"] = (d,)
 
 
-def _gru(spec, prefix, input_size, hidden, n_layers):
+def _gru(spec, prefix, input_size, hidden, n_layers, gates=3):
+    """nn.GRU (gates = 3: r, z, n) / nn.LSTM (gates = 4: i, f, g, o) parameter names, bidirectional."""
     for l in range(n_layers):
         isz = input_size if l == 0 else 2 * hidden
         for sfx in ("", "_reverse"):
-            spec[f"{prefix}.weight_ih_l{l}{sfx}"] = (3 * hidden, isz)
-            spec[f"{prefix}.weight_hh_l{l}{sfx}"] = (3 * hidden, hidden)
-            spec[f"{prefix}.bias_ih_l{l}{sfx}"] = (3 * hidden,)
-            spec[f"{prefix}.bias_hh_l{l}{sfx}"] = (3 * hidden,)
+            spec[f"{prefix}.weight_ih_l{l}{sfx}"] = (gates * hidden, isz)
+            spec[f"{prefix}.weight_hh_l{l}{sfx}"] = (gates * hidden, hidden)
+            spec[f"{prefix}.bias_ih_l{l}{sfx}"] = (gates * hidden,)
+            spec[f"{prefix}.bias_hh_l{l}{sfx}"] = (gates * hidden,)
 
 
 def crnn_cnn_out(input_shape, channels):
@@ -138,7 +140,7 @@ def param_spec(cfg: HeadConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             _bn(s, f"model.cnn.{4*i+1}", c)
             cin = c
         C, H, W = crnn_cnn_out((T, F), cfg.crnn_cnn_channels)
-        _gru(s, "model.rnn", C * H, L, nb)
+        _gru(s, "model.rnn", C * H, L, nb, gates=4 if cfg.crnn_rnn_type == "lstm" else 3)
         _lin(s, "model.fc", E, 2 * L)
     elif mt == "gru":                     # architectures.py:129-145
         _gru(s, "model.gru", F, L, nb)
@@ -209,7 +211,8 @@ def head_macs(cfg: HeadConfig) -> int:
         for l in range(nb):
             isz = I if l == 0 else 2 * L
             steps_rev = w if l < nb - 1 else 1
-            m += w * 3 * L * (isz + L) + steps_rev * 3 * L * (isz + L)
+            ng = 4 if cfg.crnn_rnn_type == "lstm" else 3
+            m += w * ng * L * (isz + L) + steps_rev * ng * L * (isz + L)
         m += 2 * L * E
     elif mt == "gru":
         for l in range(nb):

@@ -108,6 +108,8 @@ struct GruArgs {
     int B, T, H, reverse, steps;
 };
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
+// LSTM recurrence for one direction, same arguments (xg is [B][T][4H], gate order i, f, g, o)
+hipError_t launch_lstm(const GruArgs& a, hipStream_t s);
 
 // Tail of every head in ONE launch: emb = x We^T + be  (the head's last Linear, written to `emb`),
 // hid = act(emb W0^T + b0), logit = hid . w3 + b3, prob = sigmoid(logit) when `probs` is set

@@ -1003,6 +1003,196 @@ __global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ LSTM recurrence
+// nn.LSTM cell (PyTorch gate order i, f, g, o in the 4H rows of W_ih / W_hh): with xg = x W_ih^T + b_ih precomputed,
+//   i, f, o = sigmoid(xg + h W_hh^T + b_hh), g = tanh(.), c' = f c + i g, h' = o tanh(c')
+// (CRNNModel's default backend: nanowakeword/modules/architectures.py:247-254, model.py:214).  Same argument block as the
+// GRU (xg is [B][T][4H]); same "reverse direction of the last layer runs one step" shortcut in the plan.
+//
+// Generic kernel (any H % 4 == 0, H <= 512): 32 clips per workgroup, wave w owns hidden units [32w, 32w+32), W_hh
+// streamed from L2 every step, four 32x32 accumulators on v_mfma_f32_32x32x2_f32; h and c stay in registers in the
+// C layout, h also in LDS as the next step's A operand.
+__global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hs = reinterpret_cast<float*>(smem_raw);           // [32][H+4]
+    const int H = a.H, ldh = H + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b0 = blockIdx.x * 32;
+    const int j = wave * 32 + i;
+    const bool jok = j < H;
+    const int jc = jok ? j : H - 1;
+    for (int idx = threadIdx.x; idx < 32 * ldh; idx += blockDim.x) hs[idx] = 0.0f;
+    float hprev[16], cprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hprev[r] = 0.0f; cprev[r] = 0.0f; }
+    float bh[4];
+    const float* wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bh[q] = a.b_hh[q * H + jc];
+        wq[q] = a.w_hh + (size_t)(q * H + jc) * H + 4 * hh;
+    }
+    const float* arow = hs + (size_t)i * ldh + 4 * hh;
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        float xq[4][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[q][r] = 0.0f;
+            if (b < a.B && jok) {
+                const float* xg = a.xg + ((size_t)b * a.T + t) * 4 * H;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xq[q][r] = xg[q * H + j];
+            }
+        }
+        if (step > 0) {
+            for (int k = 0; k < H; k += 8) {
+                float4 av = make_float4(0, 0, 0, 0), bw[4];
+                const bool ok = k + 4 * hh + 4 <= H;
+                if (ok) av = *reinterpret_cast<const float4*>(arow + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bw[q] = ok ? *reinterpret_cast<const float4*>(wq[q] + k) : make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw[q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw[q].w, acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int b = b0 + c;
+            float hn = 0.0f, cn = 0.0f;
+            if (b < a.B && jok) {
+                const float ig = 1.0f / (1.0f + expf(-(xq[0][r] + acc[0][r] + bh[0])));
+                const float fg = 1.0f / (1.0f + expf(-(xq[1][r] + acc[1][r] + bh[1])));
+                const float gg = tanhf(xq[2][r] + acc[2][r] + bh[2]);
+                const float og = 1.0f / (1.0f + expf(-(xq[3][r] + acc[3][r] + bh[3])));
+                cn = fg * cprev[r] + ig * gg;
+                hn = og * tanhf(cn);
+                if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+            }
+            hprev[r] = hn; cprev[r] = cn;
+            if (jok) hs[(size_t)c * ldh + j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// Register-resident variant for H in {32, 64, 128}: 16 clips per workgroup, wave w owns the 16 hidden units
+// [16w, 16w+16) of all four gates on v_mfma_f32_16x16x4_f32; its W_hh slices (4 gates x H/4 contiguous floats per lane)
+// are loaded once and stay in 4*H/4 VGPRs for every step (H = 128: 128 registers, eight waves = two per SIMD).
+template <int H>
+__global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
+    constexpr int KS = H / 4, LDH = H + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hs = reinterpret_cast<float*>(smem_raw);           // [16][H+4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int j = 16 * wave + n;
+    for (int idx = threadIdx.x; idx < 16 * LDH; idx += blockDim.x) hs[idx] = 0.0f;
+    float wreg[4][KS], bh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4* src = reinterpret_cast<const float4*>(a.w_hh + (size_t)(q * H + j) * H + g * KS);
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4) {
+            const float4 v = src[s4];
+            wreg[q][4 * s4] = v.x; wreg[q][4 * s4 + 1] = v.y; wreg[q][4 * s4 + 2] = v.z; wreg[q][4 * s4 + 3] = v.w;
+        }
+        bh[q] = a.b_hh[q * H + j];
+    }
+    float hprev[4], cprev[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { hprev[r] = 0.0f; cprev[r] = 0.0f; }
+    const float* arow = hs + n * LDH + g * KS;
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float xq[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 4 * H + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[q][r] = xg[q * H];
+        }
+        if (step > 0) {
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + 4 * s4);
+                const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wreg[q][4 * s4 + e], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * g + r, b = b0 + c;
+            float hn = 0.0f, cn = 0.0f;
+            if (b < a.B) {
+                const float ig = 1.0f / (1.0f + expf(-(xq[0][r] + acc[0][r] + bh[0])));
+                const float fg = 1.0f / (1.0f + expf(-(xq[1][r] + acc[1][r] + bh[1])));
+                const float gg = tanhf(xq[2][r] + acc[2][r] + bh[2]);
+                const float og = 1.0f / (1.0f + expf(-(xq[3][r] + acc[3][r] + bh[3])));
+                cn = fg * cprev[r] + ig * gg;
+                hn = og * tanhf(cn);
+                if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+            }
+            hprev[r] = hn; cprev[r] = cn;
+            hs[c * LDH + j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
+    if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
+    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
+        const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
+        const dim3 grid((a.B + 15) / 16);
+        switch (a.H) {
+            case 32: hipLaunchKernelGGL(lstm16_kernel<32>, grid, dim3(128), lds16, s, a); break;
+            case 64: hipLaunchKernelGGL(lstm16_kernel<64>, grid, dim3(256), lds16, s, a); break;
+            default: hipLaunchKernelGGL(lstm16_kernel<128>, grid, dim3(512), lds16, s, a); break;
+        }
+        return hipGetLastError();
+    }
+    const int waves = (a.H + 31) / 32;
+    const size_t lds = (size_t)32 * (a.H + 4) * sizeof(float);
+    {
+        hipError_t ea = nww_allow_lds(reinterpret_cast<const void*>(lstm_kernel), lds);
+        if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL(lstm_kernel, dim3((a.B + 31) / 32), dim3(waves * 64), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();

@@ -135,13 +135,13 @@ struct SpecBuilder {
     void bn(const std::string& p, int c) {
         add(p + ".weight", {c}); add(p + ".bias", {c}); add(p + ".running_mean", {c}); add(p + ".running_var", {c});
     }
-    void gru(const std::string& p, int in, int H, int layers) {
+    void gru(const std::string& p, int in, int H, int layers, int G = 3) {   // G = 3: nn.GRU, 4: nn.LSTM
         for (int l = 0; l < layers; ++l) {
             const int isz = l == 0 ? in : 2 * H;
             for (const char* sfx : {"", "_reverse"}) {
                 const std::string s = "_l" + std::to_string(l) + sfx;
-                add(p + ".weight_ih" + s, {3 * H, isz}); add(p + ".weight_hh" + s, {3 * H, H});
-                add(p + ".bias_ih" + s, {3 * H}); add(p + ".bias_hh" + s, {3 * H});
+                add(p + ".weight_ih" + s, {G * H, isz}); add(p + ".weight_hh" + s, {G * H, H});
+                add(p + ".bias_ih" + s, {G * H}); add(p + ".bias_hh" + s, {G * H});
             }
         }
     }
@@ -182,7 +182,7 @@ void build_spec(nww_handle* h) {
                 cin = co;
             }
             int C, H, W; crnn_out(c, &C, &H, &W);
-            s.gru("model.rnn", C * H, L, nb); s.lin("model.fc", E, 2 * L);
+            s.gru("model.rnn", C * H, L, nb, c.crnn_rnn_lstm ? 4 : 3); s.lin("model.fc", E, 2 * L);
             break;
         }
         case NWW_HEAD_GRU:
@@ -500,10 +500,11 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
     return true;
 }
 
-// nn.GRU(bidirectional) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers xg_id, seqA, seqB.
+// nn.GRU / nn.LSTM (bidirectional; G = 3 / 4 gates) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers
+// xg_id, seqA, seqB.
 void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int I, int H, int layers, int xg_id,
-                    int seqA, int seqB, int last_id) {
-    p.need(xg_id, (size_t)T * 3 * H);
+                    int seqA, int seqB, int last_id, int G = 3) {
+    p.need(xg_id, (size_t)T * G * H);
     p.need(last_id, (size_t)2 * H);
     int cur_in = in_id, cur_I = I;
     for (int l = 0; l < layers; ++l) {
@@ -523,23 +524,23 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                 p.add("gemm:" + prefix + ".ih" + sfx + "(last frame)", [=](Run& r) {
                     GemmArgs g;
                     g.A = src(r, in_buf) + (size_t)(T - 1) * Iin; g.lda = T * Iin; g.W = wih;
-                    g.C = r.buf[xg_id] + (size_t)(T - 1) * 3 * H; g.ldc = T * 3 * H;
-                    g.M = r.B; g.N = 3 * H; g.K = Iin; g.bias = bih; g.alpha = nullptr; g.beta = nullptr; g.act = ACT_NONE;
+                    g.C = r.buf[xg_id] + (size_t)(T - 1) * G * H; g.ldc = T * G * H;
+                    g.M = r.B; g.N = G * H; g.K = Iin; g.bias = bih; g.alpha = nullptr; g.beta = nullptr; g.act = ACT_NONE;
                     g.res = nullptr; g.ldres = 0; g.rscale = 1.f;
                     return launch_gemm(g, r.stream);
                 });
             } else {
-                add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, 3 * H, cur_I, wih, bih, ACT_NONE);
+                add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
             }
             const int in_T = T;
-            p.add("gru:" + prefix + sfx, [=](Run& r) {
+            p.add((G == 4 ? "lstm:" : "gru:") + prefix + sfx, [=](Run& r) {
                 GruArgs a;
                 a.xg = r.buf[xg_id]; a.w_hh = whh; a.b_hh = bhh;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
                 a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H; a.col_off = dir ? H : 0;
                 a.B = r.B; a.T = in_T; a.H = H; a.reverse = dir;
                 a.steps = (last && dir) ? 1 : in_T;          // reverse half of rnn_out[:, -1] is its first step
-                return launch_gru(a, r.stream);
+                return G == 4 ? launch_lstm(a, r.stream) : launch_gru(a, r.stream);
             });
         }
         cur_in = seq_out; cur_I = 2 * H;
@@ -719,7 +720,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int seq = cur ^ 1, C = cin, Hc = hh, Wc = ww;
             p.need(seq, (size_t)C * Hc * Wc);
             p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
-            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, cur, 3, 4);
+            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, cur, 3, 4, c.crnn_rnn_lstm ? 4 : 3);
             set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }

@@ -63,10 +63,11 @@ def infer_head_config(sd: Mapping, input_shape: Optional[Tuple[int, int]] = None
         if input_shape is None:
             raise ValueError("crnn: pass input_shape=(T, F)")
         L = shp("model.rnn.weight_hh_l0")[1]
+        gates = shp("model.rnn.weight_hh_l0")[0] // L          # nn.GRU stacks 3 gates, nn.LSTM 4 (architectures.py:238-254)
+        if gates not in (3, 4) or shp("model.rnn.weight_hh_l0")[0] != gates * L:
+            raise ValueError(f"crnn: unexpected recurrent weight shape {shp('model.rnn.weight_hh_l0')}")
         cfg = HeadConfig("crnn", input_shape, layer_dim=L, n_blocks=n_indexed(r"model\.rnn\.weight_hh_l(\d+)$"),
-                         crnn_cnn_channels=chans, crnn_rnn_type="gru", **kw)
-        if shp("model.rnn.weight_hh_l0")[0] != 3 * L:
-            raise ValueError("crnn with an LSTM backend is out of scope (only crnn_rnn_type='gru')")
+                         crnn_cnn_channels=chans, crnn_rnn_type="lstm" if gates == 4 else "gru", **kw)
     elif "model.gru.weight_hh_l0" in keys:
         L = shp("model.gru.weight_hh_l0")[1]
         F = shp("model.gru.weight_ih_l0")[1]
@@ -139,6 +140,17 @@ def _unpack_onnx_gru(sd, prefix, layer, W, R, B, hidden):
         sd[f"{prefix}.bias_hh_l{layer}{sfx}"] = np.ascontiguousarray(B[d][3 * H:][perm], np.float32)
 
 
+def _unpack_onnx_lstm(sd, prefix, layer, W, R, B, hidden):
+    """ONNX LSTM packs gates [i, o, f, c] per direction; nn.LSTM stores [i, f, g, o] (torch symbolic for aten::lstm)."""
+    H = hidden
+    perm = np.r_[0:H, 2 * H:3 * H, 3 * H:4 * H, H:2 * H]
+    for d, sfx in enumerate(("", "_reverse")):
+        sd[f"{prefix}.weight_ih_l{layer}{sfx}"] = np.ascontiguousarray(W[d][perm], np.float32)
+        sd[f"{prefix}.weight_hh_l{layer}{sfx}"] = np.ascontiguousarray(R[d][perm], np.float32)
+        sd[f"{prefix}.bias_ih_l{layer}{sfx}"] = np.ascontiguousarray(B[d][:4 * H][perm], np.float32)
+        sd[f"{prefix}.bias_hh_l{layer}{sfx}"] = np.ascontiguousarray(B[d][4 * H:][perm], np.float32)
+
+
 def state_dict_from_onnx(path_or_bytes):
     """Recover (HeadConfig, state_dict, info) from a reference-exported ONNX model.
 
@@ -169,8 +181,9 @@ def state_dict_from_onnx(path_or_bytes):
 
     convs = [n for n in g.nodes if n.op_type == "Conv" and anon(n.inputs[1])]
     grus = [n for n in g.nodes if n.op_type == "GRU"]
-    if any(n.op_type == "LSTM" for n in g.nodes):
-        raise NotImplementedError("LSTM backends (crnn_rnn_type='lstm', model_type='lstm') are out of scope")
+    lstms = [n for n in g.nodes if n.op_type == "LSTM"]
+    if lstms and not any(n.op_type == "Conv" and anon(n.inputs[1]) for n in g.nodes):
+        raise NotImplementedError("model_type='lstm' (LSTMModel) is out of scope; the CRNN's LSTM backend is supported")
 
     def folded(node, wkey, bias_key, bn_prefix):
         W = np.asarray(g.initializers[node.inputs[1]], np.float32)
@@ -189,6 +202,14 @@ def state_dict_from_onnx(path_or_bytes):
             H = int(n.attrs["hidden_size"])
             W, R, B = (np.asarray(g.initializers[t]) for t in n.inputs[1:4])
             _unpack_onnx_gru(sd, prefix, l, W, R, B, H)
+
+    def lstm_layers(prefix):
+        for l, n in enumerate(lstms):
+            if n.attrs.get("direction") != b"bidirectional":
+                raise ValueError(f"LSTM node '{n.name}': expected the bidirectional nn.LSTM export")
+            H = int(n.attrs["hidden_size"])
+            W, R, B = (np.asarray(g.initializers[t]) for t in n.inputs[1:4])
+            _unpack_onnx_lstm(sd, prefix, l, W, R, B, H)
 
     mode, clip_samples, fe = "features", 16000, None
     if "model.mel_spec.real_basis" in named:                                        # E2E_MelSpectrogram_CNN
@@ -221,10 +242,10 @@ def state_dict_from_onnx(path_or_bytes):
             for i, n in enumerate(convs):
                 p = f"model.conformer_blocks.{i}.conv_module"
                 folded(n, f"{p}.depthwise_conv.weight", f"{p}.depthwise_conv.bias", f"{p}.batch_norm")
-        elif grus and convs:                                                        # CRNN (GRU backend)
+        elif (grus or lstms) and convs:                                             # CRNN (GRU or LSTM backend)
             for i, n in enumerate(convs):
                 folded(n, f"model.cnn.{4*i}.weight", f"model.cnn.{4*i}.bias", f"model.cnn.{4*i+1}")
-            gru_layers("model.rnn")
+            gru_layers("model.rnn") if grus else lstm_layers("model.rnn")
         elif grus:                                                                  # GRU
             gru_layers("model.gru")
 

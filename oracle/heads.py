@@ -108,8 +108,16 @@ def gru_cell(x_gates, h, w_hh, b_hh, H):
     return (1 - z) * n + z * h
 
 
-def bigru_last(x, sd, prefix, n_layers, H):
-    """nn.GRU(batch_first, bidirectional)(x)[0][:, -1, :].
+def lstm_cell(xg, h, c, w_hh, b_hh, H):
+    """torch.nn.LSTM cell, gate order i, f, g, o (CRNNModel's default backend, architectures.py:247-254)."""
+    g = xg + h @ w_hh.T + b_hh
+    i, f, gg, o = sigmoid(g[:, :H]), sigmoid(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), sigmoid(g[:, 3 * H:])
+    c = f * c + i * gg
+    return (o * np.tanh(c)).astype(xg.dtype), c.astype(xg.dtype)
+
+
+def bigru_last(x, sd, prefix, n_layers, H, lstm=False):
+    """nn.GRU / nn.LSTM (batch_first, bidirectional)(x)[0][:, -1, :].
 
     The reference takes ``rnn_out[:, -1, :]`` (architectures.py:142,282): the forward
     direction after all T steps concatenated with the reverse direction's output at
@@ -125,10 +133,14 @@ def bigru_last(x, sd, prefix, n_layers, H):
             b_ih = sd[f"{prefix}.bias_ih_l{l}{sfx}"]; b_hh = sd[f"{prefix}.bias_hh_l{l}{sfx}"]
             xg = inp @ w_ih.T + b_ih                          # [B,T,3H]
             h = np.zeros((B, H), x.dtype)
+            c = np.zeros((B, H), x.dtype)
             seq = np.zeros((B, T, H), x.dtype)
             order = range(T) if sfx == "" else range(T - 1, -1, -1)
             for t in order:
-                h = gru_cell(xg[:, t], h, w_hh, b_hh, H).astype(x.dtype)
+                if lstm:
+                    h, c = lstm_cell(xg[:, t], h, c, w_hh, b_hh, H)
+                else:
+                    h = gru_cell(xg[:, t], h, w_hh, b_hh, H).astype(x.dtype)
                 seq[:, t] = h
                 if last and sfx == "_reverse":
                     break                                      # only t = T-1 is consumed
@@ -178,7 +190,7 @@ def net_cnn(x, sd, cfg):
 
 
 def net_crnn(x, sd, cfg):
-    """CRNNModel with rnn_type='gru' (architectures.py:209-287)."""
+    """CRNNModel (architectures.py:209-287), rnn_type 'gru' or the default 'lstm'."""
     a = cfg.activation
     h = x[:, None]
     for i in range(len(cfg.crnn_cnn_channels)):
@@ -186,7 +198,7 @@ def net_crnn(x, sd, cfg):
         h = maxpool2(act(batch_norm(h, sd, f"model.cnn.{4*i+1}"), a))
     B, C, H, W = h.shape
     seq = h.reshape(B, C * H, W).transpose(0, 2, 1)              # sequence over W (:272-276)
-    last = bigru_last(np.ascontiguousarray(seq), sd, "model.rnn", cfg.n_blocks, cfg.layer_dim)
+    last = bigru_last(np.ascontiguousarray(seq), sd, "model.rnn", cfg.n_blocks, cfg.layer_dim, lstm=cfg.crnn_rnn_type == "lstm")
     return linear(last, sd["model.fc.weight"], sd["model.fc.bias"])
 
 

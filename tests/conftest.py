@@ -64,6 +64,20 @@ def predict_trace():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def golden_heads_r02():
+    """round-2 reference goldens (tools/make_goldens.py::make_round2_goldens): LSTM CRNN, other conv stacks, E2E at 1.5 / 2 s"""
+    z = np.load(os.path.join(GOLDEN, "heads_r02.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    meta = json.loads(str(d.pop("meta_json")))
+    return d, meta
+
+
+def head_case_names_r02():
+    z = np.load(os.path.join(GOLDEN, "heads_r02.npz"), allow_pickle=False)
+    return sorted(json.loads(str(z["meta_json"])).keys())
+
+
 def head_case_names():
     z = np.load(os.path.join(GOLDEN, "heads.npz"), allow_pickle=False)
     return sorted(json.loads(str(z["meta_json"])).keys())

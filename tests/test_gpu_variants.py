@@ -1,0 +1,195 @@
+"""GPU parity for everything that is not the default path of a default-config head (run with -m gpu):
+round-2 reference goldens (CRNN with the reference's default LSTM backend, other conv stacks and recurrent widths,
+the native E2E composite at 1.5 s / 2 s clips), every fallback / variant kernel behind an environment knob, the C4
+streaming configuration at full size, and batch invariance at the per-GPU sizes of BASELINE configs 3 and 5."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import head_case_names_r02
+from nanowakeword_amd.config import FrontendConfig, HeadConfig
+from nanowakeword_amd.synth import synth_features, synth_pcm, synth_state_dict
+from parity import logit_bounds
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def HipModel():
+    from nanowakeword_amd.session import HipModel
+    return HipModel
+
+
+@pytest.mark.parametrize("name", head_case_names_r02())
+def test_round2_heads_vs_reference(HipModel, golden_heads_r02, golden_frontend, name):
+    d, meta = golden_heads_r02
+    g = golden_frontend
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    n_mels = 40 if cfg.input_shape == (98, 40) else 64
+    fe = FrontendConfig(n_mels=n_mels, center=n_mels == 64)
+    m = HipModel(cfg, fe, state_dict=sd, window=g["window"], mel_fb=g["fb64"] if n_mels == 64 else g["fb40"])
+    if cfg.model_type == "e2e_dnn":
+        # clip length 24 000 / 32 000: general export-form average pool (a17), through the PCM entry point
+        pcm = d[f"{name}/pcm"]
+        lp, pp = m.forward_pcm(pcm)
+        rp = d[f"{name}/logits_pcm"].ravel()
+        lm32 = oracle.frontend_logmel(pcm, g["window"], g["fb64"])
+        lm64 = oracle.frontend_logmel(pcm, g["window"], g["fb64"], dtype=np.float64).astype(np.float32)
+        bound = logit_bounds(["noise0", "noise1", "speechlike0", "speechlike1", "loud0", "zeros0"], rp,
+                             oracle.model_forward(lm32, sd, cfg).ravel(), oracle.model_forward(lm64, sd, cfg).ravel())
+        assert np.all(np.abs(lp - rp) <= bound), (name, np.abs(lp - rp), bound)
+        assert np.all(np.abs(pp - d[f"{name}/probs_pcm_export"].ravel()) <= bound)
+        m.close()
+        return
+    feats = synth_features(4, cfg.input_shape)
+    logits, probs, emb = m.forward_features(feats, return_embedding=True)
+    ref = d[f"{name}/logits_feat"].ravel()
+    assert np.abs(logits - ref).max() <= 1e-4, (name, np.abs(logits - ref).max())
+    e_ref = d[f"{name}/emb_feat"]
+    assert np.abs(emb - e_ref).max() <= 1e-4 * max(1.0, np.abs(e_ref).max())
+    for B in (1, 17, 50):                                   # ragged batches: partial 16- / 32-clip recurrent workgroups
+        fx = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(fx)
+        assert np.abs(lg - oracle.model_forward(fx, sd, cfg).ravel()).max() <= 1e-4, (name, B)
+    if f"{name}/logits_pcm" in d:
+        rp = d[f"{name}/logits_pcm"].ravel()
+        lp, _ = m.forward_pcm(g["pcm"])
+        lm32 = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"]).transpose(0, 2, 1)
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"], dtype=np.float64).astype(np.float32).transpose(0, 2, 1)
+        bound = logit_bounds(g["names"], rp, oracle.model_forward(np.ascontiguousarray(lm32), sd, cfg).ravel(),
+                             oracle.model_forward(np.ascontiguousarray(lm64), sd, cfg).ravel())
+        assert np.all(np.abs(lp - rp) <= bound), (name, np.abs(lp - rp), bound)
+    m.close()
+
+
+# Every knob is read once per process, hence one subprocess per setting.  Each runs the heads whose plan the knob changes
+# against the oracle (features) and, for the frontend knobs, against the reference goldens.
+_KNOB_SCRIPT = r'''
+import json, os, sys
+import numpy as np, oracle
+from nanowakeword_amd.config import FrontendConfig, HeadConfig
+from nanowakeword_amd.session import HipModel
+from nanowakeword_amd.synth import synth_features, synth_state_dict
+heads, want_in_plan, not_in_plan, check_fe = json.loads(sys.argv[1])
+worst = 0.0
+for spec in heads:
+    cfg = HeadConfig(**spec)
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    plan = m.describe_plan()
+    for w in want_in_plan:
+        assert w in plan, (w, plan)
+    for w in not_in_plan:
+        assert w not in plan, (w, plan)
+    for B in (3, 40):
+        x = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(x)
+        worst = max(worst, float(np.abs(lg - oracle.model_forward(x, sd, cfg).ravel()).max()))
+    m.close()
+if check_fe:
+    sys.path.insert(0, os.path.join(os.environ["NWW_ROOT"], "tests"))
+    from parity import assert_frontend_close
+    g = dict(np.load(os.path.join(os.environ["NWW_ROOT"], "tests", "golden", "frontend.npz")))
+    for n_mels, center, mk, dk, fk in ((64, True, "mel64", "db64", "fb64"), (40, False, "mel40", "db40", "fb40")):
+        cfg = HeadConfig("dnn", (101, 64) if center else (98, 40))
+        m = HipModel(cfg, FrontendConfig(n_mels=n_mels, center=center), state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=g[fk])
+        db, mel = m.frontend(g["pcm"], return_power=True)
+        assert_frontend_close(mel, db, g[mk], g[dk], "knob")
+        lg, _ = m.forward_pcm(g["pcm"])                     # frames-major output path of the same kernel
+        lm = np.ascontiguousarray(oracle.frontend_logmel(g["pcm"], g["window"], g[fk], center=center).transpose(0, 2, 1))
+        assert np.abs(lg - oracle.model_forward(lm, synth_state_dict(cfg), cfg).ravel())[:4].max() <= 1e-4
+        m.close()
+print("WORST", worst)
+assert worst <= 1e-4, worst
+'''
+
+_CNN = dict(model_type="cnn", input_shape=(101, 64))
+_CRNN = dict(model_type="crnn", input_shape=(101, 64))
+_CRNN4 = dict(model_type="crnn", input_shape=(32, 96), crnn_cnn_channels=[16, 32, 64, 64])
+_CRNN_LSTM = dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm")
+_E2E = dict(model_type="e2e_dnn", input_shape=(64, 101))
+_GRU = dict(model_type="gru", input_shape=(30, 64), layer_dim=64)
+_BC = dict(model_type="bcresnet", input_shape=(32, 40), embedding_dim=16)
+
+
+@pytest.mark.parametrize("env,heads,want,unwanted,check_fe", [
+    ({"NWW_TRUNK": "0"}, [_CNN, _CRNN, _E2E], [], ["trunk"], False),                    # unfused conv1 / conv2 kernels
+    ({"NWW_CONV_MFMA": "0"}, [_CRNN, _CRNN4, _E2E, _BC], [], ["conv3x3_mfma", "conv1_mfma"], False),   # VALU 3x3 convs
+    ({"NWW_GRU16": "0"}, [_CRNN, _GRU, _CRNN_LSTM], [], [], False),                     # streaming recurrent kernels
+    ({"NWW_E2E_FUSE_POOL": "0"}, [_E2E], ["avgpool"], [], False),                       # stand-alone export-form pool
+    ({"NWW_TRUNK_X3": "0"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),             # float32-MFMA fused trunk
+    ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
+    ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
+    ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel
+    ({"NWW_TRUNK_STRIPS": "3"}, [_CNN], ["trunk"], [], False),                          # three row strips
+    ({"NWW_TAIL": "0"}, [_CNN, _GRU], [], ["tail:"], False),                            # separate GEMMs + sigmoid instead of the fused tail
+], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else None)
+def test_knob_variants_in_subprocess(env, heads, want, unwanted, check_fe):
+    import json
+    e = dict(os.environ, NWW_ROOT=ROOT, PYTHONPATH=os.pathsep.join([ROOT] + sys.path), **env)
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, json.dumps([heads, want, unwanted, check_fe])], env=e,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "WORST" in r.stdout
+
+
+def test_c4_streaming_full_size(HipModel, golden_frontend):
+    """BASELINE config 4 at full size: 1024 lock-step streams x 125 hops of 80 ms (10 s) on the CRNN-GRU head.
+    Properties over all streams (the oracle cannot follow 128 000 window scores): duplicated streams score
+    identically whatever their slot, scores are finite probabilities, nothing fires before the window is full; and
+    three hops of eight streams are checked against the oracle on the exact 1 s windows."""
+    from nanowakeword_amd.interpreter import StreamBatch
+    g = golden_frontend
+    cfg = HeadConfig("crnn", (101, 64))
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    S, hop, n_hops = 1024, 1280, 125
+    base = np.stack([synth_pcm("speechlike" if s % 2 else "noise", 1, hop * n_hops, seed=100 + s)[0] for s in range(64)])
+    idx = np.random.default_rng(4).integers(0, 64, S)
+    idx[:64] = np.arange(64)
+    streams = base[idx]                                       # every distinct stream appears in several slots
+    sb = StreamBatch(m, S, 16000, hop)
+    raw = np.zeros((n_hops, S), np.float32)
+    for i in range(n_hops):
+        sb.push(np.ascontiguousarray(streams[:, i * hop:(i + 1) * hop]))
+        raw[i] = sb.raw_scores
+    assert np.isfinite(raw).all() and (raw >= 0).all() and (raw <= 1).all()
+    assert not raw[:12].any() and raw[12:].all()              # 12.5 hops fill the 1 s window
+    for s in range(64, S):
+        assert np.array_equal(raw[:, s], raw[:, idx[s]]), s   # slot independence, bit for bit
+    for i in (12, 60, 124):                                   # first full window, mid-stream, last hop
+        end = (i + 1) * hop
+        win = streams[:8, end - 16000:end]
+        lm = oracle.frontend_logmel(win, g["window"], g["fb64"]).transpose(0, 2, 1)
+        want = oracle.sigmoid(oracle.model_forward(np.ascontiguousarray(lm), sd, cfg)).ravel()
+        assert np.abs(raw[i, :8] - want).max() <= 1e-4, (i, np.abs(raw[i, :8] - want).max())
+    sb.close(); m.close()
+
+
+@pytest.mark.parametrize("head,B", [("bcresnet", 8192), ("conformer", 2048)])
+def test_batch_invariance_at_baseline_sizes(HipModel, golden_frontend, head, B):
+    """BASELINE configs 3 (BcResNet, 65 536 / 8 GPUs) and 5 (Conformer, 16 384 / 8 GPUs) at their per-GPU batch:
+    a clip's logit does not depend on the batch size or its position (bit-exact), and the first clips equal the
+    small batch that IS checked against the oracle."""
+    g = golden_frontend
+    cfg = HeadConfig(head, (101, 64))
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    x = synth_pcm("noise", B, 16000, seed=7)
+    lg, _ = m.forward_pcm(x)
+    assert np.isfinite(lg).all()
+    l16, _ = m.forward_pcm(x[:16])
+    assert np.array_equal(lg[:16], l16)
+    perm = np.random.default_rng(1).permutation(B)
+    lp, _ = m.forward_pcm(np.ascontiguousarray(x[perm]))
+    assert np.array_equal(lp, lg[perm])
+    lm = oracle.frontend_logmel(x[:6], g["window"], g["fb64"]).transpose(0, 2, 1)
+    lo = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+    assert np.abs(lg[:6] - lo).max() <= 1e-4
+    m.close()

@@ -19,7 +19,7 @@ from nanowakeword_amd.synth import synth_features, synth_state_dict
 from nanowakeword_amd.weights import state_dict_from_onnx
 
 ONNX_DIR = os.path.join(GOLDEN, "onnx")
-HEADS = ["dnn", "cnn", "crnn", "gru", "bcresnet", "conformer", "e2e_dnn"]
+HEADS = ["dnn", "cnn", "crnn", "crnn_lstm", "gru", "bcresnet", "conformer", "e2e_dnn"]   # crnn_lstm = the reference's default CRNN backend
 
 
 @pytest.fixture(scope="module")
@@ -93,6 +93,21 @@ def test_gru_gate_unpacking_matches_original_layout(expected):
             for t in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
                 k = f"model.gru.{t}_l{l}{sfx}"
                 assert np.array_equal(sd[k], orig[k]), k
+
+
+def test_lstm_gate_unpacking_matches_original_layout(expected):
+    """ONNX packs LSTM gates [i, o, f, c]; the graph walk must give back nn.LSTM's [i, f, g, o] rows bit for bit."""
+    _, meta = expected
+    cfg = HeadConfig(**{**meta["crnn_lstm"], "input_shape": tuple(meta["crnn_lstm"]["input_shape"])})
+    assert cfg.crnn_rnn_type == "lstm"
+    got, sd, _ = state_dict_from_onnx(os.path.join(ONNX_DIR, "crnn_lstm.onnx"))
+    assert got.crnn_rnn_type == "lstm" and got.layer_dim == 16 and got.n_blocks == 2
+    orig = synth_state_dict(cfg)
+    for l in range(cfg.n_blocks):
+        for sfx in ("", "_reverse"):
+            for t in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                k = f"model.rnn.{t}_l{l}{sfx}"
+                assert sd[k].shape[0] == 4 * 16 and np.array_equal(sd[k], orig[k]), k
 
 
 @pytest.mark.gpu

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from nanowakeword_amd.config import HeadConfig, param_spec
 from nanowakeword_amd.synth import synth_features, synth_state_dict, state_dict_checksum
-from conftest import head_case_names
+from conftest import head_case_names, head_case_names_r02
 from parity import assert_frontend_close, logit_bounds, DB_ATOL
 
 LOGIT_ATOL = 2e-5   # oracle vs reference on identical float32 features
@@ -109,3 +109,42 @@ def test_head_against_reference(golden_heads, golden_frontend, name):
             assert np.all(np.abs(oracle.sigmoid(lp).reshape(-1, 1, 1) - pe) <= bound.reshape(-1, 1, 1))
             # export pool patch == adaptive pool at this shape
             assert np.abs(rp - d[f"{name}/logits_pcm_adaptivepool"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", head_case_names_r02())
+def test_round2_cases_against_reference(golden_heads_r02, golden_frontend, name):
+    """CRNN with the reference's default LSTM backend, other conv stacks / recurrent widths, and the native E2E
+    composite at 1.5 s / 2 s clips where the export-form average pool differs from the adaptive pool."""
+    d, meta = golden_heads_r02
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    assert state_dict_checksum(sd) == str(d[f"{name}/sd_checksum"])
+    g = golden_frontend
+    if cfg.model_type == "e2e_dnn":
+        pcm = d[f"{name}/pcm"]
+        lm = oracle.frontend_logmel(pcm, g["window"], g["fb64"])
+        assert lm.shape[1:] == cfg.input_shape
+        lp = oracle.model_forward(lm, sd, cfg).ravel()
+        rp = d[f"{name}/logits_pcm"].ravel()
+        lm64 = oracle.frontend_logmel(pcm, g["window"], g["fb64"], dtype=np.float64).astype(np.float32)
+        lx = oracle.model_forward(lm64, sd, cfg).ravel()
+        names = ["noise0", "noise1", "speechlike0", "speechlike1", "loud0", "zeros0"]
+        bound = logit_bounds(names, rp, lp, lx)
+        assert np.all(np.abs(lp - rp) <= bound), (np.abs(lp - rp), bound)
+        assert np.all(np.abs(oracle.sigmoid(lp) - d[f"{name}/probs_pcm_export"].ravel()) <= bound)
+        if cfg.input_shape[1] == 201:      # here the export pool is NOT the adaptive pool: the oracle must follow the export
+            assert np.abs(rp - d[f"{name}/logits_pcm_adaptivepool"].ravel()).max() > 1e-3
+        return
+    feats = synth_features(4, cfg.input_shape)
+    logits = oracle.model_forward(feats, sd, cfg)
+    assert np.abs(logits - d[f"{name}/logits_feat"]).max() <= LOGIT_ATOL
+    e_ref = d[f"{name}/emb_feat"]
+    assert np.abs(oracle.head_forward(feats, sd, cfg) - e_ref).max() <= 2e-5 * max(1.0, np.abs(e_ref).max())
+    if f"{name}/logits_pcm" in d:
+        lm = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"]).transpose(0, 2, 1)
+        lp = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg)
+        rp = d[f"{name}/logits_pcm"]
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"], dtype=np.float64).transpose(0, 2, 1)
+        lx = oracle.model_forward(np.ascontiguousarray(lm64, dtype=np.float32), sd, cfg)
+        bound = logit_bounds(g["names"], rp, lp, lx)
+        assert np.all(np.abs(lp - rp) <= bound), (np.abs(lp - rp).ravel(), bound.ravel())

@@ -288,6 +288,7 @@ def main():
     make_wire_fixtures(os.path.join(args.out, "wire_messages.json"))
     make_audio_features_traces(os.path.join(args.out, "audio_features_trace.json"))
     make_onnx_fixtures(os.path.join(args.out, "onnx"))
+    make_round2_goldens(args.out)
     print("done ->", args.out)
 
 
@@ -362,6 +363,93 @@ def make_predict_traces(path):
     print("predict_trace.json rows:", {k: (len(v["rows"]) if isinstance(v, dict) and "rows" in v else v)
                                        for k, v in traces.items()})
 
+
+
+def make_round2_goldens(out_dir):
+    """Round-2 additions (separate file so the round-1 fixtures stay byte-identical): CRNN with the reference's DEFAULT
+    recurrent backend (nn.LSTM, model.py:214), CRNN conv stacks other than [16, 32, 32], recurrent widths that take the
+    generic kernels, and the native E2E composite at clip lengths where the export-form average pool
+    (make_onnx_safe_adaptive_pool, _export/onnx.py:96-154) is NOT the adaptive pool."""
+    install_stubs()
+    torch.set_num_threads(1)
+    from nanowakeword.modules.model import Model
+    from nanowakeword._export import onnx as ref_onnx
+    from nanowakeword_amd.config import HeadConfig, param_spec
+    from nanowakeword_amd.synth import synth_pcm, synth_features, synth_state_dict, state_dict_checksum
+    fr = dict(np.load(os.path.join(out_dir, "frontend.npz"), allow_pickle=False))
+    db64 = fr["db64"]
+
+    def ref_model(cfg, sd_np, n_samples=16000):
+        conf = {"activation_function": cfg.activation, "embedding_dim": cfg.embedding_dim,
+                "crnn_cnn_channels": list(cfg.crnn_cnn_channels), "crnn_rnn_type": cfg.crnn_rnn_type,
+                "conformer_d_model": cfg.conformer_d_model, "conformer_n_head": cfg.conformer_n_head}
+        if cfg.model_type == "e2e_dnn":
+            m = Model(conf, "g", input_shape=(n_samples,), model_type="e2e_dnn", mode="e2e")
+        else:
+            m = Model(conf, "g", input_shape=cfg.input_shape, model_type=cfg.model_type, layer_dim=cfg.layer_dim, n_blocks=cfg.n_blocks)
+        ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items()
+                    if not k.endswith("num_batches_tracked") and not k.startswith("model.mel_spec")}
+        assert ref_keys == dict(param_spec(cfg)), set(ref_keys) ^ set(param_spec(cfg))
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+        assert not unexpected, unexpected
+        return m.eval()
+
+    cases = [
+        ("crnn_lstm_16x96", HeadConfig("crnn", (16, 96), crnn_rnn_type="lstm")),                      # the reference's default CRNN
+        ("crnn_lstm_101x64", HeadConfig("crnn", (101, 64), crnn_rnn_type="lstm")),
+        ("crnn_lstm_16x96_b2_h64_silu", HeadConfig("crnn", (16, 96), layer_dim=64, n_blocks=2, activation="silu", crnn_rnn_type="lstm")),
+        ("crnn_lstm_98x40_h48", HeadConfig("crnn", (98, 40), layer_dim=48, crnn_rnn_type="lstm")),    # generic LSTM kernel
+        ("crnn_gru_101x64_ch8_16", HeadConfig("crnn", (101, 64), crnn_cnn_channels=[8, 16])),
+        ("crnn_gru_16x96_ch16_32_64_64", HeadConfig("crnn", (16, 96), crnn_cnn_channels=[16, 32, 64, 64])),
+        ("crnn_gru_64x64_h48", HeadConfig("crnn", (64, 64), layer_dim=48)),                           # generic GRU kernel
+    ]
+    heads, meta = {}, {}
+    for name, cfg in cases:
+        sd = synth_state_dict(cfg)
+        m = ref_model(cfg, sd)
+        feats = synth_features(4, cfg.input_shape)
+        with torch.no_grad():
+            out = {"logits_feat": m(torch.from_numpy(feats)).numpy(), "emb_feat": m.model(torch.from_numpy(feats)).numpy()}
+            if cfg.input_shape == (101, 64):
+                out["logits_pcm"] = m(torch.from_numpy(np.ascontiguousarray(db64.transpose(0, 2, 1)))).numpy()
+        out["sd_checksum"] = np.array(state_dict_checksum(sd))
+        meta[name] = cfg.to_dict()
+        for k, v in out.items():
+            heads[f"{name}/{k}"] = v
+        print("r02", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+    # ---- E2E composite at 1.5 s and 2 s clips: frames 151 / 201 -> conv3 output (64,16,37) / (64,16,50): the export
+    # pool windows are (16,10)/(16,9) and (16,14)/(16,12) while AdaptiveAvgPool2d((1,4)) uses ragged windows
+    for n_samples in (24000, 32000):
+        frames = 1 + n_samples // 160
+        name = f"e2e_dnn_64x{frames}"
+        cfg = HeadConfig("e2e_dnn", (64, frames))
+        sd = synth_state_dict(cfg)
+        m = ref_model(cfg, sd, n_samples)
+        pcm = np.concatenate([synth_pcm("noise", 2, n_samples, seed=41), synth_pcm("speechlike", 2, n_samples, seed=42),
+                              synth_pcm("loud", 1, n_samples, seed=43), synth_pcm("zeros", 1, n_samples)])
+        ref_onnx.replace_mel_spectrogram(m)
+        xin = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+        with torch.no_grad():
+            logits_adaptive = m(xin).numpy()
+
+            class W(torch.nn.Module):
+                def __init__(s, mm):
+                    super().__init__(); s.trained_model = mm
+                def forward(s, x):
+                    return torch.sigmoid(s.trained_model(x)).view(-1, 1, 1)
+            w = W(m).eval()
+            ref_onnx.make_onnx_safe_adaptive_pool(w, xin[:1].unsqueeze(1))
+            probs_export = w(xin.unsqueeze(1)).numpy()
+            logits_export = m(xin).numpy()
+        heads[f"{name}/pcm"] = pcm
+        heads[f"{name}/logits_pcm"] = logits_export
+        heads[f"{name}/probs_pcm_export"] = probs_export
+        heads[f"{name}/logits_pcm_adaptivepool"] = logits_adaptive
+        heads[f"{name}/sd_checksum"] = np.array(state_dict_checksum(sd))
+        meta[name] = cfg.to_dict()
+        print("r02", name, "export-vs-adaptive max |dlogit|", float(np.abs(logits_export - logits_adaptive).max()))
+    heads["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out_dir, "heads_r02.npz"), **heads)
 
 
 def make_wire_fixtures(path):
@@ -468,6 +556,7 @@ def make_onnx_fixtures(outdir):
         ("bcresnet", HeadConfig("bcresnet", (16, 24), embedding_dim=16)),
         ("conformer", HeadConfig("conformer", (8, 12), n_blocks=2, embedding_dim=16, conformer_d_model=32, conformer_n_head=8)),
         ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))),
+        ("crnn_lstm", HeadConfig("crnn", (8, 16), layer_dim=16, n_blocks=2, embedding_dim=16, crnn_rnn_type="lstm")),   # reference default backend
     ]
     meta = {}
     arrays = {}
@@ -508,5 +597,7 @@ def make_onnx_fixtures(outdir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--onnx-only":
         make_onnx_fixtures(os.path.join(REPO, "tests", "golden", "onnx"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--r02-only":
+        make_round2_goldens(os.path.join(REPO, "tests", "golden"))
     else:
         main()

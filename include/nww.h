@@ -171,6 +171,38 @@ int nww_stream_close(nww_handle* h);
 /* samples seen per stream since open/reset                                                               */
 int64_t nww_stream_filled(const nww_handle* h);
 
+/* ---- embedding-mode preprocessor state on the device (S lock-step streams) -------------------------------
+ * Replaces the buffers and windowing of nanowakeword/data/AudioFeatures.py around its two ONNX models
+ * (melspectrogram.onnx / embedding_model.onnx: un-vendored release binaries, pluggable here - the caller runs
+ * them and hands their outputs over, host or device pointers):
+ *   melspectrogram_buffer (np.ones((76,32)) at reset, newest 970 frames kept)      AudioFeatures.py:107,119,393-398
+ *   melspec_transform x/10 + 2 (raw = 1)                                            :124,146
+ *   76-frame windows every 8 frames, one per new 80 ms chunk, oldest first          :434-440
+ *   feature_buffer (newest 120 rows) and get_features(n) = its last n rows          :446-457
+ *   batch path: -80 padding to the longest clip, all windows of a clip              :188-227, 231-295
+ * The handle must be a finalized feature-mode head with in_cols == emb_dim; nww_emb_forward scores every
+ * stream on get_features(in_rows) without the features leaving the device.                                    */
+int nww_emb_open(nww_handle* h, int32_t n_streams, int32_t mel_bins, int32_t emb_dim, int32_t mel_cap, int32_t feat_cap);
+int nww_emb_reset(nww_handle* h);              /* mel ring = ones(76, bins), feature ring empty (re-seed it with nww_emb_push_features) */
+int nww_emb_close(nww_handle* h);
+int nww_emb_state(const nww_handle* h, int32_t* mel_frames, int32_t* feature_rows);
+/* mel [n_streams][n_frames][mel_bins] float32: the mel model's output for the newest audio of every stream      */
+int nww_emb_push_mel(nww_handle* h, const float* mel, int32_t n_frames, int32_t on_device, int32_t raw);
+/* windows [n_streams][n_valid][76][mel_bins]: the windows of the n_chunks newest 80 ms chunks, oldest first       */
+int nww_emb_windows(nww_handle* h, int32_t n_chunks, float* windows, int32_t on_device, int32_t* n_valid);
+/* emb [n_streams][k][emb_dim]: the embedding model's rows for those windows                                       */
+int nww_emb_push_features(nww_handle* h, const float* emb, int32_t k, int32_t on_device);
+/* out [n_streams][n_out][emb_dim], n_out = min(n_frames, rows held)                                               */
+int nww_emb_get_features(nww_handle* h, int32_t n_frames, float* out, int32_t on_device, int32_t* n_out);
+/* logits / probs [n_streams] (host pointers, either may be NULL)                                                 */
+int nww_emb_forward(nww_handle* h, float* logits, float* probs);
+/* batch path. mel [B][F][bins] -> windows [B][n_windows][76][bins], n_windows = (F - 76) / 8 + 1                 */
+int nww_emb_window_batch(nww_handle* h, const float* mel, int32_t B, int32_t F, int32_t bins, float* windows,
+                         int32_t on_device, int32_t* n_windows);
+/* packed: B ragged spectrograms back to back ([sum(frames)][bins], host) -> out [B][Fmax][bins] (host)           */
+int nww_emb_pad_batch(nww_handle* h, const float* packed, const int32_t* frames, int32_t B, int32_t bins, int32_t Fmax,
+                      float pad, int32_t raw, float* out);
+
 const char* nww_version(void);
 
 #ifdef __cplusplus

@@ -41,6 +41,8 @@ SYMBOLS = [
     "nww_forward_features_dev", "nww_reserve", "nww_describe_plan", "nww_set_profiling", "nww_get_profile",
     "nww_stream_open", "nww_stream_push", "nww_stream_push_dev", "nww_stream_reset", "nww_stream_close",
     "nww_stream_filled", "nww_version",
+    "nww_emb_open", "nww_emb_reset", "nww_emb_close", "nww_emb_state", "nww_emb_push_mel", "nww_emb_windows",
+    "nww_emb_push_features", "nww_emb_get_features", "nww_emb_forward", "nww_emb_window_batch", "nww_emb_pad_batch",
 ]
 
 
@@ -87,6 +89,18 @@ def load_library():
     lib.nww_stream_close.argtypes = [vp]; lib.nww_stream_close.restype = C.c_int
     lib.nww_stream_filled.argtypes = [vp]; lib.nww_stream_filled.restype = C.c_int64
     lib.nww_version.argtypes = []; lib.nww_version.restype = C.c_char_p
+    i32p = C.POINTER(i32)
+    lib.nww_emb_open.argtypes = [vp, i32, i32, i32, i32, i32]; lib.nww_emb_open.restype = C.c_int
+    lib.nww_emb_reset.argtypes = [vp]; lib.nww_emb_reset.restype = C.c_int
+    lib.nww_emb_close.argtypes = [vp]; lib.nww_emb_close.restype = C.c_int
+    lib.nww_emb_state.argtypes = [vp, i32p, i32p]; lib.nww_emb_state.restype = C.c_int
+    lib.nww_emb_push_mel.argtypes = [vp, vp, i32, i32, i32]; lib.nww_emb_push_mel.restype = C.c_int
+    lib.nww_emb_windows.argtypes = [vp, i32, vp, i32, i32p]; lib.nww_emb_windows.restype = C.c_int
+    lib.nww_emb_push_features.argtypes = [vp, vp, i32, i32]; lib.nww_emb_push_features.restype = C.c_int
+    lib.nww_emb_get_features.argtypes = [vp, i32, vp, i32, i32p]; lib.nww_emb_get_features.restype = C.c_int
+    lib.nww_emb_forward.argtypes = [vp, vp, vp]; lib.nww_emb_forward.restype = C.c_int
+    lib.nww_emb_window_batch.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32p]; lib.nww_emb_window_batch.restype = C.c_int
+    lib.nww_emb_pad_batch.argtypes = [vp, vp, i32p, i32, i32, i32, C.c_float, i32, vp]; lib.nww_emb_pad_batch.restype = C.c_int
     _lib = lib
     return lib
 

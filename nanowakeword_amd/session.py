@@ -248,6 +248,84 @@ class HipModel:
     def stream_close(self):
         self._check(self.lib.nww_stream_close(self._h))
 
+    # ------------------------------------------------------------------ embedding-mode preprocessor state (nww_emb_*)
+    def emb_open(self, n_streams: int = 1, mel_bins: int = 32, emb_dim: int = 96, mel_cap: int = 970, feat_cap: int = 120):
+        self._check(self.lib.nww_emb_open(self._h, int(n_streams), int(mel_bins), int(emb_dim), int(mel_cap), int(feat_cap)))
+        self._emb = (int(n_streams), int(mel_bins), int(emb_dim))
+
+    def emb_reset(self):
+        self._check(self.lib.nww_emb_reset(self._h))
+
+    def emb_close(self):
+        self._check(self.lib.nww_emb_close(self._h))
+
+    def emb_state(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self.lib.nww_emb_state(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def emb_push_mel(self, mel, raw: bool = True):
+        """mel float32 [S, n_frames, bins]: the mel model's output for the newest audio; raw applies x/10 + 2."""
+        S, bins, _ = self._emb
+        mel = _as_f32(mel)
+        if mel.ndim != 3 or mel.shape[0] != S or mel.shape[2] != bins:
+            raise ValueError(f"mel must have shape ({S}, n_frames, {bins}), got {mel.shape}")
+        self._check(self.lib.nww_emb_push_mel(self._h, mel.ctypes.data_as(C.c_void_p), mel.shape[1], 0, int(bool(raw))))
+
+    def emb_windows(self, n_chunks: int) -> np.ndarray:
+        S, bins, _ = self._emb
+        out = np.empty((S, int(n_chunks), 76, bins), np.float32)
+        nv = C.c_int32()
+        self._check(self.lib.nww_emb_windows(self._h, int(n_chunks), out.ctypes.data_as(C.c_void_p), 0, C.byref(nv)))
+        return np.ascontiguousarray(out.reshape(-1)[:S * nv.value * 76 * bins].reshape(S, nv.value, 76, bins))
+
+    def emb_push_features(self, emb):
+        S, _, D = self._emb
+        emb = _as_f32(emb)
+        if emb.ndim != 3 or emb.shape[0] != S or emb.shape[2] != D:
+            raise ValueError(f"embeddings must have shape ({S}, k, {D}), got {emb.shape}")
+        if emb.shape[1]:
+            self._check(self.lib.nww_emb_push_features(self._h, emb.ctypes.data_as(C.c_void_p), emb.shape[1], 0))
+
+    def emb_get_features(self, n_frames: int) -> np.ndarray:
+        S, _, D = self._emb
+        out = np.empty((S, int(n_frames), D), np.float32)
+        n = C.c_int32()
+        self._check(self.lib.nww_emb_get_features(self._h, int(n_frames), out.ctypes.data_as(C.c_void_p), 0, C.byref(n)))
+        return np.ascontiguousarray(out.reshape(-1)[:S * n.value * D].reshape(S, n.value, D))
+
+    def emb_forward(self):
+        """(logits [S], probs [S]) of the head on get_features(T) of every stream; features stay on the device."""
+        S = self._emb[0]
+        logits, probs = np.empty(S, np.float32), np.empty(S, np.float32)
+        self._check(self.lib.nww_emb_forward(self._h, logits.ctypes.data_as(C.c_void_p), probs.ctypes.data_as(C.c_void_p)))
+        return logits, probs
+
+    def emb_window_batch(self, mel) -> np.ndarray:
+        """mel float32 [B, F, bins] -> windows [B, (F-76)//8+1, 76, bins] (AudioFeatures._get_embeddings_batch windowing)."""
+        mel = _as_f32(mel)
+        B, F, bins = mel.shape
+        if F < 76:
+            raise ValueError("Embedding model requires the input melspectrograms to have at least 76 frames")
+        W = (F - 76) // 8 + 1
+        out = np.empty((B, W, 76, bins), np.float32)
+        nw = C.c_int32()
+        self._check(self.lib.nww_emb_window_batch(self._h, mel.ctypes.data_as(C.c_void_p), B, F, bins, out.ctypes.data_as(C.c_void_p), 0, C.byref(nw)))
+        assert nw.value == W
+        return out
+
+    def emb_pad_batch(self, specs, pad: float = -80.0, raw: bool = False) -> np.ndarray:
+        """list of float32 [frames_i, bins] -> [B, max frames, bins] padded with `pad` (AudioFeatures.py:213-225)."""
+        specs = [_as_f32(s) for s in specs]
+        bins = specs[0].shape[1]
+        frames = np.array([s.shape[0] for s in specs], np.int32)
+        Fmax = int(frames.max())
+        packed = np.ascontiguousarray(np.concatenate(specs, axis=0))
+        out = np.empty((len(specs), Fmax, bins), np.float32)
+        self._check(self.lib.nww_emb_pad_batch(self._h, packed.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               len(specs), bins, Fmax, float(pad), int(bool(raw)), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def set_profiling(self, enable: bool = True):
         self._check(self.lib.nww_set_profiling(self._h, int(enable)))
 

@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+python -m pytest tests/test_audio_features.py tests/test_cpu_library.py -m gpu -x -q 2>&1 | tail -25

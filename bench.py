@@ -34,17 +34,29 @@ PEAK_BF16_TFLOPS = 16 * 157.3  # dense bf16 MFMA peak = 16 x the f32 MFMA rate (
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed steps before the W warm-up steps until this much time has passed: the GPU needs ~0.1 s of load "
+                         "to reach its sustained clocks (20 cold steps run 10 %% slower than the same steps a second later)")
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
     ap.add_argument("--head", default="cnn")
     ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6"],
                     help="arithmetic of the fused conv trunk's conv2 (all float32-grade; nww_config.conv_arith)")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP events around the launches of every n-th timed step (an event per launch boundary costs the "
+                         "stream ~10 us: n = 1 slows the timed loop by ~10 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the self-audit legs (other conv arithmetics, sustained loop, PCIe-inclusive rate); N=1 only anyway")
     ap.add_argument("--sustain-seconds", type=float, default=2.5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: split this many clips over the ranks (BASELINE config 3: 65536 over 8); default 0 = "
+                         "weak scaling with --batch clips per GPU")
+    ap.add_argument("--gather", default="capi", choices=["capi", "torch"],
+                    help="N>1: the logits all-gather through the C-ABI (nww_forward_pcm_gather_dev: RCCL on the kernels' stream) "
+                         "or through torch.distributed")
     ap.add_argument("--debug-single-gpu", action="store_true",
                     help="control-flow check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the gather "
                          "runs over gloo on host copies (never a measurement)")
@@ -139,19 +151,23 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
     lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2)]
     hlog = [torch.empty(B, dtype=torch.float32).pin_memory() for _ in range(2)]
-    copy_s, comp_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    up = [torch.cuda.Event() for _ in range(2)]
+    NCOPY = 4                                             # the upload of a batch is split over four copy streams
+    copy_s, comp_s = [torch.cuda.Stream(dev) for _ in range(NCOPY)], torch.cuda.Stream(dev)
+    up = [[torch.cuda.Event() for _ in range(NCOPY)] for _ in range(2)]
     done = [torch.cuda.Event() for _ in range(2)]
+    rows = (B + NCOPY - 1) // NCOPY
 
     def run(k):
         for i in range(k):
             j = i & 1
-            with torch.cuda.stream(copy_s):
-                copy_s.wait_event(done[j])                # the kernels that read dbuf[j] two batches ago are finished
-                dbuf[j].copy_(host[j], non_blocking=True)
-                up[j].record(copy_s)
+            for c, cs in enumerate(copy_s):
+                with torch.cuda.stream(cs):
+                    cs.wait_event(done[j])                # the kernels that read dbuf[j] two batches ago are finished
+                    dbuf[j][c * rows:(c + 1) * rows].copy_(host[j][c * rows:(c + 1) * rows], non_blocking=True)
+                    up[j][c].record(cs)
             with torch.cuda.stream(comp_s):
-                comp_s.wait_event(up[j])
+                for c in range(NCOPY):
+                    comp_s.wait_event(up[j][c])
                 m.forward_pcm_dev(dbuf[j].data_ptr(), B, N, lbuf[j].data_ptr(), 0, comp_s.cuda_stream)
                 hlog[j].copy_(lbuf[j], non_blocking=True)
                 done[j].record(comp_s)
@@ -208,6 +224,11 @@ def main():
     arith = a.conv_arith
     model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb, conv_arith=arith)
     B, N = a.batch, 16000
+    scaling = "weak"
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit("--global-batch must be divisible by the number of ranks")
+        B, scaling = a.global_batch // world, "strong"
     pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
     pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
     logits = torch.empty(B, dtype=torch.float32, device=dev)
@@ -215,16 +236,44 @@ def main():
     gathered = torch.empty(B * world, dtype=torch.float32, device=gdev) if world > 1 else None
     model.reserve(B, N)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    gather_via = "none"
+    if world > 1:
+        gather_via = "torch.distributed"
+        if a.gather == "capi" and not a.debug_single_gpu:
+            # the communicator of the C-ABI: rank 0 creates the RCCL id, torch.distributed only carries its 128 bytes
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(HipModel.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                model.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+                gather_via = "capi"
+            except Exception as e:                                  # stay measurable: fall back to the torch collective
+                print(f"[bench] rank {rank}: C-ABI communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ok = torch.tensor([1 if gather_via == "capi" else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)               # all ranks must agree on the collective they run
+            if int(ok.item()) == 0:
+                gather_via = "torch.distributed"
+    if gather_via == "capi":
+        logits = gathered[rank * B:(rank + 1) * B]                  # this rank's slot of the gathered vector
 
     def step():
+        if gather_via == "capi":
+            model.forward_pcm_gather_dev(pcm.data_ptr(), B, N, gathered.data_ptr(), stream)   # kernels + RCCL all-gather, one stream
+            return
         model.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
         if world > 1:
             dist.all_gather_into_tensor(gathered, logits if not a.debug_single_gpu else logits.cpu())   # RCCL over xGMI: 4 B per clip
 
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < a.prewarm_seconds:      # clock ramp (untimed, not counted in W)
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(dev)
-    model.set_profiling(True)
+    model.set_profiling(max(1, a.profile_every))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -308,14 +357,14 @@ def main():
         out = {
             "metric": "clips/sec (1 s @16 kHz PCM->logits)", "value": round(value, 1), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.model_type} head on (101,64) log-mel, batch={B}/GPU, 1 s 16 kHz mono int16 "
                                    "clips, 64-mel 25 ms/10 ms center frontend, fused STFT+mel HIP kernel, fp32",
                        "clips_per_gpu": B, "n_samples": N,
                        "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
                                       "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)"}[arith],
-                       "parallelism": f"batch-split x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
+                       "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via})" if world > 1 else "")},
             "roofline": roofline,
             "kernel_ms": kernel_ms,
         }

@@ -151,7 +151,8 @@ int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen);
  * forward records one event per launch boundary (frontend, each head launch, sigmoid).
  * nww_get_profile synchronises those events and returns, per plan entry (same order as
  * nww_describe_plan), the accumulated milliseconds and the number of launches since the last
- * nww_set_profiling(h, 1).  n_inout: capacity in, entries out.                                */
+ * nww_set_profiling(h, 1).  n_inout: capacity in, entries out.  enable = n > 1 samples every n-th
+ * forward only (each event costs the stream ~10 us; sampling keeps a timed loop undisturbed).    */
 int nww_set_profiling(nww_handle* h, int32_t enable);
 int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches, int32_t* n_inout);
 
@@ -202,6 +203,21 @@ int nww_emb_window_batch(nww_handle* h, const float* mel, int32_t B, int32_t F, 
 /* packed: B ragged spectrograms back to back ([sum(frames)][bins], host) -> out [B][Fmax][bins] (host)           */
 int nww_emb_pad_batch(nww_handle* h, const float* packed, const int32_t* frames, int32_t B, int32_t bins, int32_t Fmax,
                       float pad, int32_t raw, float* out);
+
+/* ---- multi-GPU: batch split, one RCCL all-gather of the per-clip logits ------------------------
+ * One process (and one handle) per GPU; every rank scores its own contiguous shard of the clips.  The path's only
+ * exchange is an all-gather of 4 bytes per clip over RCCL / xGMI, enqueued on the same stream as the kernels.
+ * The reference has no counterpart (it is single-process).  RCCL is bound at run time, so single-GPU users never
+ * load it.  Rank 0 creates the 128-byte id and hands it to the other ranks by any means (file, socket, MPI,
+ * torch.distributed - bench.py broadcasts it); then every rank calls nww_comm_init.                            */
+#define NWW_COMM_ID_BYTES 128
+int nww_comm_unique_id(void* id128);
+int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const void* id128);
+int nww_comm_destroy(nww_handle* h);
+/* d_send [count] -> d_recv [world][count] on every rank; asynchronous on `stream`                                */
+int nww_all_gather_logits(nww_handle* h, const float* d_send, float* d_recv, int32_t count, void* stream);
+/* forward of this rank's B clips + all-gather into d_all_logits [world][B], one stream, no host hop               */
+int nww_forward_pcm_gather_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream);
 
 const char* nww_version(void);
 

@@ -43,6 +43,7 @@ SYMBOLS = [
     "nww_stream_filled", "nww_version",
     "nww_emb_open", "nww_emb_reset", "nww_emb_close", "nww_emb_state", "nww_emb_push_mel", "nww_emb_windows",
     "nww_emb_push_features", "nww_emb_get_features", "nww_emb_forward", "nww_emb_window_batch", "nww_emb_pad_batch",
+    "nww_comm_unique_id", "nww_comm_init", "nww_comm_destroy", "nww_all_gather_logits", "nww_forward_pcm_gather_dev",
 ]
 
 
@@ -101,6 +102,11 @@ def load_library():
     lib.nww_emb_forward.argtypes = [vp, vp, vp]; lib.nww_emb_forward.restype = C.c_int
     lib.nww_emb_window_batch.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32p]; lib.nww_emb_window_batch.restype = C.c_int
     lib.nww_emb_pad_batch.argtypes = [vp, vp, i32p, i32, i32, i32, C.c_float, i32, vp]; lib.nww_emb_pad_batch.restype = C.c_int
+    lib.nww_comm_unique_id.argtypes = [vp]; lib.nww_comm_unique_id.restype = C.c_int
+    lib.nww_comm_init.argtypes = [vp, i32, i32, vp]; lib.nww_comm_init.restype = C.c_int
+    lib.nww_comm_destroy.argtypes = [vp]; lib.nww_comm_destroy.restype = C.c_int
+    lib.nww_all_gather_logits.argtypes = [vp, vp, vp, i32, vp]; lib.nww_all_gather_logits.restype = C.c_int
+    lib.nww_forward_pcm_gather_dev.argtypes = [vp, vp, i32, i32, vp, vp]; lib.nww_forward_pcm_gather_dev.restype = C.c_int
     _lib = lib
     return lib
 

@@ -16,6 +16,7 @@
 #include "layers.h"
 #include "trunk.h"
 #include "emb_stream.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -73,6 +74,8 @@ struct nww_handle {
     // streaming rings: [S][2*W] int16, sample p of a stream lives at p and p+W
     int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
     EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
+    void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
+    int comm_rank = 0, comm_world = 1;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
@@ -80,6 +83,8 @@ struct nww_handle {
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
     bool profiling = false;
+    int prof_period = 1, prof_counter = 0;   // sampling: only every prof_period-th forward records events
+    bool prof_active = false;
     std::vector<std::vector<hipEvent_t>> prof_runs;   // one event list per recorded forward
     std::vector<std::vector<int>> prof_ids;           // plan-entry id of each interval
     std::vector<hipEvent_t> event_pool;
@@ -94,7 +99,7 @@ static hipEvent_t prof_event(nww_handle* h) {
     return e;
 }
 static void prof_mark(nww_handle* h, hipStream_t s, int id_of_next) {
-    if (!h->profiling) return;
+    if (!h->profiling || !h->prof_active) return;
     hipEvent_t e = prof_event(h);
     if (!e) return;
     (void)hipEventRecord(e, s);
@@ -103,6 +108,8 @@ static void prof_mark(nww_handle* h, hipStream_t s, int id_of_next) {
 }
 static void prof_begin(nww_handle* h) {
     if (!h->profiling) return;
+    h->prof_active = (h->prof_counter++ % h->prof_period) == 0;
+    if (!h->prof_active) return;
     h->prof_runs.emplace_back();
     h->prof_ids.emplace_back();
 }
@@ -325,12 +332,14 @@ static void free_ws(nww_handle* h) {
 extern "C" int nww_stream_close(nww_handle* h);
 
 extern "C" int nww_emb_close(nww_handle* h);
+extern "C" int nww_comm_destroy(nww_handle* h);
 extern "C" int nww_destroy(nww_handle* h) {
     if (!h) return NWW_OK;
     (void)hipSetDevice(h->cfg.device);
     free_ws(h);
     nww_stream_close(h);
     nww_emb_close(h);
+    nww_comm_destroy(h);
     if (h->d_weights) (void)hipFree(h->d_weights);
     for (auto& kv : h->x3_weights) (void)hipFree(kv.second);
     if (h->d_tables) (void)hipFree(h->d_tables);
@@ -872,6 +881,8 @@ extern "C" int nww_set_profiling(nww_handle* h, int32_t enable) {
     h->prof_ms.assign(h->plan.size() + 2, 0.0);
     h->prof_cnt.assign(h->plan.size() + 2, 0);
     h->profiling = enable != 0;
+    h->prof_period = enable > 1 ? enable : 1;     // enable = n > 1: sample every n-th forward (an event per launch boundary costs ~10 us)
+    h->prof_counter = 0; h->prof_active = false;
     return NWW_OK;
 }
 
@@ -1161,6 +1172,111 @@ extern "C" int nww_stream_push(nww_handle* h, const int16_t* chunk, float* logit
     int rc = stream_push_dev(h, h->d_chunk, h->d_logits, h->d_probs, s);
     if (rc) return rc;
     return copy_out(h, S, logits, probs, nullptr, s);
+}
+
+// ------------------------------------------------------------------------------------------ RCCL (multi-GPU gather)
+// The path's only exchange: an all-gather of the per-clip float32 logits (4 B per clip) over RCCL / xGMI, enqueued on
+// the SAME stream as the kernels so a step never touches the host.  RCCL is bound at run time (dlopen): a process
+// that already carries one (PyTorch's bundled librccl.so) is reused, otherwise the system librccl.so.1 is loaded; a
+// single-GPU user never loads it at all.
+struct NcclId { char internal[128]; };       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+}  // namespace
+static RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {            // already in the process?
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (a.lib) break;
+        }
+        if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) { a.err = std::string("cannot load RCCL: ") + dlerror(); return a; }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) a.err = "RCCL library lacks the expected symbols";
+        return a;
+    }();
+    return api;
+}
+static const char* rccl_str(int rc) { return rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"; }
+
+extern "C" int nww_comm_unique_id(void* id128) {
+    if (!id128) return NWW_ERR_INVALID;
+    RcclApi& a = rccl();
+    if (!a.err.empty()) { g_create_err = a.err; return NWW_ERR_UNSUPPORTED; }
+    const int rc = a.GetUniqueId(id128);
+    if (rc != 0) { g_create_err = std::string("ncclGetUniqueId: ") + rccl_str(rc); return NWW_ERR_HIP; }
+    return NWW_OK;
+}
+
+extern "C" int nww_comm_destroy(nww_handle* h) {
+    if (!h) return NWW_ERR_INVALID;
+    if (h->comm) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_rank = 0; h->comm_world = 1;
+    return NWW_OK;
+}
+
+extern "C" int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const void* id128) {
+    if (!h) return NWW_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !id128) return fail(h, NWW_ERR_INVALID, "nww_comm_init: bad rank/world/id");
+    RcclApi& a = rccl();
+    if (!a.err.empty()) return fail(h, NWW_ERR_UNSUPPORTED, "%s", a.err.c_str());
+    nww_comm_destroy(h);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    NcclId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    const int rc = a.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_str(rc));
+    h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+    return NWW_OK;
+}
+
+static int all_gather_dev(nww_handle* h, const float* d_send, float* d_recv, int count, hipStream_t s) {
+    if (!h->comm) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    const int rc = rccl().AllGather(d_send, d_recv, (size_t)count, /* ncclFloat32 */ 7, h->comm, s);
+    if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclAllGather: %s", rccl_str(rc));
+    return NWW_OK;
+}
+
+// d_send [count] of this rank -> d_recv [world][count] on every rank, enqueued on `stream` (no synchronisation)
+extern "C" int nww_all_gather_logits(nww_handle* h, const float* d_send, float* d_recv, int32_t count, void* stream) {
+    if (!h) return NWW_ERR_INVALID;
+    if (!d_send || !d_recv || count <= 0) return fail(h, NWW_ERR_INVALID, "nww_all_gather_logits: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return all_gather_dev(h, d_send, d_recv, count, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+// One sharded step without a host hop: this rank's B clips -> its B logits (written at d_all_logits + rank * B), then
+// the all-gather into d_all_logits [world][B], both on `stream`.
+extern "C" int nww_forward_pcm_gather_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_pcm || !d_all_logits) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    if (!h->comm) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    float* mine = d_all_logits + (size_t)h->comm_rank * B;
+    rc = forward_pcm_dev(h, d_pcm, B, N, mine, nullptr, s);
+    if (rc) return rc;
+    return all_gather_dev(h, mine, d_all_logits, B, s);       // in place: send buffer = this rank's slot of the receive buffer
 }
 
 // ------------------------------------------------------------------------------------------ embedding-mode state

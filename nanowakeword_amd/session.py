@@ -326,7 +326,37 @@ class HipModel:
                                                len(specs), bins, Fmax, float(pad), int(bool(raw)), out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def set_profiling(self, enable: bool = True):
+    # ------------------------------------------------------------------ multi-GPU gather through the C-ABI (RCCL)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id; rank 0 creates it and hands it to the other ranks (any transport)."""
+        lib = _lib.load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.nww_comm_unique_id(buf)
+        if rc != 0:
+            raise NwwError(lib.nww_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._check(self.lib.nww_comm_init(self._h, int(rank), int(world), C.create_string_buffer(unique_id, 128)))
+        self._comm = (int(rank), int(world))
+
+    def comm_destroy(self):
+        self._check(self.lib.nww_comm_destroy(self._h))
+
+    def all_gather_logits_dev(self, send_ptr: int, recv_ptr: int, count: int, stream: int = 0):
+        self._check(self.lib.nww_all_gather_logits(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count),
+                                                   C.c_void_p(stream) if stream else None))
+
+    def forward_pcm_gather_dev(self, pcm_ptr: int, B: int, N: int, all_logits_ptr: int, stream: int = 0):
+        """this rank's B clips -> all ranks' logits [world, B] at all_logits_ptr; kernels + RCCL all-gather on one stream"""
+        self._check(self.lib.nww_forward_pcm_gather_dev(self._h, C.c_void_p(pcm_ptr), int(B), int(N), C.c_void_p(all_logits_ptr),
+                                                        C.c_void_p(stream) if stream else None))
+
+    def set_profiling(self, enable=True):
+        """True/1: HIP events around every launch of every forward; n > 1: of every n-th forward only; False: off."""
         self._check(self.lib.nww_set_profiling(self._h, int(enable)))
 
     def get_profile(self):

@@ -193,3 +193,35 @@ def test_batch_invariance_at_baseline_sizes(HipModel, golden_frontend, head, B):
     lo = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
     assert np.abs(lg[:6] - lo).max() <= 1e-4
     m.close()
+
+
+def test_capi_communicator_world1(HipModel, golden_frontend):
+    """RCCL through the C-ABI (nww_comm_*): a one-rank communicator on the 1-GPU box exercises the run-time binding, the
+    by-value 128-byte id and the in-place all-gather on the kernels' stream; the gathered vector must be the logits."""
+    import torch
+    g = golden_frontend
+    cfg = HeadConfig("cnn", (101, 64))
+    m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=g["fb64"])
+    uid = HipModel.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    m.comm_init(0, 1, uid)
+    dev = torch.device("cuda", 0)
+    x = synth_pcm("noise", 64, 16000, seed=2)
+    pcm = torch.from_numpy(x).to(dev)
+    out = torch.zeros(64, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    m.forward_pcm_gather_dev(pcm.data_ptr(), 64, 16000, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    want, _ = m.forward_pcm(x)
+    assert np.array_equal(out.cpu().numpy(), want)
+    send = torch.arange(10, dtype=torch.float32, device=dev)
+    recv = torch.zeros(10, dtype=torch.float32, device=dev)
+    m.all_gather_logits_dev(send.data_ptr(), recv.data_ptr(), 10, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    with pytest.raises(ValueError):
+        m.comm_init(1, 1, uid)                                # rank outside the world
+    m.comm_destroy()
+    with pytest.raises(Exception, match="communicator"):
+        m.forward_pcm_gather_dev(pcm.data_ptr(), 64, 16000, out.data_ptr(), stream)
+    m.close()

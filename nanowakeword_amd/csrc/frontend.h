@@ -10,9 +10,10 @@ hipError_t fe_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int 
                      float* d_db, float* d_mel, int frames_major, int fc_max, int block, int max_grid,
                      hipStream_t stream);
 
-// Wave-private kernel (frontend2.hip, the default): same contract.  mfma_mel = 1: mel contraction on the matrix cores
-// (d_plan from fe2_build_mel_plan), 0: sparse VALU loop.  block = 256 (4 waves); max_grid workgroups.
-int fe2_lds_bytes(int waves, int mfma_mel);
+// Wave-private kernel (frontend2.hip, the default): same contract.  mel_mode 2: lane = filter with register-resident
+// weights (needs n_mels <= 64 and max_taps <= 28, else mode 1), 1: mel contraction on the matrix cores (d_plan from
+// fe2_build_mel_plan), 0: sparse loop over LDS tables.  max_taps = longest filter support.  block = 256 (4 waves).
+int fe2_lds_bytes(int waves, int mel_mode);
 hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p,
                       const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
-                      int mfma_mel, int block, int max_grid, hipStream_t stream);
+                      int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream);

@@ -49,21 +49,31 @@ __device__ __forceinline__ float fe2_db(float mel, float amin, float mult, float
     return mel > amin ? db : floor_db;      // the clamp floor exactly as the reference computes it (-100 dB)
 }
 
+// MEL: how S4 contracts the powers with the filterbank
+//   2  lane = filter (n_mels <= 64, every filter <= MAXT taps): the lane's weights stay in MAXT registers for the whole
+//      launch, one LDS read + one fmaf per tap, zero-padded to MAXT - same summation order as the sparse loop.
+//      The default: on gfx950 the float32 MFMA runs at the VALU rate AND blocks the SIMD's VALU while it runs
+//      (tools/ubench/mfma_valu_overlap.hip: a v_mfma_f32_16x16x4_f32 wave and a VALU wave on one SIMD take a + b,
+//      AGPR accumulators or not), so the dense 16 x 16 x K tiles with half their rows empty cost 2048 matrix-pipe
+//      clocks per item against ~900 for these 370 VALU instructions.
+//   1  v_mfma_f32_16x16x4_f32 tiles (any n_mels <= 128, any filterbank)
+//   0  sparse loop over LDS tables (any filterbank; A/B reference)
 // FAST_OUT: frames-major log-mel only (the PCM -> logit path): branch-free S4 epilogue
-template <int MFMA_MEL, int FAST_OUT>
+template <int MEL, int FAST_OUT, int MAXT>
 __global__ void __launch_bounds__(256, 3)
 fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad,
                 int n_mels, float amin, float db_mult, float floor_db, const FeTables* __restrict__ gtb,
                 const Fe2MelPlan* __restrict__ plan, float* __restrict__ out_db, float* __restrict__ out_mel,
                 int frames_major, int dbg, int skew_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MFMA_MEL = MEL == 1;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwv = blockDim.x >> 6;
-    const int tb_bytes = MFMA_MEL ? 0 : (int)sizeof(Fe2MelLds);
+    const int tb_bytes = MEL == 0 ? (int)sizeof(Fe2MelLds) : 0;
     Fe2MelLds* mt = reinterpret_cast<Fe2MelLds*>(smem);
     float* slab = reinterpret_cast<float*>(smem + tb_bytes) + wv * (FE2_G * FE2_FRAME_DW);
-    if (!MFMA_MEL) {      // the only workgroup barrier of the kernel: sparse-mel tables -> LDS, once
+    if (MEL == 0) {       // the only workgroup barrier of the kernel: sparse-mel tables -> LDS, once
         for (int i = threadIdx.x; i < FE_MAX_MELS; i += blockDim.x)
             mt->desc[i] = (uint32_t)gtb->mel_lo[i] | ((uint32_t)gtb->mel_cnt[i] << 8) | ((uint32_t)gtb->mel_off[i] << 16);
         for (int i = threadIdx.x; i < FE_MAX_MELW; i += blockDim.x) mt->w[i] = gtb->melw[i];
@@ -89,6 +99,16 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
         co_off[r] = f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j;
     }
     // S4 (MFMA): per-chunk metadata, lane c of one register = chunk c (read back with v_readlane)
+    // S4 (register filters): lane = filter
+    float wreg[MAXT];
+    int mel_lo_lane = 0;
+    if (MEL == 2) {
+        const int j = min(lane, n_mels - 1);
+        mel_lo_lane = gtb->mel_lo[j];
+        const int cnt = lane < n_mels ? gtb->mel_cnt[j] : 0, off = gtb->mel_off[j];
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) wreg[i] = i < cnt ? gtb->melw[off + i] : 0.0f;
+    }
     const int mel_nchunks = MFMA_MEL ? plan->nchunks : 0;
     const uint32_t mel_meta = MFMA_MEL ? plan->chunk_meta[lane] : 0u;
     const bool aligned = ((reinterpret_cast<uintptr_t>(pcm) | (row_stride * sizeof(int16_t))) & 3) == 0;
@@ -267,6 +287,42 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
                     load_chunk(min(c + 2, last), a0, b0);
                     if (c + 1 < mel_nchunks) run_chunk(c + 1, a1, b1);
                 }
+            } else if (MEL == 2) {
+                // two frames per trip: two independent fmaf chains; rows of frames >= nf hold stale (finite) data and
+                // are staged too - the copy-out takes nf rows only
+                const float* p0 = slab + mel_lo_lane;
+#pragma unroll 1
+                for (int f = 0; f < FE2_G; f += 2) {
+                    const float* pa = p0 + f * FE2_FRAME_DW + FE2_PSHIFT(f);        // PSHIFT(f) == PSHIFT(f + 1) for even f
+                    const float* pb = pa + FE2_FRAME_DW;
+                    float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < MAXT; ++i) { ma = fmaf(pa[i], wreg[i], ma); mb = fmaf(pb[i], wreg[i], mb); }
+                    if (lane < n_mels) {
+                        const float da = fe2_db(ma, amin, db_mult, floor_db), db2 = fe2_db(mb, amin, db_mult, floor_db);
+                        if (FAST_OUT) {
+                            float* st = slab + f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + lane;
+                            st[0] = da;
+                            st[FE2_FRAME_DW] = db2;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int fq = f + q;
+                                const float m = q ? mb : ma, db = q ? db2 : da;
+                                if (fq < nf) {
+                                    if (frames_major) {
+                                        slab[fq * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(fq) + lane] = db;
+                                        if (out_mel) out_mel[((size_t)b * T + t0 + fq) * n_mels + lane] = m;
+                                    } else {
+                                        const size_t o = ((size_t)b * n_mels + lane) * T + t0 + fq;
+                                        if (out_db) out_db[o] = db;
+                                        if (out_mel) out_mel[o] = m;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
             } else {
                 const int f = lane & 7;
                 if (f < nf) {
@@ -313,26 +369,32 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
     }
 }
 
-int fe2_lds_bytes(int waves, int mfma_mel) {
-    return waves * FE2_G * FE2_FRAME_DW * 4 + (mfma_mel ? 0 : (int)sizeof(Fe2MelLds));
+int fe2_lds_bytes(int waves, int mel_mode) {
+    return waves * FE2_G * FE2_FRAME_DW * 4 + (mel_mode == 0 ? (int)sizeof(Fe2MelLds) : 0);
 }
 
 hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p,
                       const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
-                      int mfma_mel, int block, int max_grid, hipStream_t stream) {
+                      int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream) {
     if (block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
     const int nwv = block / 64;
     const int ngroups = (T + FE2_G - 1) / FE2_G;
-    const int lds = fe2_lds_bytes(nwv, mfma_mel);
+    // mel_mode: 2 = register-resident filters (falls back to the MFMA tiles when the filterbank does not fit), 1, 0
+    int mode = mel_mode;
+    if (mode == 2 && (p.n_mels > 64 || max_taps > 28)) mode = 1;
+    const int lds = fe2_lds_bytes(nwv, mode);
     const int fast = (frames_major && d_db && !d_mel) ? 1 : 0;
-    auto kern = mfma_mel ? (fast ? fe2_wave_kernel<1, 1> : fe2_wave_kernel<1, 0>) : fe2_wave_kernel<0, 0>;
+    auto kern = mode == 0 ? fe2_wave_kernel<0, 0, 1>
+              : mode == 1 ? (fast ? fe2_wave_kernel<1, 1, 1> : fe2_wave_kernel<1, 0, 1>)
+              : max_taps <= 20 ? (fast ? fe2_wave_kernel<2, 1, 20> : fe2_wave_kernel<2, 0, 20>)
+                               : (fast ? fe2_wave_kernel<2, 1, 28> : fe2_wave_kernel<2, 0, 28>);
     const void* fn = reinterpret_cast<const void*>(kern);
     {
         hipError_t e = nww_allow_lds(fn, (size_t)lds);
         if (e != hipSuccess) return e;
     }
     static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
-    static const int skew = [] { const char* e = getenv("NWW_FE_SKEW"); return e ? atoi(e) : 2; }();   // x 4096 clocks per wave slot
+    static const int skew = [] { const char* e = getenv("NWW_FE_SKEW"); return e ? atoi(e) : 0; }();   // experiment: x 4096 clocks per wave slot
     const long long total = (long long)B * ngroups;
     long long need = (total + nwv - 1) / nwv;
     int grid = (int)(need < max_grid ? need : max_grid);

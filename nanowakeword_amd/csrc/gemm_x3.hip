@@ -144,15 +144,14 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
     // One LDS stage per workgroup (53 KB for BN = 128, so two workgroups share a CU and cover each other's staging
-    // phases); the next k-tile's global loads travel in registers while the current one is multiplied.
-    Stage st;
-    if (kt_begin < kt_end) gload(kt_begin, st);
+    // phases).  Global loads run TWO k-tiles ahead in two register stages: with one tile of lookahead a load had only
+    // one tile's MFMAs (~1.5k clocks) to land and the loop was bound by HBM latency (fc1: 7.5k clocks per k-tile).
+    constexpr bool DEEP = CB <= 4;                             // wider tiles have no registers left for a second stage
+    Stage st0, st1;
+    if (kt_begin < kt_end) gload(kt_begin, st0);
+    if (DEEP && kt_begin + 1 < kt_end) gload(kt_begin + 1, st1);
     const int a_off = (wave * 32 + i) * X3_ROW + 16 * h, w_off = i * X3_ROW + 16 * h;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        __syncthreads();                                       // everyone is done reading the previous tile
-        lstore(0, st);
-        __syncthreads();
-        if (kt + 1 < kt_end) gload(kt + 1, st);
+    auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const unsigned char* ap = As(0) + a_off + 32 * kk;
@@ -171,6 +170,20 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[c], 0, 0, 0);
             }
+        }
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += DEEP ? 2 : 1) {
+        __syncthreads();                                       // everyone is done reading the previous tile
+        lstore(0, st0);
+        __syncthreads();
+        if (kt + (DEEP ? 2 : 1) < kt_end) gload(kt + (DEEP ? 2 : 1), st0);
+        multiply();
+        if (DEEP && kt + 1 < kt_end) {
+            __syncthreads();
+            lstore(0, st1);
+            __syncthreads();
+            if (kt + 3 < kt_end) gload(kt + 3, st1);
+            multiply();
         }
     }
 

@@ -57,6 +57,7 @@ struct nww_handle {
     float* d_weights = nullptr;
     FeTables* d_tables = nullptr;
     Fe2MelPlan* d_melplan = nullptr;
+    int mel_max_taps = 0;          // longest filter support of the mel filterbank
     hipStream_t own_stream = nullptr;
     std::vector<Step> plan;
     size_t buf_per_clip[6] = {0, 0, 0, 0, 0, 0};   // floats per clip of each workspace buffer
@@ -633,6 +634,8 @@ extern "C" int nww_finalize(nww_handle* h) {
         HIP_TRY(h, hipMalloc(&h->d_tables, tbytes));
         HIP_TRY(h, hipMemset(h->d_tables, 0, tbytes));
         HIP_TRY(h, hipMemcpy(h->d_tables, &tb, sizeof(FeTables), hipMemcpyHostToDevice));
+        h->mel_max_taps = 0;
+        for (int j = 0; j < h->fe.n_mels; ++j) h->mel_max_taps = tb.mel_cnt[j] > h->mel_max_taps ? tb.mel_cnt[j] : h->mel_max_taps;
         std::vector<Fe2MelPlan> plan(1);
         const std::string e2 = fe2_build_mel_plan(h->fe, fb.data(), plan.data());
         if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
@@ -991,10 +994,10 @@ static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float
     static const int blk_env = [] { const char* e = getenv("NWW_FE_BLOCK"); return e ? atoi(e) : 256; }();
     static const int wg_env = [] { const char* e = getenv("NWW_FE_WGS_PER_CU"); return e ? atoi(e) : 3; }();
     static const int ver_env = [] { const char* e = getenv("NWW_FE_V"); return e ? atoi(e) : 2; }();      // 1: barrier-per-stage kernel
-    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 1; }();    // 0: sparse VALU mel
+    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();    // 2: register filters, 1: MFMA tiles, 0: sparse LDS loop
     hipError_t e = ver_env == 1
         ? fe_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s)
-        : fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, 256, h->cu_count * wg_env, s);
+        : fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * wg_env, s);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }
@@ -1194,9 +1197,24 @@ struct RcclApi {
 static RcclApi& rccl() {
     static RcclApi api = [] {
         RcclApi a;
-        for (const char* name : {"librccl.so", "librccl.so.1"}) {            // already in the process?
-            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        // 1. the RCCL that sits next to the HIP runtime this process actually runs on (a PyTorch process carries its own
+        //    libamdhip64 + librccl pair; mixing one stack's RCCL with the other's HSA runtime fails at communicator
+        //    creation), 2. one that is already loaded, 3. the system library
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.find_last_of('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* name : {"librccl.so", "librccl.so.1"}) {
+                    a.lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (a.lib) break;
+                }
+            }
+        }
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
             if (a.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         }
         if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!a.lib) a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);

@@ -11,6 +11,7 @@ struct TrunkArgs {
     int B, H, W, act;
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
     int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
+    int skew = 0;                                      // experiment: s_sleep(127) units for the CU's second workgroup
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;

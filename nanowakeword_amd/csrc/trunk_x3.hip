@@ -155,7 +155,14 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
 // A workgroup keeps ONE strip index for its whole life, so the zero halos written once stay valid.  (Walking whole clips
 // strip by strip instead - equal work per workgroup, halo rows re-zeroed per item - measured 0.417 vs 0.406 ms.)
 template <int ACT, int PRODUCTS, bool BN, int NW>
-__global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
+__device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
+    // conv2's bf16 MFMAs overlap with the SIMD's other wave's VALU / LDS work only when their accumulators live in
+    // AGPRs (tools/ubench/mfma_valu_overlap.hip: max(a, b) instead of a + b).  hipcc picks the VGPR form for kernels
+    // bounded to <= 256 registers unless something mentions an AGPR, and once AGPRs are in play it splits a 256-register
+    // budget 128 / 128 - too few VGPRs for the 108 registers of conv2 weight fragments (it then parks them in AGPRs and
+    // copies them back before every MFMA: measured 0.46 vs 0.39 ms).  The 4-wave form has a 512-register budget, so
+    // 224 VGPRs + 32 accumulator AGPRs = 256 registers, two workgroups per CU, works: the empty asm flips the form.
+    if constexpr (NW == 4) { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }
     constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
@@ -282,6 +289,12 @@ __global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
     const bool full1 = (W1 & 15) == 0;
 
     const int b0 = (int)blockIdx.x / S, bstep = (int)gridDim.x / S;
+    if (a.skew > 0) {
+        // two 4-wave workgroups per CU run identical items and would stay in the same phase (conv1: VALU/latency-heavy,
+        // conv2: matrix-pipe-bound) forever; delay the one that got the SIMD's second wave slot by part of an item once
+        const int slot = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 1;
+        for (int k = 0; k < slot * a.skew; ++k) __builtin_amdgcn_s_sleep(127);
+    }
     __syncthreads();
     if (b0 < a.B) load_plane_sync(a.in + (size_t)b0 * H * W + in_off);
     __syncthreads();
@@ -318,8 +331,12 @@ __global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
                 conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
                 t += 1;
             }
-            for (; t + 1 < t_end; t += 2)
-                conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+            if (NW == 8)                                     // the 4-wave shape has no registers for a second tile in flight
+                for (; t + 1 < t_end; t += 2)
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+            else
+                for (; t + 1 < t_end; t += 1)
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
             if (t < t_end)
                 conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
         }
@@ -329,6 +346,19 @@ __global__ void __launch_bounds__(64 * NW, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
         }
         __syncthreads();                                     // A1 is free for the next item's P1, In holds its rows
     }
+}
+
+// Two launch shapes of the same body (an attribute cannot depend on a template parameter):
+//   8 waves, one workgroup per CU, 256 registers per lane, MFMAs in the VGPR form
+//   4 waves, two workgroups per CU (three row strips), 224 VGPRs + AGPR accumulators
+template <int ACT, int PRODUCTS, bool BN, int NW>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
+    static_assert(NW == 8, "8-wave shape");
+    cnn_trunk_x3_body<ACT, PRODUCTS, BN, 8>(a);
+}
+template <int ACT, int PRODUCTS, bool BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) cnn_trunk_x3_kernel4(TrunkArgs a) {
+    cnn_trunk_x3_body<ACT, PRODUCTS, BN, 4>(a);
 }
 }  // namespace
 
@@ -353,8 +383,10 @@ int trunk_x3_pick_strips(int H, int W) {
 hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, hipStream_t s) {
     static const int dbg = [] { const char* e = getenv("NWW_TRUNK_DBG"); return e ? atoi(e) : 0; }();
     static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    static const int skew = [] { const char* e = getenv("NWW_X3_SKEW"); return e ? atoi(e) : 0; }();
     TrunkArgs aa = a;
     aa.dbg = dbg;
+    aa.skew = skew;
     int S = trunk_x3_pick_strips(a.H, a.W);
     if (force_strips > S && force_strips <= a.H / 4) S = force_strips;
     if (S < 1) return hipErrorInvalidValue;
@@ -375,8 +407,14 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);  \
     }
+#define X3T_LAUNCH4(ACTV, PRODV, BNV)                                                                              \
+    {                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_x3_kernel4<ACTV, PRODV, BNV>), lds);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((cnn_trunk_x3_kernel4<ACTV, PRODV, BNV>), dim3(grid), dim3(256), lds, s, aa);           \
+    }
 #define X3T_NW(ACTV, PRODV, BNV)                                                                                   \
-    if (nw == 4) X3T_LAUNCH(ACTV, PRODV, BNV, 4) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
+    if (nw == 4) X3T_LAUNCH4(ACTV, PRODV, BNV) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
 #define X3T_BN(ACTV, PRODV)                                                                                        \
     if (bn) X3T_NW(ACTV, PRODV, true) else X3T_NW(ACTV, PRODV, false)
 #define X3T_ACT(ACTV)                                                                                              \
@@ -388,6 +426,7 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
         default: return hipErrorInvalidValue;
     }
 #undef X3T_LAUNCH
+#undef X3T_LAUNCH4
 #undef X3T_NW
 #undef X3T_BN
 #undef X3T_ACT

@@ -13,6 +13,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that hand torch tensors to the library (RCCL communicator, device pointers) need ONE ROCm stack in the
+    # process: importing torch first makes libnwwhip.so bind to the HIP runtime PyTorch ships, like bench.py does.
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
 
 
 def _hip_device_available() -> bool:

@@ -66,8 +66,18 @@ __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __re
     o[0] = (uint16_t)(hi >> 16); o[16] = (uint16_t)(mid >> 16); o[32] = (uint16_t)(lo >> 16);
 }
 
-template <int CB>
-__global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
+// NST = register stages of global loads in flight (k-tiles of lookahead).  The bulk shapes use 1 (two workgroups per
+// CU cover each other); the small-M instance <1, 4> (M <= 64: the interpreter's B = 1 .. 16 calls) is pure load
+// latency - 25 dependent k-tiles of ~2.4 us each - and runs 32-column tiles (4x the workgroups) with four k-tiles in
+// flight.  Per-output summation order is the same in every instance: same k-tile sequence, same products, same
+// split-K chunks - results stay bit-identical across batch sizes.
+template <int CB, int NST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gemm_x3_kernel(GemmArgs g) {
+    // accumulators in AGPRs: two workgroups share a CU, and one's bf16 MFMAs run beside the other's split/stage VALU
+    // work only in the AGPR form (tools/ubench/mfma_valu_overlap.hip).  The empty asm flips hipcc's
+    // choice; the plain launch bound keeps the register file unsplit, amdgpu_num_vgpr caps the VGPR side so that
+    // VGPRs + accumulator AGPRs <= 256 (two waves per SIMD).
+    { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }
     constexpr int BN = 32 * CB;
     constexpr int WPIECES = BN * 12;                           // 16-byte pieces of a W tile (32 k x 3 terms per row)
     constexpr int WLD = (WPIECES + 255) / 256;
@@ -144,12 +154,12 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
     // One LDS stage per workgroup (53 KB for BN = 128, so two workgroups share a CU and cover each other's staging
-    // phases).  Global loads run TWO k-tiles ahead in two register stages: with one tile of lookahead a load had only
-    // one tile's MFMAs (~1.5k clocks) to land and the loop was bound by HBM latency (fc1: 7.5k clocks per k-tile).
-    constexpr bool DEEP = CB <= 4;                             // wider tiles have no registers left for a second stage
-    Stage st0, st1;
-    if (kt_begin < kt_end) gload(kt_begin, st0);
-    if (DEEP && kt_begin + 1 < kt_end) gload(kt_begin + 1, st1);
+    // phases); global loads run NST k-tiles ahead in NST register stages.
+    Stage st[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q)
+        if (kt_begin + q < kt_end) gload(kt_begin + q, st[q]);
+    const bool has_rows = bm + wave * 32 < g.M;                  // waves whose 32 rows lie beyond M only help with the staging
     const int a_off = (wave * 32 + i) * X3_ROW + 16 * h, w_off = i * X3_ROW + 16 * h;
     auto multiply = [&]() {
 #pragma unroll
@@ -172,18 +182,16 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmArgs g) {
             }
         }
     };
-    for (int kt = kt_begin; kt < kt_end; kt += DEEP ? 2 : 1) {
-        __syncthreads();                                       // everyone is done reading the previous tile
-        lstore(0, st0);
-        __syncthreads();
-        if (kt + (DEEP ? 2 : 1) < kt_end) gload(kt + (DEEP ? 2 : 1), st0);
-        multiply();
-        if (DEEP && kt + 1 < kt_end) {
-            __syncthreads();
-            lstore(0, st1);
-            __syncthreads();
-            if (kt + 3 < kt_end) gload(kt + 3, st1);
-            multiply();
+    for (int kt = kt_begin; kt < kt_end; kt += NST) {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            if (kt + q < kt_end) {
+                __syncthreads();                               // everyone is done reading the previous tile
+                lstore(0, st[q]);
+                __syncthreads();
+                if (kt + q + NST < kt_end) gload(kt + q + NST, st[q]);
+                if (NST == 1 || has_rows) multiply();
+            }
         }
     }
 
@@ -247,18 +255,23 @@ bool gemm_x3_usable(const GemmArgs& g) {
 
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     static const int force_cb = [] { const char* e = getenv("NWW_X3_CB"); return e ? atoi(e) : 0; }();
-    const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);
-    const int bn = 32 * cb;
     const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
     GemmArgs a = g;
     a.splitk = sk;
+    if (g.M <= 64) {                                           // small batches: latency, not throughput (see the kernel comment)
+        dim3 grid1(1, (g.N + 31) / 32, sk);
+        hipLaunchKernelGGL((gemm_x3_kernel<1, 4>), grid1, dim3(256), (size_t)(X3_BM + 32) * X3_ROW, s, a);
+        return hipGetLastError();
+    }
+    const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);
+    const int bn = 32 * cb;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
     const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;
 #define X3_LAUNCH(CBV)                                                                                             \
     case CBV: {                                                                                                    \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV>), lds);                     \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV, 1>), lds);                  \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((gemm_x3_kernel<CBV>), grid, dim3(256), lds, s, a);                                     \
+        hipLaunchKernelGGL((gemm_x3_kernel<CBV, 1>), grid, dim3(256), lds, s, a);                                  \
         break;                                                                                                     \
     }
     switch (cb) {

@@ -76,6 +76,7 @@ struct nww_handle {
     int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
     EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
     void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
+    unsigned char* pin_in = nullptr; unsigned char* pin_out = nullptr;   // pinned staging for small host-pointer calls
     int comm_rank = 0, comm_world = 1;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
@@ -341,6 +342,8 @@ extern "C" int nww_destroy(nww_handle* h) {
     nww_stream_close(h);
     nww_emb_close(h);
     nww_comm_destroy(h);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->d_weights) (void)hipFree(h->d_weights);
     for (auto& kv : h->x3_weights) (void)hipFree(kv.second);
     if (h->d_tables) (void)hipFree(h->d_tables);
@@ -1081,10 +1084,40 @@ extern "C" int nww_frontend(nww_handle* h, const int16_t* pcm, int32_t B, int32_
     return nww_frontend_ex(h, pcm, B, N, logmel_out, nullptr, frames_out);
 }
 
+// Small host-pointer calls (the interpreter's B = 1 .. 16 predict() path) go through pinned staging buffers: a
+// hipMemcpyAsync from pageable memory costs ~40-60 us of runtime staging and synchronisation per call, a memcpy into a
+// pinned buffer plus a true async copy ~10.
+constexpr size_t PIN_BYTES = 1 << 20;
+static int h2d_small(nww_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes <= PIN_BYTES) {
+        if (!h->pin_in) HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), PIN_BYTES, hipHostMallocDefault));
+        std::memcpy(h->pin_in, src, bytes);      // host-pointer entry points synchronise before returning: the buffer is free again
+        HIP_TRY(h, hipMemcpyAsync(dst, h->pin_in, bytes, hipMemcpyHostToDevice, s));
+        return NWW_OK;
+    }
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    return NWW_OK;
+}
+
 static int copy_out(nww_handle* h, int B, float* logits, float* probs, float* emb, hipStream_t s) {
-    if (logits) HIP_TRY(h, hipMemcpyAsync(logits, h->d_logits, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (probs) HIP_TRY(h, hipMemcpyAsync(probs, h->d_probs, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (emb) HIP_TRY(h, hipMemcpyAsync(emb, h->d_emb, (size_t)B * h->cfg.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, s));
+    const size_t nb = (size_t)B * sizeof(float), ne = (size_t)B * h->cfg.embedding_dim * sizeof(float);
+    const size_t need = (logits ? nb : 0) + (probs ? nb : 0) + (emb ? ne : 0);
+    if (need <= PIN_BYTES) {
+        if (!h->pin_out) HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), PIN_BYTES, hipHostMallocDefault));
+        size_t off = 0;
+        unsigned char *pl = nullptr, *pp = nullptr, *pe = nullptr;
+        if (logits) { pl = h->pin_out + off; off += nb; HIP_TRY(h, hipMemcpyAsync(pl, h->d_logits, nb, hipMemcpyDeviceToHost, s)); }
+        if (probs) { pp = h->pin_out + off; off += nb; HIP_TRY(h, hipMemcpyAsync(pp, h->d_probs, nb, hipMemcpyDeviceToHost, s)); }
+        if (emb) { pe = h->pin_out + off; off += ne; HIP_TRY(h, hipMemcpyAsync(pe, h->d_emb, ne, hipMemcpyDeviceToHost, s)); }
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (logits) std::memcpy(logits, pl, nb);
+        if (probs) std::memcpy(probs, pp, nb);
+        if (emb) std::memcpy(emb, pe, ne);
+        return NWW_OK;
+    }
+    if (logits) HIP_TRY(h, hipMemcpyAsync(logits, h->d_logits, nb, hipMemcpyDeviceToHost, s));
+    if (probs) HIP_TRY(h, hipMemcpyAsync(probs, h->d_probs, nb, hipMemcpyDeviceToHost, s));
+    if (emb) HIP_TRY(h, hipMemcpyAsync(emb, h->d_emb, ne, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return NWW_OK;
 }
@@ -1171,7 +1204,7 @@ extern "C" int nww_stream_push(nww_handle* h, const int16_t* chunk, float* logit
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = h->own_stream;
     const int S = h->ring_S;
-    HIP_TRY(h, hipMemcpyAsync(h->d_chunk, chunk, (size_t)S * h->ring_hop * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    { int rcs = h2d_small(h, h->d_chunk, chunk, (size_t)S * h->ring_hop * sizeof(int16_t), s); if (rcs) return rcs; }
     int rc = stream_push_dev(h, h->d_chunk, h->d_logits, h->d_probs, s);
     if (rc) return rc;
     return copy_out(h, S, logits, probs, nullptr, s);
@@ -1509,7 +1542,8 @@ extern "C" int nww_forward_pcm(nww_handle* h, const int16_t* pcm, int32_t B, int
     rc = ensure_ws(h, B, N);
     if (rc) return rc;
     hipStream_t s = h->own_stream;
-    HIP_TRY(h, hipMemcpyAsync(h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    rc = h2d_small(h, h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), s);
+    if (rc) return rc;
     rc = forward_pcm_dev(h, h->d_pcm, B, N, h->d_logits, h->d_probs, s);
     if (rc) return rc;
     return copy_out(h, B, logits, probs, nullptr, s);
@@ -1523,7 +1557,8 @@ extern "C" int nww_forward_features_ex(nww_handle* h, const float* feats, int32_
     rc = ensure_ws(h, B, 0);
     if (rc) return rc;
     hipStream_t s = h->own_stream;
-    HIP_TRY(h, hipMemcpyAsync(h->d_feats, feats, (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = h2d_small(h, h->d_feats, feats, (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float), s);
+    if (rc) return rc;
     prof_begin(h);
     rc = run_head(h, h->d_feats, B, h->d_logits, h->d_probs, s);
     if (rc) return rc;

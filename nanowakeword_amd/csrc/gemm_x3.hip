@@ -27,14 +27,18 @@ namespace {
 constexpr int X3_ROW = 208;                      // bytes per LDS row: 3 terms x 32 k x bf16 + 16 pad (conflict-free b128 reads)
 constexpr int X3_BM = 128;
 
-__device__ __forceinline__ float x3_act(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return fmaxf(v, 0.0f);
-        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        case ACT_SILU: return v / (1.0f + expf(-v));
-        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        default: return v;
-    }
+// 1 / (1 + e^-v) on the hardware exp2 and reciprocal (1 ulp each; relative error <= 3e-7): 4 instructions where
+// expf + IEEE division take ~35 - the epilogue of a short-K GEMM is as long as its main loop otherwise.
+__device__ __forceinline__ float x3_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+template <int ACT>
+__device__ __forceinline__ float x3_act(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_SILU) return v * x3_sigmoid(v);
+    if (ACT == ACT_SIGMOID) return x3_sigmoid(v);
+    return v;
 }
 
 // x -> three float32 bit patterns whose upper halves are the bf16 terms (lo is truncated when packed; it has at
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __re
 // latency - 25 dependent k-tiles of ~2.4 us each - and runs 32-column tiles (4x the workgroups) with four k-tiles in
 // flight.  Per-output summation order is the same in every instance: same k-tile sequence, same products, same
 // split-K chunks - results stay bit-identical across batch sizes.
-template <int CB, int NST>
+template <int CB, int NST, int ACT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gemm_x3_kernel(GemmArgs g) {
     // accumulators in AGPRs: two workgroups share a CU, and one's bf16 MFMAs run beside the other's split/stage VALU
     // work only in the AGPR form (tools/ubench/mfma_valu_overlap.hip).  The empty asm flips hipcc's
@@ -212,15 +216,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
         }
         const float bias = g.bias ? g.bias[n] : 0.0f;
         const float al2 = g.alpha ? g.alpha[n] : 1.0f, be2 = g.alpha ? g.beta[n] : 0.0f;
+        // lane (column n, row half h): rows m0 + (r & 3) + 8 (r >> 2) + 4 h.  Uniform choices (residual, full tile) are made
+        // once, outside the sixteen-row loops; the activation is a template parameter (the run-time switch, per-element
+        // bounds checks and the precise expf / division of the first version made the epilogue of a K = 144 GEMM as
+        // long as its main loop: 103 M -> 54 M VALU instructions on the Conformer's linear1).
+        float* cp = g.C + (size_t)(m0 + 4 * h) * g.ldc + n;
+        const float* rp = g.res ? g.res + (size_t)(m0 + 4 * h) * g.ldres + n : nullptr;
+        const bool full = m0 + 32 <= g.M;
+        auto finish = [&](float a) {
+            float v = a + bias;
+            v = v * al2 + be2;                 // alpha = 1, beta = 0 without a folded BatchNorm: exact
+            return x3_act<ACT>(v);
+        };
+        if (full && !rp) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < g.M) {
-                float v = acc[c][r] + bias;
-                if (g.alpha) v = v * al2 + be2;
-                v = x3_act(v, g.act);
-                if (g.res) v = g.res[(size_t)m * g.ldres + n] + g.rscale * v;
-                g.C[(size_t)m * g.ldc + n] = v;
+            for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = finish(acc[c][r]);
+        } else if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t ro = (size_t)((r & 3) + 8 * (r >> 2));
+                cp[ro * g.ldc] = rp[ro * g.ldres] + g.rscale * finish(acc[c][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mo = (r & 3) + 8 * (r >> 2);
+                if (m0 + 4 * h + mo < g.M) {
+                    float v = finish(acc[c][r]);
+                    if (rp) v = rp[(size_t)mo * g.ldres] + g.rscale * v;
+                    cp[(size_t)mo * g.ldc] = v;
+                }
             }
         }
     }
@@ -258,26 +283,39 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
     GemmArgs a = g;
     a.splitk = sk;
+#define X3_GO(CBV, NSTV, ACTV, GRID, LDSB)                                                                         \
+    {                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV, NSTV, ACTV>), LDSB);        \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((gemm_x3_kernel<CBV, NSTV, ACTV>), GRID, dim3(256), LDSB, s, a);                        \
+    }
+#define X3_ACT(CBV, NSTV, GRID, LDSB)                                                                              \
+    switch (sk > 1 ? (int)ACT_NONE : a.act) {      /* split-K partials take no epilogue: one instance serves them all */ \
+        case ACT_RELU: X3_GO(CBV, NSTV, ACT_RELU, GRID, LDSB) break;                                               \
+        case ACT_GELU: X3_GO(CBV, NSTV, ACT_GELU, GRID, LDSB) break;                                               \
+        case ACT_SILU: X3_GO(CBV, NSTV, ACT_SILU, GRID, LDSB) break;                                               \
+        case ACT_SIGMOID: X3_GO(CBV, NSTV, ACT_SIGMOID, GRID, LDSB) break;                                         \
+        default: X3_GO(CBV, NSTV, ACT_NONE, GRID, LDSB) break;                                                     \
+    }
     if (g.M <= 64) {                                           // small batches: latency, not throughput (see the kernel comment)
         dim3 grid1(1, (g.N + 31) / 32, sk);
-        hipLaunchKernelGGL((gemm_x3_kernel<1, 4>), grid1, dim3(256), (size_t)(X3_BM + 32) * X3_ROW, s, a);
+        const size_t lds1 = (size_t)(X3_BM + 32) * X3_ROW;
+        X3_ACT(1, 4, grid1, lds1)
         return hipGetLastError();
     }
     const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);
     const int bn = 32 * cb;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
     const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;
-#define X3_LAUNCH(CBV)                                                                                             \
-    case CBV: {                                                                                                    \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV, 1>), lds);                  \
-        if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((gemm_x3_kernel<CBV, 1>), grid, dim3(256), lds, s, a);                                  \
-        break;                                                                                                     \
-    }
     switch (cb) {
-        X3_LAUNCH(2) X3_LAUNCH(3) X3_LAUNCH(4) X3_LAUNCH(5) X3_LAUNCH(6)
+        case 2: X3_ACT(2, 1, grid, lds) break;
+        case 3: X3_ACT(3, 1, grid, lds) break;
+        case 4: X3_ACT(4, 1, grid, lds) break;
+        case 5: X3_ACT(5, 1, grid, lds) break;
+        case 6: X3_ACT(6, 1, grid, lds) break;
         default: return hipErrorInvalidValue;
     }
-#undef X3_LAUNCH
+#undef X3_ACT
+#undef X3_GO
     return hipGetLastError();
 }

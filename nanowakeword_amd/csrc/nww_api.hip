@@ -425,12 +425,19 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
-    // Long-K contractions (fc1 of the CNN head: K = 12 800) run on the bf16 matrix cores by exact operand splitting
-    // (gemm_x3.hip) with a fine split-K; short-K shapes stay on the float32 MFMA kernel, which hides its load latency
-    // better with its smaller tiles.  The choice depends on (N, K) only, so batch invariance is kept.
-    // NWW_GEMM_X3 = 0: never, 2: every shape with N, K >= 32 (experiments).
+    // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
+    // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
+    // (N,K) = (576,144) 0.32 / 0.46, (144,576) 0.41 / 0.51, (432,144) 0.26 / 0.33, (288,144) 0.18 / 0.24,
+    // (144,64) 0.05 / 0.07, (384,64) 0.23 / 0.29, (128,12800) 0.09 / 0.14 - and stay on the float32 MFMA kernel for the
+    // small square ones, (144,144) 0.23 / 0.18, whose single padded column tile wastes the wide kernel.  Long-K layers
+    // get a fine split-K.  The choice depends on (N, K) only, so batch invariance is kept.
+    // NWW_GEMM_X3 = 0: never, 2: every shape with N, K >= 32, 3: the round-1 rule (K >= 4096 only).
     static const int x3_mode = [] { const char* e = getenv("NWW_GEMM_X3"); return e ? atoi(e) : 1; }();
-    const bool use_x3 = x3_mode == 2 ? (N >= 32 && K >= 32) : (x3_mode == 1 && p.h->conv_products != 0 && K >= 4096 && N >= 64 && N <= 256);
+    const bool small_square = N <= 160 && K > 64 && K <= 160;
+    const bool use_x3 = p.h->conv_products != 0 &&
+                        (x3_mode == 2 ? (N >= 32 && K >= 32)
+                         : x3_mode == 3 ? (K >= 4096 && N >= 64 && N <= 256)
+                         : (x3_mode == 1 && N >= 64 && K >= 32 && !small_square));
     const void* wx3 = nullptr;
     if (use_x3) {
         auto it = p.h->x3_weights.find(W);
@@ -451,7 +458,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
         g.Wx3 = wx3;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
-        if (wx3 && x3_mode == 1) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
+        if (wx3 && x3_mode != 2 && K >= 4096) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
         g.splitk_ws = r.splitk_ws;
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
         return launch_gemm(g, r.stream);

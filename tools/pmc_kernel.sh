@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes (instruction mix, stall breakdown, LDS / MFMA busy) for every kernel whose name contains $1, over bench.py.
-# usage (GPU box): bash tools/pmc_kernel.sh <kernel-substring> [outdir-tag] [extra bench args...]
+# usage (GPU box): [PMC_CMD='python tools/bench_configs.py C5'] bash tools/pmc_kernel.sh <kernel-substring> [outdir-tag]
 K=$1; TAG=${2:-pmc_$1}; shift; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 run() {
   n=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-extras $EXTRA > $OUT/$n.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -o p -- ${PMC_CMD:-python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-extras} > $OUT/$n.log 2>&1
   python - <<PY
 import csv
 from collections import defaultdict
@@ -15,7 +15,7 @@ per = defaultdict(list)
 for row in csv.DictReader(open("$OUT/$n/p_counter_collection.csv")):
     if "$K" in row["Kernel_Name"]:
         per[row["Counter_Name"]].append(float(row["Counter_Value"]))
-print("$K $n", {k: max(v) for k, v in per.items()})
+print("$K $n", {k: (max(v), len(v)) for k, v in per.items()})
 PY
 }
 run mix SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_BRANCH

@@ -104,16 +104,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
     const int lr = tid >> 3, lq = tid & 7;
     const float* arow[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) arow[q] = g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
+    for (int q = 0; q < 4; ++q)
+        arow[q] = g.a_blocked ? g.A + ((size_t)(bm >> 7) * g.a_blocked * 128 + lr + 32 * q) * 32 + 4 * lq
+                              : g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
+    const int a_kstep = g.a_blocked ? 128 * 32 : 32;           // floats between consecutive k-tiles of a row
     struct Stage { float4 a[4]; uint4 w[WLD]; };
     auto gload = [&](int kt, Stage& st) {
         const int k = kt * 32 + 4 * lq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (k + 4 <= g.K) {
-                st.a[q] = *reinterpret_cast<const float4*>(arow[q] + kt * 32);
+                st.a[q] = *reinterpret_cast<const float4*>(arow[q] + (size_t)kt * a_kstep);
             } else {                                           // K tail: element-wise, zero beyond K
-                const float* p = arow[q] + kt * 32;
+                const float* p = arow[q] + (size_t)kt * a_kstep;
                 st.a[q].x = k + 0 < g.K ? p[0] : 0.0f; st.a[q].y = k + 1 < g.K ? p[1] : 0.0f;
                 st.a[q].z = k + 2 < g.K ? p[2] : 0.0f; st.a[q].w = k + 3 < g.K ? p[3] : 0.0f;
             }
@@ -274,7 +277,7 @@ static int x3_pick_cb(int N) {
 }
 
 bool gemm_x3_usable(const GemmArgs& g) {
-    return g.Wx3 != nullptr && g.N >= 32 && g.K >= 32 && (g.lda % 4 == 0) &&
+    return g.Wx3 != nullptr && g.N >= 32 && g.K >= 32 && (g.lda % 4 == 0) && (!g.a_blocked || g.K % 32 == 0) &&
            ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
 }
 

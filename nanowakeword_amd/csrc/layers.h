@@ -45,6 +45,10 @@ struct GemmArgs {
     // W pre-split into three bf16 terms ([N][ceil(K/16)][3][16], gemm_x3.hip); when set the contraction runs on the
     // bf16 matrix cores with exact operand splitting (float32-equivalent), else on v_mfma_f32_32x32x2_f32
     const void* Wx3 = nullptr;
+    // > 0 (split-operand kernel only): A is stored as [ceil(M/128)][a_blocked = K/32][128][32] tiles (written that way by
+    // the fused conv trunk) instead of row-major - every tile load is one contiguous 16 KB block.  With row-major A
+    // (row stride 51 KB for fc1) the same loads reach 2.5-2.9 TB/s (tools/ubench/strided_read.hip)
+    int a_blocked = 0;
     // dual GEMM (BcResNet block): C = (A2 W2^T * alpha2 + beta2) + rscale * act((A W^T + bias) * alpha + beta), the second
     // product (shortcut branch) computed by the same workgroup instead of a separate GEMM + a residual round trip
     const float* A2 = nullptr; int lda2 = 0; const float* W2 = nullptr; int K2 = 0;
@@ -57,6 +61,8 @@ struct GemmArgs {
     int dw_H = 0, dw_W = 0, dw_Ho = 0, dw_Wo = 0, dw_sh = 1, dw_sw = 1;
 };
 size_t gemm_x3_weight_bytes(int N, int K);
+// wave-specialised form (gemm_x3s.hip): producer waves stage + split, consumer waves multiply; same results bit for bit
+hipError_t launch_gemm_x3s(const GemmArgs& g, hipStream_t s);
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);
 bool gemm_x3_usable(const GemmArgs& g);
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s);

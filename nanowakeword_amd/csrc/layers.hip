@@ -257,7 +257,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         return hipGetLastError();
     }
     if (!g.A2 && gemm_x3_usable(g)) {
-        hipError_t e = launch_gemm_x3(g, s);
+        // M <= 64: the latency-oriented instance of gemm_x3.hip.  NWW_X3S=1 runs larger M on the wave-specialised kernel
+        // (gemm_x3s.hip; bit-identical results, measured slower: fc1 0.104 vs 0.091 ms, Conformer linear1 0.42 vs 0.30).
+        static const int use_x3s = [] { const char* e = getenv("NWW_X3S"); return e ? atoi(e) : 0; }();
+        hipError_t e = (use_x3s && g.M > 64) ? launch_gemm_x3s(g, s) : launch_gemm_x3(g, s);
         if (e != hipSuccess) return e;
         if (g.splitk > 1 && g.splitk_ws) {
             const size_t total = (size_t)g.M * g.N;

@@ -63,6 +63,8 @@ struct nww_handle {
     size_t buf_per_clip[6] = {0, 0, 0, 0, 0, 0};   // floats per clip of each workspace buffer
     // workspace (grown on demand)
     int cap_B = 0, cap_N = 0;
+    bool trunk_blocked = false;    // CNN head: the fused trunk writes fc1's A operand as [128][32] tiles (decided at plan time)
+    int cap_rows = 0;              // cap_B rounded up to 128: the blocked trunk -> fc1 buffer is written in 128-clip row blocks
     float* d_ws = nullptr;
     int16_t* d_pcm = nullptr;
     float* d_logmel = nullptr;     // [B][n_mels*frames]
@@ -423,7 +425,7 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 // rows_per_clip: M = B*rows_per_clip
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
-              int res_id = 99, float rscale = 1.f) {
+              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -450,6 +452,9 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         }
         if (it != p.h->x3_weights.end()) wx3 = it->second;
     }
+    // the producer may write A directly as this kernel's [128][32] tiles (the fused trunk feeding fc1)
+    const int a_blocked = (a_blocked_inout && *a_blocked_inout && wx3 && K % 32 == 0 && rows_per_clip == 1) ? K / 32 : 0;
+    if (a_blocked_inout) *a_blocked_inout = a_blocked != 0;
     if (K >= 2048 && (size_t)16 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)16 * rows_per_clip * N;
     p.add("gemm:" + name, [=](Run& r) {
         GemmArgs g;
@@ -457,6 +462,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
         g.Wx3 = wx3;
+        g.a_blocked = a_blocked;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
         if (wx3 && x3_mode != 2 && K >= 4096) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
         g.splitk_ws = r.splitk_ws;
@@ -484,7 +490,7 @@ static int trunk_fits(int C1, int H, int W) { int per_cu = 0; return trunk_pick_
 // fused conv1+pool+conv2+pool (trunk.hip) when the 1->16->32 pattern fits LDS; returns false if not applicable
 bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
                const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
-               const float* b2, const float* al2, const float* be2, int act) {
+               const float* b2, const float* al2, const float* be2, int act, const bool* out_blocked = nullptr) {
     static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
@@ -494,6 +500,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
     if ((x3 == 6 || x3 == 9) && trunk_x3_pick_strips(H, W) > 0) {
         p.add("trunk_x3:" + name, [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
+            if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
             return launch_cnn_trunk_x3(a, x3, max_grid, r.stream);
         });
         return true;
@@ -674,12 +681,21 @@ extern "C" int nww_finalize(nww_handle* h) {
             break;
         }
         case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
-            if (!add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
-                           p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act)) {
+            // trunk -> fc1 hand-over as the GEMM's own A tiles when both run on the split-operand path and the geometry allows
+            // 16-byte stores inside a 32-feature tile row (NWW_FC1_BLOCKED=0: plain [B][K] layout)
+            static const int want_blocked = [] { const char* e = getenv("NWW_FC1_BLOCKED"); return e ? atoi(e) : 1; }();
+            const int H2 = T / 4, W2 = F / 4;
+            h->trunk_blocked = want_blocked && (h->conv_products == 6 || h->conv_products == 9) && trunk_x3_pick_strips(T, F) > 0 &&
+                               (W2 % 4) == 0 && ((H2 * W2) % 4) == 0 && ((32 * H2 * W2) % 32) == 0;
+            const bool fused = add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
+                                         p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked);
+            if (!fused) {
+                h->trunk_blocked = false;
                 add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
                 add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
             }
-            add_gemm(p, "fc1", 1, 0, 1, 128, 32 * (T / 4) * (F / 4), p.W("model.fc1.weight"), p.W("model.fc1.bias"), act);
+            add_gemm(p, "fc1", 1, 0, 1, 128, 32 * H2 * W2, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, nullptr, nullptr, 99, 1.f,
+                     &h->trunk_blocked);
             set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
             break;
         }
@@ -940,7 +956,7 @@ static int ensure_ws(nww_handle* h, int B, int N) {
     const nww_config& c = h->cfg;
     size_t per = 0;
     for (int i = 0; i < 6; ++i) per += (h->buf_per_clip[i] + 3) & ~(size_t)3;
-    HIP_TRY(h, hipMalloc(&h->d_ws, (per * nB + 4) * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->d_ws, (per * (size_t)((nB + 127) / 128 * 128) + 4) * sizeof(float)));
     const int T = nN > 0 ? fe_num_frames(h->fe, nN) : 0;
     if (nN > 0) {
         HIP_TRY(h, hipMalloc(&h->d_pcm, (size_t)nB * nN * sizeof(int16_t) + 16));
@@ -952,7 +968,7 @@ static int ensure_ws(nww_handle* h, int B, int N) {
     HIP_TRY(h, hipMalloc(&h->d_logits, (size_t)nB * sizeof(float) + 16));
     HIP_TRY(h, hipMalloc(&h->d_probs, (size_t)nB * sizeof(float) + 16));
     if (h->splitk_per_clip) HIP_TRY(h, hipMalloc(&h->d_splitk, h->splitk_per_clip * (size_t)nB * sizeof(float) + 16));
-    h->cap_B = nB; h->cap_N = nN;
+    h->cap_B = nB; h->cap_N = nN; h->cap_rows = (nB + 127) / 128 * 128;
     return NWW_OK;
 }
 
@@ -971,7 +987,7 @@ static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, flo
     size_t off = 0;
     for (int i = 0; i < 6; ++i) {
         r.buf[i] = h->d_ws + off;
-        off += ((h->buf_per_clip[i] + 3) & ~(size_t)3) * (size_t)h->cap_B;
+        off += ((h->buf_per_clip[i] + 3) & ~(size_t)3) * (size_t)h->cap_rows;
     }
     int id = 1;
     for (auto& st : h->plan) {

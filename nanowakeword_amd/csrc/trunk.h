@@ -12,6 +12,9 @@ struct TrunkArgs {
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
     int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
     int skew = 0;                                      // experiment: s_sleep(127) units for the CU's second workgroup
+    // > 0: write the output as the split-operand GEMM's A tiles instead of [B][C2][H/4][W/4]: 128-clip row blocks x
+    // out_blocked k-tiles of 32 features, each (row block, k-tile) a contiguous [128][32] float tile (gemm_x3.hip)
+    int out_blocked = 0;
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;

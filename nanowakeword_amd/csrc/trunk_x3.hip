@@ -90,7 +90,7 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
 template <int ACT, int PRODUCTS, bool BN, bool TWO>
 __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane_off, int rowB, int nX, int t,
                                                const bf16x8 (&bw)[27], float bias2, float al2, float be2,
-                                               float* outb, int i, int hi, int H2, int W2) {
+                                               float* outb, int i, int hi, int H2, int W2, int blk_kt, int blk_k0) {
     const int R0 = t / nX, X0 = t - R0 * nX;
     const int t1 = TWO ? t + 1 : t;
     const int R1 = t1 / nX, X1 = t1 - R1 * nX;
@@ -140,6 +140,10 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
         else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
         const int pcol = 8 * X + 4 * hi;
         float* dst = outb + ((size_t)i * H2 + R) * W2 + pcol;
+        if (blk_kt) {      // blocked: outb = the clip's row inside its 128-row block, k = feature index of (channel, row, column)
+            const int k = i * H2 * W2 + blk_k0 + R * W2 + pcol;
+            dst = outb + (size_t)(k >> 5) * (128 * 32) + (k & 31);
+        }
         if ((W2 & 3) == 0 && pcol + 3 < W2) {
             *reinterpret_cast<float4*>(dst) = o;
         } else {
@@ -315,6 +319,8 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
         __syncthreads();
         // ---------------- P2: conv2 on the bf16 MFMA; tiles in pairs, a lone tile alone
         float* outb = a.out + (size_t)b * C2 * H2 * W2 + out_off;
+        const int blk_kt = a.out_blocked, blk_k0 = (int)out_off;
+        if (blk_kt) outb = a.out + ((size_t)(b >> 7) * blk_kt * 128 + (b & 127)) * 32;
         float4 pre[4];
         const bool fetch = bnext < a.B;
         if (fetch && vec_in) {
@@ -328,17 +334,17 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
         if (!(a.dbg & 2)) {
             int t = t_begin;
             if (wave >= NW / 2 && t < t_end) {           // out of phase with the SIMD's other wave (see trunk.hip)
-                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
                 t += 1;
             }
             if (NW == 8)                                     // the 4-wave shape has no registers for a second tile in flight
                 for (; t + 1 < t_end; t += 2)
-                    conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
             else
                 for (; t + 1 < t_end; t += 1)
-                    conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
             if (t < t_end)
-                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2);
+                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
         }
         if (fetch) {
             if (vec_in) store_plane_regs(pre);

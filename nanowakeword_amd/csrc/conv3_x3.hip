@@ -1,0 +1,267 @@
+// conv3_x3.hip - Conv2d(32, Cout, 3, padding 1) (+ folded BN) + act (+ MaxPool2 | export-form AvgPool) on the bf16 matrix
+// cores by exact operand splitting: the third conv stage of the E2E mel-CNN (32 -> 64, un-pooled, avg-pool fused;
+// nanowakeword/modules/architectures.py:851-853) and of CRNN (32 -> 32, pooled; :217-225).
+//
+// Same arithmetic as conv2 of the fused trunk (trunk_x3.hip): every float32 value is hi + mid + lo, three bf16 numbers
+// holding its 24 significant bits exactly; the six largest of the nine bf16 x bf16 partial products go to
+// v_mfma_f32_32x32x16_bf16 with float32 accumulation (products < 2^-23 of the result are dropped).  The float32-MFMA
+// kernel this replaces (conv3x3_mfma_kernel, trunk.hip) spends 144 x 64 = 9216 matrix-pipe clocks per 32 pixel x 32
+// channel tile, this one 108 x 32 = 3456 - and on gfx950 the float32 MFMA runs at the VALU rate and blocks the VALU
+// while it runs, the bf16 one does neither.
+//
+// One workgroup (8 waves) = one (clip, 32-channel output group); a workgroup keeps its group for its whole life, so
+// the group's weights are split and laid out as MFMA B fragments in LDS once:
+//   Wt [tap 9][k-block 2][term 3][k-half 2][cout 32][8 cin] bf16 = 54 KB   (one 16-byte fragment per lane, consecutive)
+//   A3 [H + 3][W + 2] pixels x 208 B ([term 3][32 cin] bf16 + 16 B pad: conflict-free 16-byte fragment reads), zero halo
+// Per clip the 32 input planes are read once from HBM (coalesced), split, and stored channels-last into A3; a tile is
+// 2 rows x 16 columns (the accumulator's 4-register groups are 2x2 windows, as in the trunk); per tap and 16-channel
+// block a wave reads three fragments per tile and three weight fragments, issued one step ahead of the MFMAs.
+// The next clip's planes are fetched into registers under the MFMA loop (one pixel x 32 channels per thread).
+//
+// Measured (E2E mel-CNN, 16 x 25 x 32 -> 64 + avg-pool, B = 4096): 0.83 ms (float32 MFMA) -> 0.415 ms; B = 1: 63 -> 21 us.
+// Ablation of the 0.415: no MFMA loop 0.07, no epilogue 0.35, no LDS re-reads 0.40 - the loop runs at ~68 % of the
+// nominal bf16 matrix rate (0.184 ms for the 6 x 2 x 9 x 32 x 64 x 400 multiply-adds per clip) and LDS bandwidth is
+// not the limit; LDS capacity is (A3 107 KB + Wt 54 KB = one workgroup per CU, so staging / epilogue do not overlap).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "layers.h"
+#include "trunk.h"
+#include "conv_tile_epilogue.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int PS3 = 208;                 // bytes per A3 pixel
+constexpr int WT_BYTES = 9 * 2 * 3 * 1024;
+
+__device__ __forceinline__ void split3c(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+
+template <int ACT, bool POOL, bool AVG>
+__global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
+    constexpr int NW = 8, NTHR = 512, C1 = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int H = a.H, W = a.W, Wp = W + 2;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const int rowB = Wp * PS3;
+    const int a3_bytes = (H + 3) * rowB;
+    unsigned char* A3 = lds3;
+    unsigned char* Wt = lds3 + ((a3_bytes + 15) & ~15);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    const int ngroups = a.Cout / 32;
+    const int grp = (int)blockIdx.x % ngroups;                 // fixed for the workgroup's life
+    // ---- zero A3 (halo stays zero), split this group's weights into B fragments
+    for (int k = tid; k < a3_bytes / 4; k += NTHR) reinterpret_cast<uint32_t*>(A3)[k] = 0u;
+    for (int idx = tid; idx < 32 * C1 * 9; idx += NTHR) {      // (cout, cin, tap)
+        const int co = idx / (C1 * 9), r = idx - co * (C1 * 9), ci = r / 9, tap = r - ci * 9;
+        uint32_t th, tm, tl;
+        split3c(a.w[((size_t)(32 * grp + co) * C1 + ci) * 9 + tap], th, tm, tl);
+        const int kb = ci >> 4, kh = (ci >> 3) & 1, e = ci & 7;
+        unsigned char* d = Wt + ((tap * 2 + kb) * 3) * 1024 + (kh * 32 + co) * 16 + e * 2;
+        *reinterpret_cast<uint16_t*>(d) = (uint16_t)(th >> 16);
+        *reinterpret_cast<uint16_t*>(d + 1024) = (uint16_t)(tm >> 16);
+        *reinterpret_cast<uint16_t*>(d + 2048) = (uint16_t)(tl >> 16);
+    }
+    const int cout = 32 * grp + i;
+    const float bias = a.bias ? a.bias[cout] : 0.0f;
+    const float al = a.alpha ? a.alpha[cout] : 1.0f, be = a.alpha ? a.beta[cout] : 0.0f;
+    const bool bn = a.alpha != nullptr;
+    const int nRp = POOL ? H / 2 : (H + 1) / 2, nX = (W + 15) / 16, nT = nRp * nX;
+    const int t_base = nT / NW, t_rem = nT - t_base * NW;
+    const int t_begin = wave * t_base + min(wave, t_rem), t_end = t_begin + t_base + (wave < t_rem ? 1 : 0);
+    const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
+    const int lane_off = (dyi * Wp + xi) * PS3 + 16 * hi;      // the lane's pixel inside a tile, its 8 channels of a k-block
+    const unsigned char* wlane = Wt + lane * 16;
+
+    // Fused export-form AvgPool (full-height windows along x, _export/onnx.py:146-152).  A lane's registers 4k+q hold column 16X + 4k + 2hi + (q & 1) of rows 2R + (q >> 1),
+    // so the two rows of a column are added first (row 2R, then 2R + 1) and the window test runs once per column.
+    auto avg_epilogue = [&](const f32x16& acc, int R, int X, float* wsum, AvgWin aw) {
+        const bool row1 = 2 * R + 1 < H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v0 = acc[4 * k + dx] + bias, v1 = acc[4 * k + 2 + dx] + bias;
+                if (bn) { v0 = v0 * al + be; v1 = v1 * al + be; }
+                v0 = trunk_act<ACT>(v0);
+                v1 = trunk_act<ACT>(v1);
+                const int x = 16 * X + 4 * k + 2 * hi + dx;
+                const float col = x < W ? v0 + (row1 ? v1 : 0.0f) : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < aw.ow) wsum[j] += (unsigned)(x - j * aw.sw) < (unsigned)aw.kw ? col : 0.0f;
+            }
+    };
+
+    // conv for tile t (and t + 1 when TWO): 9 taps x 2 sixteen-channel blocks x 6 products
+    auto tiles = [&](int t, auto two_c, float* outb, float* wsum, AvgWin aw) {
+        constexpr bool TWO = decltype(two_c)::value;
+        const int R0 = t / nX, X0 = t - R0 * nX;
+        const int t1 = TWO ? t + 1 : t;
+        const int R1 = t1 / nX, X1 = t1 - R1 * nX;
+        const unsigned char* pa = A3 + lane_off + (2 * R0) * rowB + 16 * X0 * PS3;
+        const unsigned char* pb = A3 + lane_off + (2 * R1) * rowB + 16 * X1 * PS3;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        bf16x8 na[3], nb[3], nw[3];
+        auto fetch = [&](int step) {                           // step = tap * 2 + k-block
+            const int tap = step >> 1, kb = step & 1;
+            const int off = (tap / 3) * rowB + (tap % 3) * PS3 + 32 * kb;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 64 * tm);
+                if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + off + 64 * tm);
+                nw[tm] = *reinterpret_cast<const bf16x8*>(wlane + (step * 3 + tm) * 1024);
+            }
+        };
+        fetch(0);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            bf16x8 ca[3], cb[3], cw[3];
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; cw[tm] = nw[tm]; }
+            if (step + 1 < 18) fetch(step + 1);
+            __builtin_amdgcn_sched_barrier(0);                 // next step's LDS reads stay above this step's MFMAs
+            // terms 0 = hi, 1 = mid, 2 = lo; smallest products first (the order of trunk_x3's tap_mfma<6>)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], cw[1], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[2], cw[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[2], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], cw[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[1], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[0], acc0, 0, 0, 0);
+            if (TWO) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[1], cw[1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[2], cw[0], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[2], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[1], cw[0], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[0], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (AVG) {
+            avg_epilogue(acc0, R0, X0, wsum, aw);
+            if (TWO) avg_epilogue(acc1, R1, X1, wsum, aw);
+        } else {
+            conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
+            if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
+        }
+    };
+
+    // Staging: thread p < H*W owns pixel p.  Its 32 channel values (32 coalesced plane reads) are fetched into registers
+    // one clip AHEAD - the loads are in flight under the MFMA loop - then split and written channels-last as twelve
+    // 16-byte LDS stores.  (conv3_x3_fits guarantees H*W <= 512.)
+    const int b_first = (int)blockIdx.x / ngroups, b_step = (int)gridDim.x / ngroups;
+    const int HW = H * W;
+    const bool stager = tid < HW;
+    const int py = stager ? tid / W : 0, px = stager ? tid - py * W : 0;
+    unsigned char* my_px = A3 + ((py + 1) * Wp + px + 1) * PS3;
+    float pre[C1];
+    auto prefetch = [&](int b) {
+        if (stager && b < a.B) {
+            const float* xin = a.in + (size_t)b * C1 * HW + tid;
+#pragma unroll
+            for (int c = 0; c < C1; ++c) pre[c] = xin[(size_t)c * HW];
+        }
+    };
+    // per-lane avg-pool partials live in the 16 pad bytes of pixels 0..511 (never read by the MFMAs, never written by
+    // the staging) or, for small planes, in their own region behind the weights
+    const bool part_in_pads = (H + 3) * Wp >= NTHR;
+    float* my_part = reinterpret_cast<float*>(part_in_pads ? A3 + tid * PS3 + 192 : Wt + WT_BYTES + tid * 16);
+    const int part_stride = part_in_pads ? PS3 / 4 : 4;       // in floats, between consecutive threads
+    const float* part0 = reinterpret_cast<const float*>(part_in_pads ? A3 + 192 : Wt + WT_BYTES);
+    prefetch(b_first);
+    __syncthreads();
+    for (int b = b_first; b < a.B; b += b_step) {
+        if (stager) {
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                uint32_t th[4], tm[4], tl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3c(pre[8 * c8 + 2 * e], h0, m0, l0);
+                    split3c(pre[8 * c8 + 2 * e + 1], h1, m1, l1);
+                    th[e] = (h0 >> 16) | (h1 & 0xffff0000u);
+                    tm[e] = (m0 >> 16) | (m1 & 0xffff0000u);
+                    tl[e] = (l0 >> 16) | (l1 & 0xffff0000u);
+                }
+                *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
+                *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
+                *reinterpret_cast<uint4*>(my_px + 128 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+            }
+        }
+        __syncthreads();
+        prefetch(b + b_step);
+        float* outb = a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
+        float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+        const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow};
+        int t = t_begin;
+        for (; t + 1 < t_end; t += 2) tiles(t, std::true_type{}, outb, wsum, aw);
+        if (t < t_end) tiles(t, std::false_type{}, outb, wsum, aw);
+        if (AVG) *reinterpret_cast<float4*>(my_part) = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+        __syncthreads();                                       // every wave is done reading A3; partials visible
+        if (AVG) {
+            // fixed-order reduction: one lane per (channel, window) adds its channel's 2 * NW partials in (wave, half)
+            // order.  The next clip's staging may start meanwhile: it touches neither pads nor the partial region, and
+            // the barrier behind it separates these reads from the next partial writes.
+            const float inv = 1.0f / (float)(H * a.avg_kw);
+            for (int o = tid; o < 32 * a.avg_ow; o += NTHR) {
+                const int ci = o / a.avg_ow, j = o - ci * a.avg_ow;
+                float sum = 0.0f;
+                for (int w2 = 0; w2 < NW; ++w2)
+                    for (int h2 = 0; h2 < 2; ++h2) sum += part0[(size_t)((w2 * 64) + h2 * 32 + ci) * part_stride + j];
+                a.out[((size_t)b * a.Cout + 32 * grp + ci) * a.avg_ow + j] = sum * inv;
+            }
+        }
+    }
+}
+}  // namespace
+
+static size_t conv3_x3_a3_bytes(int H, int W) { return ((size_t)(H + 3) * (W + 2) * PS3 + 15) & ~(size_t)15; }
+
+size_t conv3_x3_lds_bytes(int H, int W) {
+    const bool part_in_pads = (H + 3) * (W + 2) >= 512;
+    return conv3_x3_a3_bytes(H, W) + WT_BYTES + (part_in_pads ? 0 : 512 * 16);
+}
+
+bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
+    if (Cout % 32 != 0 || H < 2 || W < 2 || H * W > 512) return false;
+    if (avg_ow > 0 && (pool || avg_ow > 4)) return false;
+    return conv3_x3_lds_bytes(H, W) <= 160 * 1024;
+}
+
+hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
+    if (!conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
+    const size_t lds = conv3_x3_lds_bytes(a.H, a.W);
+    const int ngroups = a.Cout / 32;
+    long want = (long)a.B * ngroups;
+    int grid = (int)(want < max_grid ? want : max_grid);
+    grid -= grid % ngroups;
+    if (grid < ngroups) grid = ngroups;
+#define C3_LAUNCH(ACTV, POOLV, AVGV)                                                                               \
+    {                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, POOLV, AVGV>), lds);      \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, AVGV>), dim3(grid), dim3(512), lds, s, a);                \
+    }
+#define C3_ACT(ACTV)                                                                                               \
+    if (a.avg_ow > 0) C3_LAUNCH(ACTV, false, true) else if (a.pool) C3_LAUNCH(ACTV, true, false) else C3_LAUNCH(ACTV, false, false)
+    switch (a.act) {
+        case ACT_RELU: C3_ACT(ACT_RELU) break;
+        case ACT_GELU: C3_ACT(ACT_GELU) break;
+        case ACT_SILU: C3_ACT(ACT_SILU) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef C3_ACT
+#undef C3_LAUNCH
+    return hipGetLastError();
+}

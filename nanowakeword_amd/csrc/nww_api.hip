@@ -523,6 +523,19 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
     p.need(out_id, avg_ow > 0 ? (size_t)Cout * avg_ow : (size_t)Cout * Ho * Wo);
     const int max_grid = p.h->cu_count;
+    // split-operand bf16 instance (conv3_x3.hip) under the same arithmetic switch as the fused trunk; the 9-product
+    // mode keeps the float32-MFMA kernel (the conv3 instance implements the 6-product form only)
+    static const int x3_enabled = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
+    if (x3_enabled && p.h->conv_products == 6 && conv3_x3_fits(H, W, Cout, avg_ow, pool)) {
+        const size_t lds = conv3_x3_lds_bytes(H, W);
+        const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : "conv3_x3:") + name, [=](Run& r) {
+            ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
+            return launch_conv3_x3(a, max_grid * per_cu, r.stream);
+        });
+        return true;
+    }
     p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
         ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
         a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;

@@ -25,18 +25,7 @@
 #include "layers.h"
 #include "trunk.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// The activation is a template parameter: a run-time switch costs ~5 scalar branches per element, and with one
-// wave per SIMD every taken branch is an exposed instruction-fetch bubble (measured: 2.7k cycles per 16 outputs).
-template <int ACT>
-__device__ __forceinline__ float trunk_act(float v) {
-    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
-    return v;
-}
+#include "conv_tile_epilogue.h"
 
 // Row strips.  A clip is cut into S strips of pooled output rows; strip s = pooled rows [R2a, R2b) needs the A1 rows
 // 2*R2a-1 .. 2*R2b (one halo row each side, recomputed by both neighbours at a seam) and for those the input rows
@@ -70,8 +59,6 @@ int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu) {
 
 // conv2 for tile t (and t+1 when TWO): 32 pixels x 32 channels x K = C1*9 each, A operands prefetched one channel
 // pair ahead of the MFMAs that consume them, then bias/BN/act, in-lane 2x2 max, half-wave exchange, 16-byte store.
-struct AvgWin { int kw, sw, ow; };       // windows [j*sw, j*sw + kw) along x, j < ow <= 4, covering all rows (oh == 1)
-
 template <int C1, int ACT, bool TWO, bool POOL = true, bool AVG = false>
 __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P1, int Wp1, int nX, int t,
                                             const float (&breg)[C1 * 9 / 2], float bias2, float al2, float be2,
@@ -119,86 +106,8 @@ __device__ __forceinline__ void conv2_tiles(const float* A1, int lane_off, int P
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int which = 0; which < (TWO ? 2 : 1); ++which) {
-        const f32x16& acc = which ? acc1 : acc0;
-        const int R = which ? R1 : R0, X = which ? X1 : X0;
-        if (POOL) {
-            float own[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[4 * k + q] + bias2;
-                    if (has_bn) v = v * al2 + be2;
-                    m = fmaxf(m, trunk_act<ACT>(v));
-                }
-                own[k] = m;                              // pooled column 8X + 2k + hi
-            }
-            // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7
-            const float s0 = hi ? own[0] : own[2], s1 = hi ? own[1] : own[3];
-            const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-            float4 o;
-            if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
-            else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
-            const int pcol = 8 * X + 4 * hi;
-            float* dst = outb + ((size_t)i * H2 + R + r_off) * W2 + pcol;
-            if ((W2 & 3) == 0 && pcol + 3 < W2) {
-                *reinterpret_cast<float4*>(dst) = o;
-            } else {
-                if (pcol + 0 < W2) dst[0] = o.x;
-                if (pcol + 1 < W2) dst[1] = o.y;
-                if (pcol + 2 < W2) dst[2] = o.z;
-                if (pcol + 3 < W2) dst[3] = o.w;
-            }
-        } else if (AVG) {
-            // fused AvgPool over full-height windows along x (the export form of AdaptiveAvgPool2d((1, ow)),
-            // _export/onnx.py:146-152): every lane adds its activated outputs to the windows they fall in; the
-            // caller reduces the per-lane sums in a fixed order.  The conv output itself never reaches HBM.
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[4 * k + q] + bias2;
-                    if (has_bn) v = v * al2 + be2;
-                    v = trunk_act<ACT>(v);
-                    const int y = 2 * (R + r_off) + (q >> 1), x = 16 * X + 4 * k + 2 * hi + (q & 1);
-                    if (y < H2 && x < W2) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < aw.ow && x >= j * aw.sw && x < j * aw.sw + aw.kw) wsum[j] += v;
-                    }
-                }
-        } else {
-            // un-pooled: quad k of this lane = columns 16X + 4k + 2hi + {0,1} of rows 2R, 2R+1.  Exchange with the
-            // partner half-wave so half 0 owns row 2R and half 1 row 2R+1, 4 consecutive columns per quad.
-            const int y = 2 * (R + r_off) + hi;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t2 = acc[4 * k + q] + bias2;
-                    if (has_bn) t2 = t2 * al2 + be2;
-                    v[q] = trunk_act<ACT>(t2);               // q = 2*dy + dx
-                }
-                const float s0 = hi ? v[0] : v[2], s1 = hi ? v[1] : v[3];   // half 0 gives away row 2R+1, half 1 row 2R
-                const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-                float4 o;
-                if (hi == 0) { o.x = v[0]; o.y = v[1]; o.z = r0; o.w = r1; }      // row 2R  : cols 4k..4k+3
-                else         { o.x = r0; o.y = r1; o.z = v[2]; o.w = v[3]; }      // row 2R+1: cols 4k..4k+3
-                const int col = 16 * X + 4 * k;
-                if (y < H2) {
-                    float* dst = outb + ((size_t)i * H2 + y) * W2 + col;
-                    if (col + 0 < W2) dst[0] = o.x;
-                    if (col + 1 < W2) dst[1] = o.y;
-                    if (col + 2 < W2) dst[2] = o.z;
-                    if (col + 3 < W2) dst[3] = o.w;
-                }
-            }
-        }
-    }
+    conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias2, al2, be2, has_bn, outb, i, hi, H2, W2, r_off, wsum, aw);
+    if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias2, al2, be2, has_bn, outb, i, hi, H2, W2, r_off, wsum, aw);
 }
 
 // STRIP = false is the whole-clip instance: its geometry is written as plain functions of H and W because the kernel

@@ -124,6 +124,7 @@ _BC = dict(model_type="bcresnet", input_shape=(32, 40), embedding_dim=16)
     ({"NWW_GRU16": "0"}, [_CRNN, _GRU, _CRNN_LSTM], [], [], False),                     # streaming recurrent kernels
     ({"NWW_E2E_FUSE_POOL": "0"}, [_E2E], ["avgpool"], [], False),                       # stand-alone export-form pool
     ({"NWW_TRUNK_X3": "0"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),             # float32-MFMA fused trunk
+    ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
     ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
     ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel

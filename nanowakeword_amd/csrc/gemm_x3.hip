@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __re
 }
 
 // NST = register stages of global loads in flight (k-tiles of lookahead).  The bulk shapes use 1 (two workgroups per
-// CU cover each other); the small-M instance <1, 4> (M <= 64: the interpreter's B = 1 .. 16 calls) is pure load
-// latency - 25 dependent k-tiles of ~2.4 us each - and runs 32-column tiles (4x the workgroups) with four k-tiles in
-// flight.  Per-output summation order is the same in every instance: same k-tile sequence, same products, same
+// CU cover each other); the small-M instance <1, 8> (M <= 64: the interpreter's B = 1 .. 16 calls) is pure load
+// latency - 25 dependent k-tiles of ~2.4 us each - and runs 32-column tiles (4x the workgroups) with eight k-tiles in
+// flight (only rows 0..63 of A are staged, so a stage is 16 registers).  Per-output summation order is the same in every instance: same k-tile sequence, same products, same
 // split-K chunks - results stay bit-identical across batch sizes.
 template <int CB, int NST, int ACT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gemm_x3_kernel(GemmArgs g) {
@@ -108,11 +108,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
         arow[q] = g.a_blocked ? g.A + ((size_t)(bm >> 7) * g.a_blocked * 128 + lr + 32 * q) * 32 + 4 * lq
                               : g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
     const int a_kstep = g.a_blocked ? 128 * 32 : 32;           // floats between consecutive k-tiles of a row
-    struct Stage { float4 a[4]; uint4 w[WLD]; };
+    constexpr int AQ = NST > 1 ? 2 : 4;                        // the small-M instance (M <= 64) stages rows 0..63 only
+    struct Stage { float4 a[AQ]; uint4 w[WLD]; };
     auto gload = [&](int kt, Stage& st) {
         const int k = kt * 32 + 4 * lq;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AQ; ++q) {
             if (k + 4 <= g.K) {
                 st.a[q] = *reinterpret_cast<const float4*>(arow[q] + (size_t)kt * a_kstep);
             } else {                                           // K tail: element-wise, zero beyond K
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
     };
     auto lstore = [&](int buf, const Stage& st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AQ; ++q) {
             uint32_t hi[4], mid[4], lo[4];
             split3(st.a[q].x, hi[0], mid[0], lo[0]); split3(st.a[q].y, hi[1], mid[1], lo[1]);
             split3(st.a[q].z, hi[2], mid[2], lo[2]); split3(st.a[q].w, hi[3], mid[3], lo[3]);
@@ -303,7 +304,7 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 64) {                                           // small batches: latency, not throughput (see the kernel comment)
         dim3 grid1(1, (g.N + 31) / 32, sk);
         const size_t lds1 = (size_t)(X3_BM + 32) * X3_ROW;
-        X3_ACT(1, 4, grid1, lds1)
+        X3_ACT(1, 8, grid1, lds1)
         return hipGetLastError();
     }
     const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);

@@ -10,7 +10,7 @@ from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_pcm, synth_state_dict
 
 dev = torch.device("cuda", 0)
-for name, cfg in (("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("dnn", HeadConfig("dnn", (101, 64)))):
+for name, cfg in (("cnn (first in process)", HeadConfig("cnn", (101, 64))), ("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("dnn", HeadConfig("dnn", (101, 64)))):
     m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
     for B in (1, 16):
         pcm = synth_pcm("noise", B, 16000, seed=3)
@@ -38,6 +38,28 @@ for name, cfg in (("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig(
             m.forward_pcm_dev(d_pcm.data_ptr(), B, 16000, d_log.data_ptr(), 0, stream)
         torch.cuda.synchronize()
         pipelined = (time.perf_counter() - t0) / n * 1e6
+        graph_us = float("nan")
+        try:                                                   # the same launches replayed from a captured graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cs = torch.cuda.current_stream(dev).cuda_stream
+                m.forward_pcm_dev(d_pcm.data_ptr(), B, 16000, d_log.data_ptr(), 0, cs)
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                g.replay()
+                torch.cuda.synchronize()
+            graph_us = (time.perf_counter() - t0) / n * 1e6
+            t0 = time.perf_counter()
+            for _ in range(n):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_pipe = (time.perf_counter() - t0) / n * 1e6
+            print(f"   graph replay + sync {graph_us:.0f} us | back-to-back {graph_pipe:.0f} us")
+        except Exception as e:
+            print("   graph capture failed:", repr(e)[:300])
         m.set_profiling(True)
         for _ in range(100):
             m.forward_pcm_dev(d_pcm.data_ptr(), B, 16000, d_log.data_ptr(), 0, stream)

@@ -1,0 +1,24 @@
+// ffn_x3.h - fused Conformer feed-forward module (ffn_x3.hip): h <- h + rscale * (W2 . swish(W1 . LayerNorm(h) + b1) + b2)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct FfnArgs {
+    float* h;                        // [M][D], updated in place (a workgroup reads and writes only its own 128 rows)
+    const float* ln_w; const float* ln_b;      // LayerNorm weight / bias [D]
+    const unsigned char* packed;     // launch_ffn_x3_pack output: per 32-unit hidden block W1 fragments, W2 fragments, b1
+    const float* b2;                 // [D]
+    int M;
+    float rscale;
+};
+
+// bytes of one packed hidden block: D/16 x 3 W1 fragments + ceil(D/32) x 2 x 3 W2 fragments of 1 KB, 32 biases
+// (padded to whole 4 KB = 256 lanes x 16 B copy steps)
+__host__ __device__ inline size_t ffn_x3_block_bytes(int D) {
+    return ((size_t)(D / 16) * 3072 + (size_t)((D + 31) / 32) * 6144 + 128 + 4095) & ~(size_t)4095;
+}
+size_t ffn_x3_packed_bytes(int D);
+bool ffn_x3_supported(int D);        // D (= d_model; hidden = 4 D) for which an instance is compiled
+// W1 [4D][D], b1 [4D], W2 [D][4D] float32 -> packed
+hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s);
+hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s);

@@ -15,6 +15,7 @@
 #include "frontend.h"
 #include "layers.h"
 #include "trunk.h"
+#include "ffn_x3.h"
 #include "emb_stream.h"
 #include <dlfcn.h>
 
@@ -83,6 +84,7 @@ struct nww_handle {
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
+    std::vector<void*> packed_weights;             // other plan-time weight packings (ffn_x3.hip)
     int conv_products = 0;                         // fused trunk: 0 = float32 MFMA, 6 | 9 = bf16 split products
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
@@ -348,6 +350,7 @@ extern "C" int nww_destroy(nww_handle* h) {
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->d_weights) (void)hipFree(h->d_weights);
     for (auto& kv : h->x3_weights) (void)hipFree(kv.second);
+    for (void* d : h->packed_weights) (void)hipFree(d);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_melplan) (void)hipFree(h->d_melplan);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -866,6 +869,24 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const std::string q = "model.conformer_blocks." + std::to_string(i);
                 auto ffn = [&](const std::string& ff) {
                     const float *lw = p.W(q + ff + ".layer_norm.weight"), *lb = p.W(q + ff + ".layer_norm.bias");
+                    // LayerNorm + linear1 + swish + linear2 + half-step residual in one kernel (ffn_x3.hip); same arithmetic
+                    // switch as the split-operand GEMMs it replaces
+                    static const int fused = [] { const char* e = getenv("NWW_FFN_FUSED"); return e ? atoi(e) : 1; }();
+                    if (fused && p.h->conv_products == 6 && ffn_x3_supported(D)) {
+                        void* packed = nullptr;
+                        if (hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
+                            launch_ffn_x3_pack(p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"),
+                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream) == hipSuccess) {
+                            p.h->packed_weights.push_back(packed);
+                            const float* b2 = p.W(q + ff + ".linear2.bias");
+                            p.add("ffn_x3:" + q + ff + " (ln+linear1+swish+linear2+0.5res)", [=](Run& r) {
+                                FfnArgs a{r.buf[hb], lw, lb, static_cast<const unsigned char*>(packed), b2, r.B * T, 0.5f};
+                                return launch_ffn_x3(a, D, r.stream);
+                            });
+                            return;
+                        }
+                        if (packed) (void)hipFree(packed);
+                    }
                     p.add("layernorm:" + q + ff, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
                     add_gemm(p, q + ff + ".linear1+swish", t1, big, T, 4 * D, D, p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"), ACT_SILU);
                     add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);

@@ -12,11 +12,11 @@ struct FfnArgs {
     float rscale;
 };
 
-// bytes of one packed hidden block: D/16 x 3 W1 fragments + ceil(D/32) x 2 x 3 W2 fragments of 1 KB, 32 biases
-// (padded to whole 4 KB = 256 lanes x 16 B copy steps)
-__host__ __device__ inline size_t ffn_x3_block_bytes(int D) {
-    return ((size_t)(D / 16) * 3072 + (size_t)((D + 31) / 32) * 6144 + 128 + 4095) & ~(size_t)4095;
-}
+// One packed hidden block = a W1 part (D/16 x 3 fragments of 1 KB) and a W2 part (ceil(D/32) x 2 x 3 fragments, then the
+// block's 32 biases), each padded to whole 4 KB copy steps (256 lanes x 16 B)
+__host__ __device__ inline size_t ffn_x3_w1_bytes(int D) { return ((size_t)(D / 16) * 3072 + 4095) & ~(size_t)4095; }
+__host__ __device__ inline size_t ffn_x3_w2_bytes(int D) { return ((size_t)((D + 31) / 32) * 6144 + 128 + 4095) & ~(size_t)4095; }
+__host__ __device__ inline size_t ffn_x3_block_bytes(int D) { return ffn_x3_w1_bytes(D) + ffn_x3_w2_bytes(D); }
 size_t ffn_x3_packed_bytes(int D);
 bool ffn_x3_supported(int D);        // D (= d_model; hidden = 4 D) for which an instance is compiled
 // W1 [4D][D], b1 [4D], W2 [D][4D] float32 -> packed

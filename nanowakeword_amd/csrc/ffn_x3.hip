@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "layers.h"
 #include "ffn_x3.h"
 
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = m < D ? W2[(size_t)m * H4 + 32 * hb + 8 * (2 * kb2 + (e >> 2)) + 4 * h + (e & 3)] : 0.0f;
-        dst = base + (size_t)D16 * 3072 + ((size_t)((ob * 2 + kb2) * 3) * 64 + lane) * 16;
+        dst = base + ffn_x3_w1_bytes(D) + ((size_t)((ob * 2 + kb2) * 3) * 64 + lane) * 16;
     }
     uint32_t hh[8], mm[8], ll[8];
 #pragma unroll
@@ -96,35 +97,40 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
     *reinterpret_cast<uint4*>(dst) = make_uint4(pack16(hh[0], hh[1]), pack16(hh[2], hh[3]), pack16(hh[4], hh[5]), pack16(hh[6], hh[7]));
     *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16(mm[0], mm[1]), pack16(mm[2], mm[3]), pack16(mm[4], mm[5]), pack16(mm[6], mm[7]));
     *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16(ll[0], ll[1]), pack16(ll[2], ll[3]), pack16(ll[4], ll[5]), pack16(ll[6], ll[7]));
-    if (f == 0 && lane < 32) reinterpret_cast<float*>(base + (size_t)D16 * 3072 + (size_t)NOB * 6144)[lane] = b1[32 * hb + lane];
+    if (f == 0 && lane < 32) reinterpret_cast<float*>(base + ffn_x3_w1_bytes(D) + (size_t)NOB * 6144)[lane] = b1[32 * hb + lane];
 }
 
 template <int D16>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;
-    constexpr int W1_BYTES = D16 * 3072, W2_BYTES = NOB * 6144, BLK = (W1_BYTES + W2_BYTES + 128 + 4095) & ~4095;
-    constexpr int NLD = BLK / 4096;                            // 16-byte pieces per thread and block
-    // two separate LDS objects, not two halves of one: hipcc then knows that the reads of one buffer cannot alias the
-    // LDS-DMA writes into the other and does not wait for the next block's fetch (s_waitcnt vmcnt(0)) in mid-block
-    __shared__ __attribute__((aligned(16))) unsigned char lds_buf0[BLK];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_buf1[BLK];
+    constexpr int W1_PART = (D16 * 3072 + 4095) & ~4095, W2_PART = (NOB * 6144 + 128 + 4095) & ~4095, BLK = W1_PART + W2_PART;
+    constexpr int B1_OFF = NOB * 6144;                         // the block's 32 biases sit behind the W2 fragments
+    // Four separate LDS objects, not four quarters of one: hipcc then knows that the reads of one buffer cannot alias
+    // the LDS-DMA writes into another and does not wait for the fetches in flight (s_waitcnt vmcnt(0)) in mid-block.
+    __shared__ __attribute__((aligned(16))) unsigned char w1b0[W1_PART];
+    __shared__ __attribute__((aligned(16))) unsigned char w1b1[W1_PART];
+    __shared__ __attribute__((aligned(16))) unsigned char w2b0[W2_PART];
+    __shared__ __attribute__((aligned(16))) unsigned char w2b1[W2_PART];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int row = (int)blockIdx.x * 128 + wave * 32 + n;
     const bool row_ok = row < a.M;
     float* hrow = a.h + (size_t)(row_ok ? row : a.M - 1) * D;
 
-    // ---- weight blocks go global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i), no
-    // staging registers; the first one is on its way while the rows are normalised
-    auto fetch_block = [&](int hb, unsigned char* buf) {
-        const unsigned char* src = a.packed + (size_t)hb * BLK + tid * 16;
-        unsigned char* dst = buf + wave * 1024;                           // wave-uniform
+    // ---- weights go global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i), no staging
+    // registers; the first parts are on their way while the rows are normalised
+    auto fetch = [&](const unsigned char* src, unsigned char* buf, auto steps) {
+        const unsigned char* sp = src + tid * 16;
+        unsigned char* dst = buf + wave * 1024;                          // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NLD; ++j)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + j * 4096),
+        for (int j = 0; j < decltype(steps)::value; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sp + j * 4096),
                                              (void __attribute__((address_space(3)))*)(dst + j * 4096), 16, 0, 0);
     };
-    fetch_block(0, lds_buf0);
+    auto fetch_w1 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK, buf, std::integral_constant<int, W1_PART / 4096>{}); };
+    auto fetch_w2 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK + W1_PART, buf, std::integral_constant<int, W2_PART / 4096>{}); };
+    fetch_w1(0, w1b0);
+    fetch_w2(0, w2b0);
 
     // ---- LayerNorm of the lane's half row (features 16kb + 8h + e) -> X fragments
     bf16x8 xf[D16][3];
@@ -167,69 +173,173 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.0f;
 
-    auto block = [&](const unsigned char* blk) {
-        const unsigned char* w1p = blk + lane * 16;
-        const unsigned char* w2p = blk + W1_BYTES + lane * 16;
-        // ---- Ht = W1 block . Xt
-        f32x16 acc1;
+    // Software pipeline over the hidden blocks: while the matrix pipe runs block hb + 1's first product, the VALU turns
+    // block hb's accumulator into operand fragments (bias, swish, three-way split) - a lone wave issues in order, and each
+    // MFMA of the dependent chain holds the wave for its 32 clocks, so the scheduler is told to put ~5 VALU instructions
+    // behind every MFMA (sched_group_barrier); then block hb's second product.  W1 parts and W2 parts are double
+    // buffered separately, each fetched a full iteration before its first use:
+    //   iteration hb:  fetch W1(hb + 2), W2(hb + 1);   Ht(hb + 1) = W1(hb + 1) . Xt  ||  hf = split(swish(Ht(hb) + b1(hb)));
+    //                  Yt += W2(hb) . hf;               barrier
+    auto gemm1_epi = [&](auto has_next, const unsigned char* w1buf, const unsigned char* w2buf, const f32x16& cur, f32x16& next,
+                         bf16x8 (&hf)[2][3]) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        constexpr int NSLOT = NEXT ? 6 * D16 : 1;              // MFMAs of the first product = slots for epilogue pieces
+        constexpr int PER = (48 + NSLOT - 1) / NSLOT;          // epilogue pieces (16 elements x 3 stages) per slot
+        const unsigned char* w1p = w1buf + lane * 16;
+        const float* b1p = reinterpret_cast<const float*>(w2buf + B1_OFF) + 4 * h;
+        float4 bq[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
-        bf16x8 nw[3];
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(b1p + 8 * g);     // biases of hidden 8g + 4h + 0..3
+        const float bias[16] = {bq[0].x, bq[0].y, bq[0].z, bq[0].w, bq[1].x, bq[1].y, bq[1].z, bq[1].w,
+                                bq[2].x, bq[2].y, bq[2].z, bq[2].w, bq[3].x, bq[3].y, bq[3].z, bq[3].w};
+        bf16x8 nw[3], cw[3];
+        if (NEXT) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
+            for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
 #pragma unroll
-        for (int kb = 0; kb < D16; ++kb) {
-            bf16x8 cw[3] = {nw[0], nw[1], nw[2]};
-            if (kb + 1 < D16) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * 3 + t) * 1024);
+            for (int r = 0; r < 16; ++r) next[r] = 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // element e of the accumulator in three pieces: (A) v = acc + bias, u = 1 + 2^(-v log2 e);  (B) y = v / u, hi, rest;
+        // (C) mid, lo.  Registers 8 kb2 .. 8 kb2 + 7 are the eight k slots of 16-block kb2 of the second product.
+        float v[16], u[16];
+        uint32_t th[16], tm[16], tl[16];
+        auto piece = [&](int p) {
+            const int e = p / 3, st = p - 3 * e;
+            if (st == 0) {
+                v[e] = cur[e] + bias[e];
+                u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
+                asm volatile("" : "+v"(v[e]), "+v"(u[e]));     // pins the piece behind its MFMA (pure arithmetic floats freely otherwise)
+            } else if (st == 1) {
+                const float y = v[e] * __builtin_amdgcn_rcpf(u[e]);
+                th[e] = __float_as_uint(y) & 0xffff0000u;
+                u[e] = y - __uint_as_float(th[e]);
+                asm volatile("" : "+v"(th[e]), "+v"(u[e]));
             } else {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w2p + t * 1024);   // first W2 fragment
+                tm[e] = __float_as_uint(u[e]) & 0xffff0000u;
+                tl[e] = __float_as_uint(u[e] - __uint_as_float(tm[e]));
+                asm volatile("" : "+v"(tm[e]), "+v"(tl[e]));
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma6(cw, xf[kb], acc1);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PX[6] = {1, 0, 2, 0, 1, 0};       // the six products, small terms first (mfma6)
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            if (NEXT) {
+                const int kb = q / 6, m = q - 6 * kb;
+                if (m == 0) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) cw[t] = nw[t];
+                }
+                if (m < 3 && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * 3 + m) * 1024);
+                next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw[PW[m]], xf[kb][PX[m]], next, 0, 0, 0);
+                asm volatile("" : "+a"(next));
+            }
+#pragma unroll
+            for (int p = q * PER; p < (q + 1) * PER && p < 48; ++p) piece(p);
+            __builtin_amdgcn_sched_barrier(0);                 // each MFMA keeps its pieces: a lone wave issues in order, and the
+        }                                                      // next MFMA of the chain waits 32 clocks for this one anyway
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+            union { uint4 q; bf16x8 b; } ch, cm, cl;
+            const int o = 8 * kb2;
+            ch.q = make_uint4(pack16(th[o], th[o + 1]), pack16(th[o + 2], th[o + 3]), pack16(th[o + 4], th[o + 5]), pack16(th[o + 6], th[o + 7]));
+            cm.q = make_uint4(pack16(tm[o], tm[o + 1]), pack16(tm[o + 2], tm[o + 3]), pack16(tm[o + 4], tm[o + 5]), pack16(tm[o + 6], tm[o + 7]));
+            cl.q = make_uint4(pack16(tl[o], tl[o + 1]), pack16(tl[o + 2], tl[o + 3]), pack16(tl[o + 4], tl[o + 5]), pack16(tl[o + 6], tl[o + 7]));
+            hf[kb2][0] = ch.b; hf[kb2][1] = cm.b; hf[kb2][2] = cl.b;
         }
-        // ---- swish(Ht + b1), re-split in place: registers 8 kb2 .. 8 kb2 + 7 are the eight k slots of 16-block kb2
-        bf16x8 hf[2][3];
-        {
-            const float* b1p = reinterpret_cast<const float*>(blk + W1_BYTES + W2_BYTES);
+    };
+    // second product: two output blocks at a time, their MFMAs alternating (a chain on one accumulator issues every 36
+    // clocks, two interleaved chains every 32: tools/ubench/mfma_valu_samewave.hip)
+    auto gemm2 = [&](const unsigned char* w2buf, const bf16x8 (&hf)[2][3]) {
+        const unsigned char* w2p = w2buf + lane * 16;
+        constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PX[6] = {1, 0, 2, 0, 1, 0};       // the six products, small terms first (mfma6)
+        constexpr int NG = 2 * ((NOB + 1) / 2);                // groups: (pair of output blocks, kb2)
+        auto frag = [&](int g, int which, int t) {             // group g = 2 * pair + kb2; which = 0 / 1: block 2 pair + which
+            const int ob = 2 * (g >> 1) + which, kb2 = g & 1;
+            return *reinterpret_cast<const bf16x8*>(w2p + ((ob * 2 + kb2) * 3 + t) * 1024);
+        };
+        bf16x8 na[3], nb[3];
 #pragma unroll
-            for (int kb2 = 0; kb2 < 2; ++kb2) {
-                const float4 ba = *reinterpret_cast<const float4*>(b1p + 8 * (2 * kb2) + 4 * h);
-                const float4 bb = *reinterpret_cast<const float4*>(b1p + 8 * (2 * kb2 + 1) + 4 * h);
-                const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-                float y[8];
+        for (int t = 0; t < 3; ++t) { na[t] = frag(0, 0, t); if (NOB > 1) nb[t] = frag(0, 1, t); }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = ffn_swish(acc1[8 * kb2 + e] + bias[e]);
-                split_frag(y, hf[kb2][0], hf[kb2][1], hf[kb2][2]);
-            }
-        }
-        // ---- Yt += W2 block . swish(Ht)
+        for (int g = 0; g < NG; ++g) {
+            const int ob = 2 * (g >> 1), kb2 = g & 1;
+            const bool two = ob + 1 < NOB;
+            bf16x8 ca[3] = {na[0], na[1], na[2]}, cb[3] = {nb[0], nb[1], nb[2]};
+            if (g + 1 < NG) {
 #pragma unroll
-        for (int s = 0; s < 2 * NOB; ++s) {                    // s = 2 ob + kb2
-            bf16x8 cw[3] = {nw[0], nw[1], nw[2]};
-            if (s + 1 < 2 * NOB) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w2p + ((s + 1) * 3 + t) * 1024);
+                for (int t = 0; t < 3; ++t) {
+                    na[t] = frag(g + 1, 0, t);
+                    if (2 * ((g + 1) >> 1) + 1 < NOB) nb[t] = frag(g + 1, 1, t);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(cw, hf[s & 1], yacc[s >> 1]);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[PW[m]], hf[kb2][PX[m]], yacc[ob], 0, 0, 0);
+                if (two) yacc[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[PW[m]], hf[kb2][PX[m]], yacc[ob + 1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    f32x16 accA, accB;
+    bf16x8 hf[2][3];
+    float4 res[NOB][4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int hb = 0; hb < NHB; hb += 2) {                      // NHB = D / 8 is even
-        fetch_block(hb + 1, lds_buf1);                         // buffer 1 was last read in block hb - 1, behind a barrier
-        block(lds_buf0);
+    fetch_w1(1, w1b1);
+    {                                                          // Ht(0), not overlapped
+        const unsigned char* w1p = w1b0 + lane * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[r] = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < D16; ++kb) {
+            bf16x8 cw[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) cw[t] = *reinterpret_cast<const bf16x8*>(w1p + (kb * 3 + t) * 1024);
+            mfma6(cw, xf[kb], accA);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // NHB = D / 8 is even.  Even block hb: cur = accA, W1(hb + 1) in w1b1, W2(hb) in w2b0; odd block: the other buffers.
+    for (int hb = 0; hb + 2 < NHB; hb += 2) {
+        fetch_w1(hb + 2, w1b0);
+        fetch_w2(hb + 1, w2b1);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm2(w2b0, hf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (hb + 2 < NHB) fetch_block(hb + 2, lds_buf0);
-        block(lds_buf1);
+        fetch_w1(hb + 3, w1b1);
+        fetch_w2(hb + 2, w2b0);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm1_epi(std::true_type{}, w1b0, w2b1, accB, accA, hf);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm2(w2b1, hf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    {                                                          // the last two blocks
+        fetch_w2(NHB - 1, w2b1);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm2(w2b0, hf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // the X fragments are dead now: their registers take the residual rows for the final update, so that those
+        // loads are in flight under the last block's MFMAs
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm1_epi(std::false_type{}, w1b0, w2b1, accB, accA, hf);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm2(w2b1, hf);
     }
 
     // ---- h <- h + rscale * (Yt + b2): lane (row n, half h) holds out features 32 ob + 8 g + 4 h + 0..3
@@ -241,7 +351,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             const int m = 32 * ob + 8 * g + 4 * h;
             if (m < D) {                                       // D % 16 == 0, so the four features are in or out together
                 const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + m);
-                float4 r = *reinterpret_cast<const float4*>(hrow + m);
+                float4 r = res[ob][g];
                 r.x += a.rscale * (yacc[ob][4 * g + 0] + b2.x);
                 r.y += a.rscale * (yacc[ob][4 * g + 1] + b2.y);
                 r.z += a.rscale * (yacc[ob][4 * g + 2] + b2.z);

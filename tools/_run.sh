@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -x -q -k "e2e or crnn or onnx" 2>&1 | tail -3
-for d in 0 8; do NWW_C3_DBG=$d python tools/bench_configs.py e2e_dnn 2>&1 | tail -1 | python -c "
+for d in 0 1 2 3 4; do NWW_FFN_DBG=$d python tools/bench_configs.py C5 2>&1 | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('dbg=$d', d['kernel_ms'])"; done
+d = json.loads(sys.stdin.read()); print('dbg=$d', [v for k, v in d['kernel_ms'].items() if 'ffn' in k])"; done

@@ -893,7 +893,11 @@ extern "C" int nww_finalize(nww_handle* h) {
                 };
                 ffn(".ff1");
                 add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
-                p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
+                static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
+                if (mha_mfma && mha_mfma_supported(T, D, NH))
+                    p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
+                else
+                    p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
                 add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
                 {
                     const std::string m = q + ".conv_module";

@@ -116,6 +116,7 @@ _CRNN_LSTM = dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm")
 _E2E = dict(model_type="e2e_dnn", input_shape=(64, 101))
 _GRU = dict(model_type="gru", input_shape=(30, 64), layer_dim=64)
 _BC = dict(model_type="bcresnet", input_shape=(32, 40), embedding_dim=16)
+_CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, conformer_d_model=96, conformer_n_head=4)
 
 
 @pytest.mark.parametrize("env,heads,want,unwanted,check_fe", [
@@ -125,6 +126,8 @@ _BC = dict(model_type="bcresnet", input_shape=(32, 40), embedding_dim=16)
     ({"NWW_E2E_FUSE_POOL": "0"}, [_E2E], ["avgpool"], [], False),                       # stand-alone export-form pool
     ({"NWW_TRUNK_X3": "0"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),             # float32-MFMA fused trunk
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
+    ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
+    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma"], False),                # one-lane-per-query attention core
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
     ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
     ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel

@@ -1,0 +1,26 @@
+// lin_x3.h - input-stationary short-K Linear layers on the bf16 matrix cores (lin_x3.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct LinArgs {
+    const float* x; int ldx;         // [M][K] input rows
+    float* out; int ldc;             // [M][N]
+    const float* res; int ldres;     // epilogue 1: out = res + rscale * (y + bias)   (res may be out)
+    float rscale;
+    const float* ln_w; const float* ln_b;      // LayerNorm over the K input features first (epilogue 2 instances only)
+    const unsigned char* packed;     // launch_lin_x3_pack output
+    int M, N;                        // N = output features written (for the GLU epilogue: of the gated product)
+    int nblk = 0;                    // filled by the launcher
+};
+
+// bytes of one packed 32-output block: parts x K/16 x 3 fragments of 1 KB + parts x 32 biases, padded to whole 4 KB copy steps
+__host__ __device__ inline size_t lin_x3_block_bytes(int K, int parts) {
+    return ((size_t)parts * (K / 16) * 3072 + (size_t)parts * 128 + 4095) & ~(size_t)4095;
+}
+bool lin_x3_supported(int K, int N);
+size_t lin_x3_packed_bytes(int K, int n_out, int parts);
+// W [parts * gate_off .. ][K] float32, bias or nullptr -> packed; parts = 2, gate_off = N for the GLU pairing (rows j and N + j)
+hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int K, int n_out, int parts, int gate_off, hipStream_t s);
+// epi: 0 plain, 1 residual, 2 GLU; ln: LayerNorm prologue (epi 2 only)
+hipError_t launch_lin_x3(const LinArgs& a, int K, int epi, bool ln, hipStream_t s);

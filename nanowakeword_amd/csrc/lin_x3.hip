@@ -1,0 +1,258 @@
+// lin_x3.hip - short-K Linear layers of the Conformer on the bf16 matrix cores (exact operand splitting), input-stationary:
+//     out[M][N] = epilogue( (LayerNorm?)(x)[M][K] . W[N][K]^T + bias ),   K = 16 .. 144 (the model width), any N
+// for attention.in_proj (plain), attention.out_proj and conv_module.conv2 (+ residual), conv_module.layer_norm + conv1 +
+// GLU (N = 2K, out = a * sigmoid(b)) and input_proj (architectures.py:471-543).  The general split-operand GEMM (gemm_x3.hip)
+// walks k-tiles per output tile; with K = 144 that is five tiles of prologue and epilogue per 128 x 160 outputs and A re-read
+// per column tile: 0.17 - 0.25 ms per layer at M = 206 848 where the matrix pipe needs 0.02 - 0.06.
+//
+// Same organisation as the fused feed-forward (ffn_x3.hip), minus the second product: a wave owns 32 rows for the whole
+// kernel, their (normalised) values live in registers as 3 x K/16 B fragments; the products are computed transposed,
+//     Yt [32 outputs x 32 rows] = W block [32 x K] . Xt,
+// so a lane of the accumulator holds 4 consecutive output features of ONE row per register group: 16-byte stores; the
+// workgroup's four waves share each 32-output block of W through LDS (plan-time packed fragments + biases, fetched one
+// block ahead by global_load_lds_dwordx4 into the other of two buffers, one barrier per block).  Two workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "layers.h"
+#include "lin_x3.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ void split3l(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+__device__ __forceinline__ uint32_t pack16l(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ void split_frag_l(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3l(v[e], h[e], m[e], l[e]);
+    union { uint4 u; bf16x8 b; } ch, cm, cl;
+    ch.u = make_uint4(pack16l(h[0], h[1]), pack16l(h[2], h[3]), pack16l(h[4], h[5]), pack16l(h[6], h[7]));
+    cm.u = make_uint4(pack16l(m[0], m[1]), pack16l(m[2], m[3]), pack16l(m[4], m[5]), pack16l(m[6], m[7]));
+    cl.u = make_uint4(pack16l(l[0], l[1]), pack16l(l[2], l[3]), pack16l(l[4], l[5]), pack16l(l[6], l[7]));
+    fh = ch.b; fm = cm.b; fl = cl.b;
+}
+
+__device__ __forceinline__ float lin_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+
+// six products, small terms first (the order of gemm_x3.hip): w = weight fragments (A operand), x = activation fragments (B)
+__device__ __forceinline__ void mfma6l(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
+}
+
+// ---- plan-time packing: one thread per (output block, fragment, lane).  Block = [part (1 | 2: GLU a, b)][kb][term][lane] 16-byte
+// fragments, then 32 biases per part, padded to whole 4 KB copy steps.  Part p of block blk is W rows p * gate_off + 32 blk + i.
+__global__ void __launch_bounds__(256) lin_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                       unsigned char* __restrict__ out, int K, int n_out, int parts, int gate_off) {
+    const int K16 = K / 16, nblk = (n_out + 31) / 32;
+    const size_t blk_bytes = lin_x3_block_bytes(K, parts);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nblk * parts * K16 * 64) return;
+    const int lane = (int)(idx & 63);
+    size_t r = idx >> 6;
+    const int kb = (int)(r % K16); r /= K16;
+    const int part = (int)(r % parts), blk = (int)(r / parts);
+    const int i = lane & 31, h = lane >> 5;
+    const int col = 32 * blk + i;                              // output feature inside the part
+    unsigned char* base = out + (size_t)blk * blk_bytes;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col < n_out ? W[(size_t)(part * gate_off + col) * K + 16 * kb + 8 * h + e] : 0.0f;
+    uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3l(v[e], hh[e], mm[e], ll[e]);
+    unsigned char* dst = base + ((size_t)((part * K16 + kb) * 3) * 64 + lane) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack16l(hh[0], hh[1]), pack16l(hh[2], hh[3]), pack16l(hh[4], hh[5]), pack16l(hh[6], hh[7]));
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16l(mm[0], mm[1]), pack16l(mm[2], mm[3]), pack16l(mm[4], mm[5]), pack16l(mm[6], mm[7]));
+    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16l(ll[0], ll[1]), pack16l(ll[2], ll[3]), pack16l(ll[4], ll[5]), pack16l(ll[6], ll[7]));
+    if (kb == 0 && lane < 32)
+        reinterpret_cast<float*>(base + (size_t)parts * K16 * 3072)[part * 32 + lane] = (bias && col < n_out) ? bias[part * gate_off + col] : 0.0f;
+}
+
+// EPI: 0 = out = y + bias;  1 = out = res + rscale * (y + bias);  2 = GLU, out = (ya + bias_a) * sigmoid(yb + bias_b)
+template <int K16, int EPI, bool LN>
+__global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
+    constexpr int K = 16 * K16, PARTS = EPI == 2 ? 2 : 1;
+    constexpr int FRAG_BYTES = PARTS * K16 * 3072, BLK = (FRAG_BYTES + PARTS * 128 + 4095) & ~4095;
+    // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
+    __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
+    __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int row = (int)blockIdx.x * 128 + wave * 32 + n;
+    const bool row_ok = row < a.M;
+    const size_t rr = (size_t)(row_ok ? row : a.M - 1);
+    const float* xrow = a.x + rr * a.ldx;
+
+    auto fetch = [&](int blk, unsigned char* buf) {
+        const unsigned char* sp = a.packed + (size_t)blk * BLK + tid * 16;
+        unsigned char* dst = buf + wave * 1024;                          // wave-uniform
+#pragma unroll
+        for (int j = 0; j < BLK / 4096; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sp + j * 4096),
+                                             (void __attribute__((address_space(3)))*)(dst + j * 4096), 16, 0, 0);
+    };
+    fetch(0, wb0);
+
+    // ---- the lane's half row (features 16kb + 8h + e), LayerNorm-ed if asked -> X fragments
+    bf16x8 xf[K16][3];
+    {
+        float v[K16][8];
+        float s = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < K16; ++kb) {
+            const float4 p0 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h);
+            const float4 p1 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h + 4);
+            v[kb][0] = p0.x; v[kb][1] = p0.y; v[kb][2] = p0.z; v[kb][3] = p0.w;
+            v[kb][4] = p1.x; v[kb][5] = p1.y; v[kb][6] = p1.z; v[kb][7] = p1.w;
+            if (LN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[kb][e];
+            }
+        }
+        float mu = 0.0f, rstd = 1.0f;
+        if (LN) {
+            s += __shfl_xor(s, 32, 64);
+            mu = s / (float)K;
+            float q = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[kb][e] - mu; q = fmaf(d, d, q); }
+            q += __shfl_xor(q, 32, 64);
+            rstd = 1.0f / sqrtf(q / (float)K + 1e-5f);
+        }
+#pragma unroll
+        for (int kb = 0; kb < K16; ++kb) {
+            if (LN) {
+                const float4 w0 = *reinterpret_cast<const float4*>(a.ln_w + 16 * kb + 8 * h), w1 = *reinterpret_cast<const float4*>(a.ln_w + 16 * kb + 8 * h + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(a.ln_b + 16 * kb + 8 * h), c1 = *reinterpret_cast<const float4*>(a.ln_b + 16 * kb + 8 * h + 4);
+                const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[kb][e] = (v[kb][e] - mu) * rstd * w[e] + c[e];
+            }
+            split_frag_l(v[kb], xf[kb][0], xf[kb][1], xf[kb][2]);
+        }
+    }
+
+    float* orow = a.out + rr * a.ldc;
+    const float* rrow = EPI == 1 ? a.res + rr * a.ldres : nullptr;
+    auto block = [&](int blk, const unsigned char* wbuf) {
+        const unsigned char* wp = wbuf + lane * 16;
+        f32x16 acc[PARTS];
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        bf16x8 nw[PARTS][3];
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * 3 + t) * 1024);
+#pragma unroll
+        for (int kb = 0; kb < K16; ++kb) {
+            bf16x8 cw[PARTS][3];
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) cw[p][t] = nw[p][t];
+            if (kb + 1 < K16) {
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * 3 + t) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) mfma6l(cw[p], xf[kb], acc[p]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane (row n, half h), register 4g + q = output feature 32 blk + 8g + 4h + q
+        if (!row_ok) return;
+        const float* bp = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 32 * blk + 8 * g + 4 * h;
+            if (col < a.N) {                                   // N % 4 == 0: the four features are in or out together
+                const float4 b0 = *reinterpret_cast<const float4*>(bp + 8 * g);
+                float4 o = make_float4(acc[0][4 * g] + b0.x, acc[0][4 * g + 1] + b0.y, acc[0][4 * g + 2] + b0.z, acc[0][4 * g + 3] + b0.w);
+                if (EPI == 2) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 + 8 * g);
+                    o.x *= lin_sigmoid(acc[PARTS - 1][4 * g] + b1.x);
+                    o.y *= lin_sigmoid(acc[PARTS - 1][4 * g + 1] + b1.y);
+                    o.z *= lin_sigmoid(acc[PARTS - 1][4 * g + 2] + b1.z);
+                    o.w *= lin_sigmoid(acc[PARTS - 1][4 * g + 3] + b1.w);
+                }
+                if (EPI == 1) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rrow + col);
+                    o.x = r4.x + a.rscale * o.x; o.y = r4.y + a.rscale * o.y; o.z = r4.z + a.rscale * o.z; o.w = r4.w + a.rscale * o.w;
+                }
+                *reinterpret_cast<float4*>(orow + col) = o;
+            }
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nblk = a.nblk;
+    for (int blk = 0; blk < nblk; blk += 2) {
+        if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
+        block(blk, wb0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blk + 1 < nblk) {
+            if (blk + 2 < nblk) fetch(blk + 2, wb0);
+            block(blk + 1, wb1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+bool lin_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 96 || K == 128 || K == 144) && N % 4 == 0 && N >= 4; }
+
+size_t lin_x3_packed_bytes(int K, int n_out, int parts) { return (size_t)((n_out + 31) / 32) * lin_x3_block_bytes(K, parts); }
+
+hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int K, int n_out, int parts, int gate_off, hipStream_t s) {
+    const size_t total = (size_t)((n_out + 31) / 32) * parts * (K / 16) * 64;
+    hipLaunchKernelGGL(lin_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, bias,
+                       reinterpret_cast<unsigned char*>(out), K, n_out, parts, gate_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t s) {
+    if (a0.M <= 0) return hipSuccess;
+    if (!lin_x3_supported(K, a0.N) || (ln && epi != 2) || (a0.ldx % 4) || (a0.ldc % 4)) return hipErrorInvalidValue;
+    LinArgs a = a0;
+    a.nblk = (a.N + 31) / 32;
+    const dim3 grid((a.M + 127) / 128);
+#define LIN_GO(K16V, EPIV, LNV) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV>), grid, dim3(256), 0, s, a);
+#define LIN_EPI(K16V)                                                                                              \
+    if (epi == 0) LIN_GO(K16V, 0, false) else if (epi == 1) LIN_GO(K16V, 1, false) else if (ln) LIN_GO(K16V, 2, true) else LIN_GO(K16V, 2, false)
+    switch (K) {
+        case 32: LIN_EPI(2) break;
+        case 64: LIN_EPI(4) break;
+        case 96: LIN_EPI(6) break;
+        case 128: LIN_EPI(8) break;
+        case 144: LIN_EPI(9) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LIN_EPI
+#undef LIN_GO
+    return hipGetLastError();
+}

@@ -16,6 +16,7 @@
 #include "layers.h"
 #include "trunk.h"
 #include "ffn_x3.h"
+#include "lin_x3.h"
 #include "emb_stream.h"
 #include <dlfcn.h>
 
@@ -474,6 +475,30 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
     });
 }
 
+// Short-K Linear on the input-stationary split-operand kernel (lin_x3.hip); false -> the caller plans the general GEMM.
+// epi 0: out = y + b; 1: out = res + rscale (y + b); 2: LayerNorm(ln_w, ln_b) first when given, W = [2N][K], out = a * sigmoid(b)
+bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K, const float* W,
+                const float* bias, int epi, int res_id = 99, float rscale = 1.f, const float* ln_w = nullptr,
+                const float* ln_b = nullptr) {
+    static const int enabled = [] { const char* e = getenv("NWW_LIN_X3"); return e ? atoi(e) : 1; }();
+    if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N)) return false;
+    const int parts = epi == 2 ? 2 : 1;
+    void* packed = nullptr;
+    if (hipMalloc(&packed, lin_x3_packed_bytes(K, N, parts)) != hipSuccess) return false;
+    if (launch_lin_x3_pack(W, bias, packed, K, N, parts, N, p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+    p.h->packed_weights.push_back(packed);
+    p.need(out_id, (size_t)rows_per_clip * N);
+    p.add("lin_x3:" + name, [=](Run& r) {
+        LinArgs a;
+        a.x = src(r, in_id); a.ldx = K; a.out = dst(r, out_id); a.ldc = N;
+        a.res = res_id == 99 ? nullptr : src(r, res_id); a.ldres = N; a.rscale = rscale;
+        a.ln_w = ln_w; a.ln_b = ln_b; a.packed = static_cast<const unsigned char*>(packed);
+        a.M = r.B * rows_per_clip; a.N = N;
+        return launch_lin_x3(a, K, epi, ln_w != nullptr, r.stream);
+    });
+    return true;
+}
+
 void set_tail(PlanCtx& p, const std::string& name, int in_id, int K, const float* W, const float* b) {
     p.tail_name = name; p.tail_in = in_id; p.tail_K = K; p.tail_W = W; p.tail_b = b;
 }
@@ -864,7 +889,8 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int D = c.conformer_d_model, NH = c.conformer_n_head;
             const int hb = 0, t1 = 1, t3 = 2, big = 3;      // h, LN/glu/attn scratch, dwconv scratch, wide scratch
             p.need(t1, (size_t)T * D); p.need(t3, (size_t)T * D);
-            add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
+            if (!add_lin_x3(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), 0))
+                add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
             for (int i = 0; i < nb; ++i) {
                 const std::string q = "model.conformer_blocks." + std::to_string(i);
                 auto ffn = [&](const std::string& ff) {
@@ -892,23 +918,29 @@ extern "C" int nww_finalize(nww_handle* h) {
                     add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
                 };
                 ffn(".ff1");
-                add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
+                if (!add_lin_x3(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), 0))
+                    add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
                 static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
                 if (mha_mfma && mha_mfma_supported(T, D, NH))
                     p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
                 else
                     p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
-                add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                if (!add_lin_x3(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), 1, hb, 1.0f))
+                    add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
                 {
                     const std::string m = q + ".conv_module";
                     const float *lw = p.W(m + ".layer_norm.weight"), *lb = p.W(m + ".layer_norm.bias");
-                    p.add("layernorm:" + m, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
-                    add_gemm(p, m + ".conv1(pw)", t1, big, T, 2 * D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), ACT_NONE);
-                    p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
+                    // LayerNorm + pointwise conv1 + GLU in one launch (lin_x3.hip), else the three separate ones
+                    if (!add_lin_x3(p, m + ".layer_norm+conv1(pw)+glu", hb, t1, T, D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), 2, 99, 1.f, lw, lb)) {
+                        p.add("layernorm:" + m, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                        add_gemm(p, m + ".conv1(pw)", t1, big, T, 2 * D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), ACT_NONE);
+                        p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
+                    }
                     const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
                     const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
                     p.add("dwconv1d+bn+swish:" + m, [=](Run& r) { return launch_dwconv1d_bn_swish(r.buf[t1], dw, db, ba, bb, r.buf[t3], r.B, T, D, 31, r.stream); });
-                    add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                    if (!add_lin_x3(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), 1, hb, 1.0f))
+                        add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
                 }
                 ffn(".ff2");
                 const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");

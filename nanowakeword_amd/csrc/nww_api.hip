@@ -817,7 +817,21 @@ extern "C" int nww_finalize(nww_handle* h) {
             // xs = x at the strided centres, then two MFMA GEMMs over M = B*Ho*Wo pixels:
             //   R = BN_s(xs . Wsc^T) ;  out = act(BN_1(d . Wpw^T)) + R      (activation BEFORE the residual add, :646-647)
             static const int ic_mfma = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
-            if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {
+            // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
+            static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
+            static const int bc_fuse0 = [] { const char* e = getenv("NWW_BC_FUSE"); return e ? atoi(e) : 0; }();
+            const bool front_fused = ic_mfma && bc_front && !bc_fuse0 && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
+            if (front_fused) {
+                const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
+                const float* dwt1 = p.W("model.block1.depthwise.weight_t");
+                const int ho1 = (T / 2 - 1) / 2 + 1, wo1 = (F / 2 - 1) / 2 + 1;
+                p.need(2, (size_t)32 * ho1 * wo1); p.need(3, (size_t)32 * ho1 * wo1);
+                const int max_grid = p.h->cu_count;
+                p.add("conv1_dw_mfma:init_conv + block1.depthwise (nhwc)", [=](Run& r) {
+                    Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
+                    return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);
+                });
+            } else if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {
                 const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
                 p.need(0, (size_t)32 * (T / 2) * (F / 2));
                 const int max_grid = p.h->cu_count;
@@ -860,7 +874,8 @@ extern "C" int nww_finalize(nww_handle* h) {
                     hh = ho; ww = wo; cur = outb;
                     continue;
                 }
-                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
+                if (!(front_fused && i == 1))
+                    p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
                 // one dual GEMM per block: shortcut and pointwise products in the same workgroup, no residual round trip
                 {
                     const float *wpw = p.W(q + ".pointwise.weight"), *a1 = p.W(q + ".bn1.alpha"), *b1 = p.W(q + ".bn1.beta");

@@ -68,4 +68,14 @@ struct Conv1NhwcArgs {
     int B, H, W, act;
 };
 bool conv1_pool_nhwc_mfma_fits(int H, int W);
+// the same fused with the first block's depthwise 3x3 (stride sh x sw, pad 1): d_out, xs_out [B][Ho][Wo][32]
+struct Conv1DwArgs {
+    const float* in; const float* w; const float* bias; const float* alpha; const float* beta;
+    const float* dw_wt;              // [9][32] depthwise weights, tap-major
+    float* d_out; float* xs_out;
+    int B, H, W, act, sh, sw;
+    int Ho = 0, Wo = 0, rows_dw = 0; // filled by the launcher
+};
+int conv1_pool_dw_rows(int H, int W, int sh);      // depthwise rows per LDS strip, 0 = does not fit
+hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a, int max_grid, hipStream_t s);
 hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s);

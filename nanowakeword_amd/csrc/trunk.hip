@@ -565,6 +565,199 @@ __global__ void __launch_bounds__(64 * NW, 2) conv1_pool_nhwc_mfma_kernel(Conv1N
     }
 }
 
+// The same first conv fused with the FIRST BLOCK'S depthwise 3x3 (stride sh x sw, padding 1; architectures.py:632-647):
+// the pooled 32-channel planes - 205 KB per clip, 1.7 GB per 8192 clips written and read back when the two stages are
+// separate launches - stay in LDS, one strip of rows at a time, and only the depthwise output d [B][Ho][Wo][32] and the
+// strided centres xs [B][Ho][Wo][32] (the shortcut's input) reach HBM.  Strip s covers depthwise rows [s * rows_dw, ...)
+// and needs the conv rows sh * oy - 1 .. sh * oy + 1 of those; a workgroup takes whole clips (plane staged once, the next
+// clip's plane prefetched into registers), conv -> barrier -> depthwise -> barrier per strip.  Depthwise taps in the
+// order and fmaf chain of dwconv3x3_nhwc_kernel.
+template <int ACT, int NW>
+__global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs a) {
+    constexpr int NTHR = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, Wp0 = W + 2;
+    const int in_f = ((H + 2) * Wp0 + 3) & ~3;
+    float* In = lds;
+    float* P = lds + in_f;                                     // [strip conv rows][W1][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < in_f; k += NTHR) In[k] = 0.0f;
+    const int i1 = lane & 15, g1 = lane >> 4;
+    float wreg[2][3];
+    int tap_off[3];
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int tap = 4 * st + g1;
+        wreg[0][st] = tap < 9 ? a.w[(size_t)i1 * 9 + tap] : 0.0f;
+        wreg[1][st] = tap < 9 ? a.w[(size_t)(16 + i1) * 9 + tap] : 0.0f;
+        tap_off[st] = tap < 9 ? (tap / 3) * Wp0 + (tap % 3) : 0;
+    }
+    float bias[2], al[2], be[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        bias[cb] = a.bias ? a.bias[16 * cb + i1] : 0.0f;
+        al[cb] = a.alpha ? a.alpha[16 * cb + i1] : 1.0f;
+        be[cb] = a.alpha ? a.beta[16 * cb + i1] : 0.0f;
+    }
+    const bool bn = a.alpha != nullptr;
+    const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4;
+    const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
+    const int Ho = a.Ho, Wo = a.Wo, sh = a.sh, sw = a.sw;
+    // depthwise: thread -> (channel c, output column slot); the nine weights of the channel stay in registers
+    const int dc = tid & 31, dslot = tid >> 5;                 // NTHR / 32 column slots
+    float dwt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwt[k] = a.dw_wt[k * 32 + dc];
+    const bool vec_in = (W & 3) == 0 && H * W <= 16 * NTHR;
+    auto load_sync = [&](const float* xin) {
+        for (int idx = tid; idx < H * W; idx += NTHR) {
+            const int y = idx / W, x = idx - y * W;
+            In[(y + 1) * Wp0 + x + 1] = xin[idx];
+        }
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < a.B) load_sync(a.in + (size_t)blockIdx.x * H * W);
+    __syncthreads();
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int bnext = b + gridDim.x;
+        float4 pre[4];
+        const bool fetch = bnext < a.B;
+        if (fetch && vec_in) {
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx4 = tid + q * NTHR;
+                if (idx4 < H * W / 4) pre[q] = xin4[idx4];
+            }
+        }
+        for (int oy0 = 0; oy0 < Ho; oy0 += a.rows_dw) {
+            const int oy1 = min(Ho, oy0 + a.rows_dw);                              // depthwise rows [oy0, oy1)
+            const int r_lo = max(0, sh * oy0 - 1), r_hi = min(H1 - 1, sh * (oy1 - 1) + 1);   // conv (pooled) rows kept in P
+            // ---- conv + BN + act + pool of rows r_lo .. r_hi -> P
+            const int nG = (r_hi - r_lo + 1) * ngx;
+            for (int g = wave; g < nG; g += NW) {
+                const int Rl = g / ngx, X = g - Rl * ngx, R = r_lo + Rl;
+                const int X0 = 4 * X;
+                const float* rowp = In + (2 * R) * Wp0 + 8 * X0 + pix_off;
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[cb][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    const float* q = rowp + tap_off[st];
+                    float av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = q[8 * u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wreg[0][st], acc[0][u], 0, 0, 0);
+                        acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wreg[1][st], acc[1][u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = 4 * (X0 + u) + g1;
+                    if (X0 + u < nX1 && col < W1) {
+                        float* dst = P + ((size_t)Rl * W1 + col) * 32 + i1;
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) {
+                            float m = -INFINITY;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float v = acc[cb][u][q] + bias[cb];
+                                if (bn) v = v * al[cb] + be[cb];
+                                m = fmaxf(m, trunk_act<ACT>(v));
+                            }
+                            dst[16 * cb] = m;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- depthwise 3x3 of the strip's rows out of P
+            float* db = a.d_out + (size_t)b * Ho * Wo * 32;
+            float* xb = a.xs_out + (size_t)b * Ho * Wo * 32;
+            for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 32) {
+                const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
+                float acc = 0.0f, centre = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = oy * sh - 1 + dy;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int xx = ox * sw - 1 + dx;
+                        const bool ok = yy >= 0 && yy < H1 && xx >= 0 && xx < W1;
+                        const float v = ok ? P[((size_t)(yy - r_lo) * W1 + xx) * 32 + dc] : 0.0f;
+                        if (dy == 1 && dx == 1) centre = v;
+                        acc = fmaf(v, dwt[dy * 3 + dx], acc);
+                    }
+                }
+                const size_t oi = ((size_t)oy * Wo + ox) * 32 + dc;
+                db[oi] = acc;
+                xb[oi] = centre;
+            }
+            __syncthreads();
+        }
+        if (fetch) {
+            if (vec_in) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx4 = tid + q * NTHR;
+                    if (idx4 < H * W / 4) {
+                        const int idx = idx4 * 4, y = idx / W, x = idx - y * W;
+                        float* d = In + (y + 1) * Wp0 + x + 1;
+                        d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+                    }
+                }
+            } else {
+                load_sync(a.in + (size_t)bnext * H * W);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// depthwise rows per strip such that input plane + strip planes fit LDS; 0 = does not fit
+int conv1_pool_dw_rows(int H, int W, int sh) {
+    const int H1 = H / 2, W1 = W / 2, Ho = (H1 - 1) / sh + 1;
+    const size_t in_b = ((((size_t)(H + 2) * (W + 2) + 3) & ~(size_t)3) + 16) * sizeof(float);
+    if (H < 4 || W < 4) return 0;
+    for (int strips = 1; strips <= Ho; ++strips) {
+        const int rows = (Ho + strips - 1) / strips;
+        const size_t conv_rows = (size_t)sh * (rows - 1) + 3;
+        if (in_b + conv_rows * W1 * 32 * sizeof(float) <= 160 * 1024) return rows;
+    }
+    return 0;
+}
+
+hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a0, int max_grid, hipStream_t s) {
+    Conv1DwArgs a = a0;
+    a.rows_dw = conv1_pool_dw_rows(a.H, a.W, a.sh);
+    if (a.rows_dw <= 0) return hipErrorInvalidValue;
+    const int H1 = a.H / 2, W1 = a.W / 2;
+    a.Ho = (H1 - 1) / a.sh + 1; a.Wo = (W1 - 1) / a.sw + 1;
+    const size_t in_f = (((size_t)(a.H + 2) * (a.W + 2) + 3) & ~(size_t)3);
+    const size_t lds = (in_f + ((size_t)a.sh * (a.rows_dw - 1) + 3) * W1 * 32 + 16) * sizeof(float);
+    int grid = a.B < max_grid ? a.B : max_grid;
+    if (grid < 1) grid = 1;
+#define C1DW_GO(ACTV)                                                                                              \
+    {                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv1_pool_dw_nhwc_kernel<ACTV, 8>), lds);      \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((conv1_pool_dw_nhwc_kernel<ACTV, 8>), dim3(grid), dim3(512), lds, s, a);                \
+    }
+    switch (a.act) {
+        case ACT_RELU: C1DW_GO(ACT_RELU) break;
+        case ACT_GELU: C1DW_GO(ACT_GELU) break;
+        case ACT_SILU: C1DW_GO(ACT_SILU) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef C1DW_GO
+    return hipGetLastError();
+}
+
 bool conv1_pool_nhwc_mfma_fits(int H, int W) { return H >= 4 && W >= 4 && (size_t)(H + 2) * (W + 2) * 4 + 64 <= 64 * 1024; }
 
 hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s) {

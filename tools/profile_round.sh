@@ -7,11 +7,12 @@ R=${1:-r02}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
-python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $OUT/pytest_gpu.txt
 python bench.py 2>/dev/null | tail -1 | tee $OUT/bench.json
 python tools/tolerance_audit.py > $OUT/tolerance_audit.json 2>$OUT/tolerance_audit.err
 python tools/bench_configs.py 2>/dev/null > $OUT/configs.jsonl
 python tools/latency_b1.py > $OUT/latency_b1.txt 2>&1
+python tools/latency_breakdown.py > $OUT/latency_breakdown.txt 2>&1
 B="python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --prewarm-seconds 0.3 --profile-every 1 --no-cpu-baseline --no-extras"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $B > $OUT/stats.log 2>&1

@@ -228,20 +228,20 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 
 static size_t conv3_x3_a3_bytes(int H, int W) { return ((size_t)(H + 3) * (W + 2) * PS3 + 15) & ~(size_t)15; }
 
-size_t conv3_x3_lds_bytes(int H, int W) {
-    const bool part_in_pads = (H + 3) * (W + 2) >= 512;
-    return conv3_x3_a3_bytes(H, W) + WT_BYTES + (part_in_pads ? 0 : 512 * 16);
+size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) {
+    const bool part_in_pads = (H + 3) * (W + 2) >= 512;       // the avg-pool partials (only that mode needs them)
+    return conv3_x3_a3_bytes(H, W) + WT_BYTES + ((avg_ow <= 0 || part_in_pads) ? 0 : 512 * 16);
 }
 
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
     if (Cout % 32 != 0 || H < 2 || W < 2 || H * W > 512) return false;
     if (avg_ow > 0 && (pool || avg_ow > 4)) return false;
-    return conv3_x3_lds_bytes(H, W) <= 160 * 1024;
+    return conv3_x3_lds_bytes(H, W, avg_ow) <= 160 * 1024;
 }
 
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     if (!conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
-    const size_t lds = conv3_x3_lds_bytes(a.H, a.W);
+    const size_t lds = conv3_x3_lds_bytes(a.H, a.W, a.avg_ow);
     const int ngroups = a.Cout / 32;
     long want = (long)a.B * ngroups;
     int grid = (int)(want < max_grid ? want : max_grid);

@@ -238,6 +238,8 @@ hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int 
 hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t s) {
     if (a0.M <= 0) return hipSuccess;
     if (!lin_x3_supported(K, a0.N) || (ln && epi != 2) || (a0.ldx % 4) || (a0.ldc % 4)) return hipErrorInvalidValue;
+    // 16-byte row loads / stores (as the general GEMM's loaders): refuse a misaligned buffer loudly instead of faulting
+    if (((reinterpret_cast<uintptr_t>(a0.x) | reinterpret_cast<uintptr_t>(a0.out) | reinterpret_cast<uintptr_t>(a0.res)) & 15) != 0) return hipErrorInvalidValue;
     LinArgs a = a0;
     a.nblk = (a.N + 31) / 32;
     const dim3 grid((a.M + 127) / 128);

@@ -555,7 +555,7 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
     // mode keeps the float32-MFMA kernel (the conv3 instance implements the 6-product form only)
     static const int x3_enabled = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
     if (x3_enabled && p.h->conv_products == 6 && conv3_x3_fits(H, W, Cout, avg_ow, pool)) {
-        const size_t lds = conv3_x3_lds_bytes(H, W);
+        const size_t lds = conv3_x3_lds_bytes(H, W, avg_ow);
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
         p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : "conv3_x3:") + name, [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};

@@ -58,7 +58,7 @@ struct ConvMfmaArgs {
 size_t conv_mfma_lds_bytes(int C1, int H, int W);
 hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);
 // split-operand bf16 instance of the same stage (conv3_x3.hip): 32 input channels, Cout % 32 == 0, six products
-size_t conv3_x3_lds_bytes(int H, int W);
+size_t conv3_x3_lds_bytes(int H, int W, int avg_ow);
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool);
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s);
 

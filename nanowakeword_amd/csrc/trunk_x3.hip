@@ -396,6 +396,11 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     int S = trunk_x3_pick_strips(a.H, a.W);
     if (force_strips > S && force_strips <= a.H / 4) S = force_strips;
     if (S < 1) return hipErrorInvalidValue;
+    // a handful of clips (the interpreter's B = 1 .. 16 calls) would occupy a handful of CUs for a whole clip each: cut
+    // every clip into four row strips on four CUs instead (23 -> 9 us at B = 1).  Seam rows are recomputed by both
+    // neighbours with the same arithmetic, so the result does not depend on the strip count (bit for bit).
+    static const int small_strips = [] { const char* e = getenv("NWW_X3_SMALL_STRIPS"); return e ? atoi(e) : 4; }();
+    if (!force_strips && small_strips > S && (long)a.B * small_strips * 4 <= max_grid && small_strips <= a.H / 4) S = small_strips;
     aa.strips = S;
     const size_t lds = trunk_x3_lds_bytes(a.H, a.W, S);
     // experiments: NWW_X3_WAVES=4 runs 4-wave workgroups, two per CU when the strip fits 80 KB

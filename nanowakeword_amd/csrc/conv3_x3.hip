@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         *reinterpret_cast<uint16_t*>(d + 1024) = (uint16_t)(tm >> 16);
         *reinterpret_cast<uint16_t*>(d + 2048) = (uint16_t)(tl >> 16);
     }
+    const int seq_ch = (POOL && a.seq_out) ? a.Cout * Ho : 0;
     const int cout = 32 * grp + i;
     const float bias = a.bias ? a.bias[cout] : 0.0f;
     const float al = a.alpha ? a.alpha[cout] : 1.0f, be = a.alpha ? a.beta[cout] : 0.0f;
@@ -151,8 +152,8 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             avg_epilogue(acc0, R0, X0, wsum, aw);
             if (TWO) avg_epilogue(acc1, R1, X1, wsum, aw);
         } else {
-            conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
-            if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw);
+            conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw, seq_ch);
+            if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw, seq_ch);
         }
     };
 
@@ -201,7 +202,9 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         }
         __syncthreads();
         prefetch(b + b_step);
-        float* outb = a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
+        // planes [Cout][Ho][Wo], or (seq_out, pooled mode) the clip's sequence rows [Wo][Cout * Ho] at channel 32 grp
+        float* outb = seq_ch ? a.out + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho
+                             : a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
         float wsum[4] = {0.f, 0.f, 0.f, 0.f};
         const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow};
         int t = t_begin;

@@ -24,11 +24,11 @@ struct AvgWin { int kw, sw, ow; };       // windows [j*sw, j*sw + kw) along x, j
 // acc = tile (R, X): conv rows 2R, 2R+1, columns 16X .. 16X+15; register 4k+q of lane (i, hi) is channel i, column
 // 16X + 4k + 2hi + (q & 1), row 2R + (q >> 1).
 // POOL: outb = [cout][H2][W2] pooled planes (H2, W2 pooled sizes).  !POOL: outb = [cout][H2][W2] with H2, W2 the conv
-// output sizes.  AVG: nothing is stored; wsum[j] collects the lane's share of window j.
+// output sizes.  AVG: nothing is stored; wsum[j] collects the lane's share of window j.  seq_ch != 0 (POOL only): see below.
 template <int ACT, bool POOL, bool AVG>
 __device__ __forceinline__ void conv_tile_epilogue(const f32x16& acc, int R, int X, float bias2, float al2, float be2,
                                                    bool has_bn, float* outb, int i, int hi, int H2, int W2, int r_off,
-                                                   float* wsum, AvgWin aw) {
+                                                   float* wsum, AvgWin aw, int seq_ch = 0) {
     if (POOL) {
         float own[4];
 #pragma unroll
@@ -49,6 +49,16 @@ __device__ __forceinline__ void conv_tile_epilogue(const f32x16& acc, int R, int
         if (hi == 0) { o.x = own[0]; o.y = r0; o.z = own[1]; o.w = r1; }
         else         { o.x = r0; o.y = own[2]; o.z = r1; o.w = own[3]; }
         const int pcol = 8 * X + 4 * hi;
+        if (seq_ch) {
+            // sequence layout for the recurrent layers (CRNN: permute(0, 3, 1, 2) + flatten, architectures.py:270-272):
+            // outb = the clip's [W2][seq_ch] rows, feature index = channel * H2 + row (channel = the caller's base + i)
+            float* dq = outb + (size_t)pcol * seq_ch + (size_t)i * H2 + R + r_off;
+            if (pcol + 0 < W2) dq[0] = o.x;
+            if (pcol + 1 < W2) dq[seq_ch] = o.y;
+            if (pcol + 2 < W2) dq[2 * (size_t)seq_ch] = o.z;
+            if (pcol + 3 < W2) dq[3 * (size_t)seq_ch] = o.w;
+            return;
+        }
         float* dst = outb + ((size_t)i * H2 + R + r_off) * W2 + pcol;
         if ((W2 & 3) == 0 && pcol + 3 < W2) {
             *reinterpret_cast<float4*>(dst) = o;

@@ -543,7 +543,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 // 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
-                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0) {
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr) {
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
@@ -557,13 +557,15 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
     if (x3_enabled && p.h->conv_products == 6 && conv3_x3_fits(H, W, Cout, avg_ow, pool)) {
         const size_t lds = conv3_x3_lds_bytes(H, W, avg_ow);
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : "conv3_x3:") + name, [=](Run& r) {
+        const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
+        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name, [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
-            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
+            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out;
             return launch_conv3_x3(a, max_grid * per_cu, r.stream);
         });
         return true;
     }
+    if (seq_inout) *seq_inout = false;                         // the float32-MFMA instance writes planes
     p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
         ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
         a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
@@ -786,6 +788,7 @@ extern "C" int nww_finalize(nww_handle* h) {
         case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287
             int cin = 1, hh = T, ww = F, cur = -1;
             int first = 0;
+            bool seq_written = false;
             if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
                 add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
                           p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
@@ -795,15 +798,23 @@ extern "C" int nww_finalize(nww_handle* h) {
             for (int i = first; i < c.n_crnn_channels; ++i) {
                 const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
-                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1))
+                // the last conv stage may write the recurrent layers' [W][C * H] sequence layout itself (conv3_x3.hip)
+                static const int seq_fused = [] { const char* e = getenv("NWW_CRNN_SEQ_FUSED"); return e ? atoi(e) : 1; }();
+                bool seq = seq_fused && i == c.n_crnn_channels - 1;
+                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq)) {
+                    seq = false;
                     add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
+                }
+                seq_written = seq;
                 hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
             }
             if (hh < 1 || ww < 1) return fail(h, NWW_ERR_INVALID, "crnn input too small for the conv stack");
-            const int seq = cur ^ 1, C = cin, Hc = hh, Wc = ww;
-            p.need(seq, (size_t)C * Hc * Wc);
-            p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
-            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, cur, 3, 4, c.crnn_rnn_lstm ? 4 : 3);
+            const int seq = seq_written ? cur : cur ^ 1, C = cin, Hc = hh, Wc = ww;
+            if (!seq_written) {
+                p.need(seq, (size_t)C * Hc * Wc);
+                p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
+            }
+            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, seq ^ 1, 3, 4, c.crnn_rnn_lstm ? 4 : 3);      // seq ^ 1: the free one of buffers 0 / 1
             set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }

@@ -54,6 +54,8 @@ struct ConvMfmaArgs {
     int B, H, W, Cout, act, pool;
     // fused AvgPool2d(kernel (H, avg_kw), stride (H, avg_sw)) -> out [B][Cout][avg_ow] when avg_ow > 0 (pool must be 0)
     int avg_kw = 0, avg_sw = 0, avg_ow = 0;
+    // conv3_x3 only, pooled mode: write out [B][W/2][Cout * H/2] (feature = channel * H/2 + row), the recurrent layers' input
+    int seq_out = 0;
 };
 size_t conv_mfma_lds_bytes(int C1, int H, int W);
 hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);

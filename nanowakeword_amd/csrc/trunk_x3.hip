@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
 // BN: either conv carries a folded BatchNorm (a missing one is alpha = 1, beta = 0, which is exact).
 // A workgroup keeps ONE strip index for its whole life, so the zero halos written once stay valid.  (Walking whole clips
 // strip by strip instead - equal work per workgroup, halo rows re-zeroed per item - measured 0.417 vs 0.406 ms.)
-template <int ACT, int PRODUCTS, bool BN, int NW>
+template <int ACT, int PRODUCTS, bool BN, int NW, bool V1 = false>
 __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     // conv2's bf16 MFMAs overlap with the SIMD's other wave's VALU / LDS work only when their accumulators live in
     // AGPRs (tools/ubench/mfma_valu_overlap.hip: max(a, b) instead of a + b).  hipcc picks the VGPR form for kernels
@@ -305,7 +305,64 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     for (int b = b0; b < a.B; b += bstep) {
         const int bnext = b + bstep;
         // ---------------- P1: conv1 + act + pool, split into bf16 terms -> A1 (channels last)
-        if (!(a.dbg & 1)) {
+        if constexpr (V1) {
+            // conv1 on the VALU ALONE (no float32 MFMA, which blocks every other wave's VALU and cannot run beside the
+            // other workgroup's bf16 MFMAs): lane = pooled pixel, its 4 x 4 input patch in registers (eight 8-byte LDS
+            // reads), the channel's nine weights and bias / BN come in as scalar operands (uniform s_loads), four conv
+            // pixels x nine fmaf per channel, pool, three-way split; the pixel's 16 channels leave as six 16-byte LDS
+            // stores (the MFMA form writes 48 two-byte pieces).  With two 4-wave workgroups per CU in opposite phases
+            // this phase runs under the other workgroup's conv2 MFMAs (AGPR accumulators: DESIGN.md 4.2a).
+            const int npx = n_a1 * W1;
+            for (int p0 = wave * 64; p0 < npx && !(a.dbg & 1); p0 += 64 * NW) {
+                const int p = p0 + lane;
+                const bool ok = p < npx;
+                const int pp = ok ? p : npx - 1;
+                const int R = pp / W1, x = pp - R * W1;
+                const float* base = In + (2 * R) * Wp0 + 2 * x;
+                float pt[4][4];
+#pragma unroll
+                for (int dy = 0; dy < 4; ++dy) {
+                    const float2 lo2 = *reinterpret_cast<const float2*>(base + dy * Wp0);
+                    const float2 hi2 = *reinterpret_cast<const float2*>(base + dy * Wp0 + 2);
+                    pt[dy][0] = lo2.x; pt[dy][1] = lo2.y; pt[dy][2] = hi2.x; pt[dy][3] = hi2.y;
+                }
+                uint32_t ph[C1 / 2], pm[C1 / 2], pl[C1 / 2];      // channel pairs packed as they are produced (register budget)
+#pragma unroll
+                for (int c2 = 0; c2 < C1 / 2; ++c2) {
+                    uint32_t th[2], tm[2], tl[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = 2 * c2 + e;
+                        float acc[4];
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const float w = a.w1[c * 9 + tap];
+                            const int ty = tap / 3, tx = tap - 3 * ty;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v = pt[(q >> 1) + ty][(q & 1) + tx];
+                                acc[q] = tap == 0 ? v * w : fmaf(v, w, acc[q]);
+                            }
+                        }
+                        const float m = pool_quad<ACT, BN>(acc[0], acc[1], acc[2], acc[3], a.b1 ? a.b1[c] : 0.0f,
+                                                           a.al1 ? a.al1[c] : 1.0f, a.al1 ? a.be1[c] : 0.0f);
+                        split3(m, th[e], tm[e], tl[e]);
+                    }
+                    ph[c2] = pack_hi16(th[0], th[1]); pm[c2] = pack_hi16(tm[0], tm[1]); pl[c2] = pack_hi16(tl[0], tl[1]);
+                    asm volatile("" : "+v"(ph[c2]), "+v"(pm[c2]), "+v"(pl[c2]));      // keeps the pairs from being computed all at once
+                }
+                if (ok) {
+                    unsigned char* wp = A1 + ((a1_shift + R) * Wp1 + x + 1) * PS;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int o = 4 * half;
+                        *reinterpret_cast<uint4*>(wp + 16 * half) = make_uint4(ph[o], ph[o + 1], ph[o + 2], ph[o + 3]);
+                        *reinterpret_cast<uint4*>(wp + 32 + 16 * half) = make_uint4(pm[o], pm[o + 1], pm[o + 2], pm[o + 3]);
+                        *reinterpret_cast<uint4*>(wp + 64 + 16 * half) = make_uint4(pl[o], pl[o + 1], pl[o + 2], pl[o + 3]);
+                    }
+                }
+            }
+        } else if (!(a.dbg & 1)) {
             f32x4 acc[4];
             int R = R_first, X = X_first;
             for (int g = wave; g < nG; g += NW) {
@@ -362,9 +419,9 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
     static_assert(NW == 8, "8-wave shape");
     cnn_trunk_x3_body<ACT, PRODUCTS, BN, 8>(a);
 }
-template <int ACT, int PRODUCTS, bool BN>
+template <int ACT, int PRODUCTS, bool BN, bool V1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) cnn_trunk_x3_kernel4(TrunkArgs a) {
-    cnn_trunk_x3_body<ACT, PRODUCTS, BN, 4>(a);
+    cnn_trunk_x3_body<ACT, PRODUCTS, BN, 4, V1>(a);
 }
 }  // namespace
 
@@ -406,6 +463,10 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     // experiments: NWW_X3_WAVES=4 runs 4-wave workgroups, two per CU when the strip fits 80 KB
     static const int force_nw = [] { const char* e = getenv("NWW_X3_WAVES"); return e ? atoi(e) : 0; }();
     const int nw = force_nw == 4 ? 4 : 8;
+    // NWW_X3_V1=1 (with NWW_X3_WAVES=4): conv1 on the VALU alone.  Parity-green and measured NEUTRAL (0.429 vs 0.425 ms; phase
+    // ablation: conv1 0.17 + conv2 0.20 + skeleton 0.03 add up exactly, with either conv1): the two workgroups of a CU
+    // stay in phase, and even in perfect anti-phase a lone VALU wave per SIMD issues at half the two-wave rate.
+    static const int valu_conv1 = [] { const char* e = getenv("NWW_X3_V1"); return e ? atoi(e) : 0; }();
     const int per_cu = (nw == 4 && lds <= 80 * 1024) ? 2 : 1;
     long want = (long)a.B * S, cap = (long)max_grid * per_cu;
     int grid = (int)(want < cap ? want : cap);
@@ -418,12 +479,14 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((cnn_trunk_x3_kernel<ACTV, PRODV, BNV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, aa);  \
     }
-#define X3T_LAUNCH4(ACTV, PRODV, BNV)                                                                              \
+#define X3T_LAUNCH4V(ACTV, PRODV, BNV, V1V)                                                                        \
     {                                                                                                              \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_x3_kernel4<ACTV, PRODV, BNV>), lds);   \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_x3_kernel4<ACTV, PRODV, BNV, V1V>), lds);  \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((cnn_trunk_x3_kernel4<ACTV, PRODV, BNV>), dim3(grid), dim3(256), lds, s, aa);           \
+        hipLaunchKernelGGL((cnn_trunk_x3_kernel4<ACTV, PRODV, BNV, V1V>), dim3(grid), dim3(256), lds, s, aa);      \
     }
+#define X3T_LAUNCH4(ACTV, PRODV, BNV)                                                                              \
+    if (valu_conv1) X3T_LAUNCH4V(ACTV, PRODV, BNV, true) else X3T_LAUNCH4V(ACTV, PRODV, BNV, false)
 #define X3T_NW(ACTV, PRODV, BNV)                                                                                   \
     if (nw == 4) X3T_LAUNCH4(ACTV, PRODV, BNV) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
 #define X3T_BN(ACTV, PRODV)                                                                                        \
@@ -438,6 +501,7 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     }
 #undef X3T_LAUNCH
 #undef X3T_LAUNCH4
+#undef X3T_LAUNCH4V
 #undef X3T_NW
 #undef X3T_BN
 #undef X3T_ACT

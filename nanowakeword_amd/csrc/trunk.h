@@ -15,6 +15,7 @@ struct TrunkArgs {
     // > 0: write the output as the split-operand GEMM's A tiles instead of [B][C2][H/4][W/4]: 128-clip row blocks x
     // out_blocked k-tiles of 32 features, each (row block, k-tile) a contiguous [128][32] float tile (gemm_x3.hip)
     int out_blocked = 0;
+    int n0 = 0;                                        // trunk_x3, two strips: workgroups [0, n0) take strip 0, the rest strip 1 (0 = alternate)
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;

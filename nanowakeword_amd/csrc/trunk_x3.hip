@@ -175,7 +175,11 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     int n_a1, a1_shift, nR2, n_in, row_shift, a1_bytes, in_f;
     size_t in_off, out_off;
     {
-        const TrunkStrip sg = trunk_strip(H, S, (int)blockIdx.x % S);
+        // strip of this workgroup (kept for life).  Default: blockIdx % S.  With two strips of unequal cost (25 pooled rows =
+        // 13 + 12: 26 conv2 tiles take the 8 waves four rounds, 24 take three) the first a.n0 workgroups take strip 0 and
+        // the rest strip 1, each group walking all clips - more CUs on the dearer strip instead of idle ones at the end.
+        const int sidx = (a.n0 > 0 && S == 2) ? ((int)blockIdx.x < a.n0 ? 0 : 1) : (int)blockIdx.x % S;
+        const TrunkStrip sg = trunk_strip(H, S, sidx);
         n_a1 = sg.a1_hi - sg.a1_lo + 1;
         a1_shift = sg.a1_lo - sg.a1_base;
         nR2 = sg.R2b - sg.R2a;
@@ -292,7 +296,9 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     const int R_first = wave / ngx, X_first = wave - R_first * ngx;
     const bool full1 = (W1 & 15) == 0;
 
-    const int b0 = (int)blockIdx.x / S, bstep = (int)gridDim.x / S;
+    const bool uneven = a.n0 > 0 && S == 2;
+    const int b0 = uneven ? ((int)blockIdx.x < a.n0 ? (int)blockIdx.x : (int)blockIdx.x - a.n0) : (int)blockIdx.x / S;
+    const int bstep = uneven ? ((int)blockIdx.x < a.n0 ? a.n0 : (int)gridDim.x - a.n0) : (int)gridDim.x / S;
     if (a.skew > 0) {
         // two 4-wave workgroups per CU run identical items and would stay in the same phase (conv1: VALU/latency-heavy,
         // conv2: matrix-pipe-bound) forever; delay the one that got the SIMD's second wave slot by part of an item once
@@ -472,6 +478,21 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     int grid = (int)(want < cap ? want : cap);
     grid -= grid % S;
     if (grid < S) grid = S;
+    // uneven split of the workgroups over two strips (see the kernel): share of strip 0 in 1/256ths, when the grid is full
+    // Measured on the (101,64) clip (13 + 12 pooled rows), trunk ms for strip 0's share 128 / 130 / 132 / 134 / 136 / 142 of
+    // 256: 0.436 / 0.433 / 0.430 / 0.423 / 0.432 / 0.449 against 0.446 with alternating strips.  NWW_X3_N0 overrides
+    // (-1 = alternate).
+    static const int n0_env = [] { const char* e = getenv("NWW_X3_N0"); return e ? atoi(e) : 0; }();
+    int n0_share = n0_env;
+    if (n0_env == 0 && S == 2) {
+        const TrunkStrip s0 = trunk_strip(a.H, 2, 0), s1 = trunk_strip(a.H, 2, 1);
+        if (s0.R2b - s0.R2a > s1.R2b - s1.R2a) n0_share = 134;     // the odd pooled row makes strip 0 ~10 % dearer
+    }
+    aa.n0 = 0;
+    if (S == 2 && n0_share > 0 && n0_share < 256 && nw == 8 && grid >= 64 && (long)a.B * 2 >= 2L * grid) {
+        aa.n0 = (int)((long)grid * n0_share / 256);
+        if (aa.n0 < 1 || aa.n0 >= grid) aa.n0 = 0;
+    }
     const bool bn = a.al1 != nullptr || a.al2 != nullptr;
 #define X3T_LAUNCH(ACTV, PRODV, BNV, NWV)                                                                          \
     {                                                                                                              \

@@ -42,6 +42,9 @@ struct GemmArgs {
     // deterministic split-K: when splitk > 1, partial[z][M][N] go to splitk_ws and a second kernel adds them
     // in z order before the epilogue (bit-reproducible, unlike atomics). 0/1 = off.
     int splitk = 0; float* splitk_ws = nullptr;
+    // split-K only: leave the partials in splitk_ws and skip the reduce launch - the consumer (the fused classifier tail)
+    // sums them itself, in the same z order, and applies bias / BN / activation (nww_api.hip: Run::deferred)
+    bool defer_reduce = false;
     // W pre-split into three bf16 terms ([N][ceil(K/16)][3][16], gemm_x3.hip); when set the contraction runs on the
     // bf16 matrix cores with exact operand splitting (float32-equivalent), else on v_mfma_f32_32x32x2_f32
     const void* Wx3 = nullptr;
@@ -129,6 +132,10 @@ struct TailArgs {
     const float *W0, *b0, *w3, *b3;
     float *emb, *logits, *probs;
     int B, act;
+    // x given as split-K partials of the producing GEMM: x[b][k] = in_act((sum_z parts[z][b][k] + in_bias[k]) * in_alpha[k] + in_beta[k]),
+    // z ascending (gemm_splitk_reduce_kernel's order and epilogue, bit for bit)
+    const float* parts = nullptr; int nparts = 0; size_t part_stride = 0;
+    const float *in_bias = nullptr, *in_alpha = nullptr, *in_beta = nullptr; int in_act = 0;
 };
 bool tail_supported(int Kin, int E);
 hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s);

@@ -262,7 +262,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         static const int use_x3s = [] { const char* e = getenv("NWW_X3S"); return e ? atoi(e) : 0; }();
         hipError_t e = (use_x3s && g.M > 64) ? launch_gemm_x3s(g, s) : launch_gemm_x3(g, s);
         if (e != hipSuccess) return e;
-        if (g.splitk > 1 && g.splitk_ws) {
+        if (g.splitk > 1 && g.splitk_ws && !g.defer_reduce) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
         }
@@ -284,7 +284,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
             default: GL_CALL(ACT_NONE) break;
         }
 #undef GL_CALL
-        if (sk > 1) {
+        if (sk > 1 && !g.defer_reduce) {
             const size_t total = (size_t)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         }
@@ -1261,7 +1261,28 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
     for (int b0 = blockIdx.x * 16; b0 < a.B; b0 += gridDim.x * 16) {
         for (int idx = tid; idx < 16 * Kin; idx += 256) {
             const int cc = idx / Kin, k = idx - cc * Kin;
-            xs[cc * ldx + k] = (b0 + cc < a.B) ? a.x[(size_t)(b0 + cc) * Kin + k] : 0.0f;
+            float v = 0.0f;
+            if (b0 + cc < a.B) {
+                if (a.parts) {                                 // the producer's split-K partials: its reduce + epilogue, done here
+                    const size_t o = (size_t)(b0 + cc) * Kin + k;
+                    // all loads of a batch of eight partials in flight before the (ordered) adds
+                    float acc = 0.0f;
+                    for (int z0 = 0; z0 < a.nparts; z0 += 8) {
+                        float pv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pv[j] = z0 + j < a.nparts ? a.parts[(size_t)(z0 + j) * a.part_stride + o] : 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (z0 + j < a.nparts) acc = (z0 + j == 0) ? pv[j] : acc + pv[j];
+                    }
+                    v = acc + (a.in_bias ? a.in_bias[k] : 0.0f);
+                    if (a.in_alpha) v = v * a.in_alpha[k] + a.in_beta[k];
+                    v = act_apply(v, a.in_act);
+                } else {
+                    v = a.x[(size_t)(b0 + cc) * Kin + k];
+                }
+            }
+            xs[cc * ldx + k] = v;
         }
         __syncthreads();
         // embedding: outputs e = g, g+16, ...; four at a time

@@ -45,6 +45,8 @@ struct Run {
     float* probs = nullptr;     // [B] or null; a plan step that writes it clears `need_sigmoid`
     bool need_sigmoid = true;
     float* splitk_ws = nullptr; size_t splitk_floats = 0; int cu_count = 256;
+    // a split-K GEMM that left its partials for the classifier tail to reduce (GemmArgs::defer_reduce)
+    struct { bool active = false; int out_id = 0, parts = 0; size_t stride = 0; const float *bias = nullptr, *alpha = nullptr, *beta = nullptr; int act = 0; } deferred;
 };
 
 }  // namespace
@@ -429,7 +431,7 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 // rows_per_clip: M = B*rows_per_clip
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
-              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr) {
+              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -471,6 +473,15 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         if (wx3 && x3_mode != 2 && K >= 4096) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
         g.splitk_ws = r.splitk_ws;
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
+        r.deferred.active = false;
+        // a handful of clips (the interpreter's calls): the fused tail sums the partials itself, in the same order - one
+        // dependent launch less (B = 1: 62 -> 58 us back-to-back).  Larger batches keep the reduce launch: the tail's few
+        // workgroups read the 16 partials slower than the full-grid reduce does (B = 4096: 0.028 vs 0.019 + 0.007 ms).
+        if (feeds_tail && g.M <= 8 && g.splitk > 1 && g.splitk_ws && !g.res) {
+            g.defer_reduce = true;
+            r.deferred.active = true; r.deferred.out_id = out_id; r.deferred.parts = g.splitk; r.deferred.stride = (size_t)g.M * N;
+            r.deferred.bias = bias; r.deferred.alpha = alpha; r.deferred.beta = beta; r.deferred.act = act;
+        }
         return launch_gemm(g, r.stream);
     });
 }
@@ -737,8 +748,11 @@ extern "C" int nww_finalize(nww_handle* h) {
                 add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
                 add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
             }
+            // fc1's split-K partials are reduced by the classifier tail itself when that is the fused kernel (NWW_TAIL_REDUCE=0: own launch)
+            static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
+            static const int tail_reduce = [] { const char* e = getenv("NWW_TAIL_REDUCE"); return e ? atoi(e) : 1; }();
             add_gemm(p, "fc1", 1, 0, 1, 128, 32 * H2 * W2, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, nullptr, nullptr, 99, 1.f,
-                     &h->trunk_blocked);
+                     &h->trunk_blocked, tail_on && tail_reduce && tail_supported(128, E));
             set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
             break;
         }
@@ -985,6 +999,11 @@ extern "C" int nww_finalize(nww_handle* h) {
         const int tin = p.tail_in, tK = p.tail_K;
         p.add("tail:" + p.tail_name + "+classifier", [=](Run& r) {
             TailArgs t{src(r, tin), tK, We, be, E, W0, b0, w3, b3, r.emb, r.logits, r.probs, r.B, act};
+            if (r.deferred.active && r.deferred.out_id == tin) {
+                t.parts = r.splitk_ws; t.nparts = r.deferred.parts; t.part_stride = r.deferred.stride;
+                t.in_bias = r.deferred.bias; t.in_alpha = r.deferred.alpha; t.in_beta = r.deferred.beta; t.in_act = r.deferred.act;
+            }
+            r.deferred.active = false;
             r.need_sigmoid = false;
             return launch_classifier_tail(t, r.stream);
         });

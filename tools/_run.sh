@@ -1,4 +1,5 @@
-for rep in 1 2; do for n0 in 0 130 132 134 136; do
-NWW_X3_N0=$n0 python bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "
+for v in 1 0; do NWW_TAIL_REDUCE=$v python bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('n0=$n0', d['ms_per_step'], d['kernel_ms']['trunk_x3:conv1+pool+conv2+pool'])"; done; done
+d = json.loads(sys.stdin.read()); print('tail_reduce=$v', d['ms_per_step'], d['kernel_ms'])"; done
+python tools/latency_breakdown.py 2>&1 | grep "^cnn B=1" | cut -c1-330
+NWW_TAIL_REDUCE=0 python tools/latency_breakdown.py 2>&1 | grep "^cnn B=1" | cut -c1-330

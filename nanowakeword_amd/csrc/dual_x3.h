@@ -1,0 +1,22 @@
+// dual_x3.h - BcResNet block's pointwise + shortcut products on the bf16 matrix cores (dual_x3.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct DualArgs {
+    const float* d;                  // [M][K] depthwise output rows
+    const float* xs;                 // [M][K] block input at the strided centres
+    float* out;                      // [M][N]
+    const unsigned char* packed;     // launch_dual_x3_pack output
+    int M, N;
+    int nblk = 0;                    // filled by the launcher
+};
+
+// one packed 32-output block: 2 x K/16 x 3 fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps
+__host__ __device__ inline size_t dual_x3_block_bytes(int K) { return ((size_t)2 * (K / 16) * 3072 + 512 + 4095) & ~(size_t)4095; }
+bool dual_x3_supported(int K, int N);
+size_t dual_x3_packed_bytes(int K, int N);
+// Wpw, Wsc [N][K]; (a1, b1) folded BN of the pointwise branch, (as, bs) of the shortcut (null = 1 / 0)
+hipError_t launch_dual_x3_pack(const float* Wpw, const float* Wsc, const float* a1, const float* b1, const float* as,
+                               const float* bs, void* out, int K, int N, hipStream_t s);
+hipError_t launch_dual_x3(const DualArgs& a, int K, int act, hipStream_t s);

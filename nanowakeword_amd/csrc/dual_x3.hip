@@ -1,0 +1,246 @@
+// dual_x3.hip - the pointwise half of a BcResNet block (architectures.py:632-647) on the bf16 matrix cores by exact operand
+// splitting, input-stationary:
+//     out[m][n] = BN_s( xs[m] . Wsc[n] )  +  act( BN_1( d[m] . Wpw[n] ) )          m = pixel (B x Ho x Wo), K = C_in = 32 / 64 / 128
+// (d = depthwise output, xs = the block input at the strided centres; activation BEFORE the residual add).  The float32-MFMA
+// dual GEMM this replaces (layers.hip: gemm_lds_kernel<ACT, 1>) is matrix-pipe-bound for the wider blocks (0.41 / 0.69 ms
+// for blocks 2 / 3 at 8192 clips, where the bf16 pipe needs a sixth of the float32 pipe's time even with six products).
+//
+// Organisation of lin_x3.hip with two inputs: a wave owns 32 pixels for the whole kernel, BOTH of their rows live in
+// registers as 3 x K/16 B fragments each; per 32-output block the products are computed transposed,
+//     Pt [32 outputs x 32 pixels] = Wpw block . Dt,     St = Wsc block . Xst,
+// so a lane holds 4 consecutive output channels of ONE pixel per register group (16-byte stores); the workgroup's four
+// waves share each block's weights through LDS (plan-time packed fragments + the four folded-BN vectors, fetched one block
+// ahead by global_load_lds_dwordx4 into the other of two buffers, one barrier per block).
+// Tried and dropped: computing d and xs here from the block input (depthwise 3x3 once per pixel, no d / xs round trip) -
+// correct, but hipcc needs 256 VGPRs + 256 AGPRs + scratch for the nine-tap loader next to the resident fragments (K = 64:
+// 0.86 ms against 0.30 + 0.24 apart; K = 128: 1.73 against 0.32 + 0.45).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "layers.h"
+#include "dual_x3.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ void split3d(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+__device__ __forceinline__ uint32_t pack16d(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ void split_frag_d(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3d(v[e], h[e], m[e], l[e]);
+    union { uint4 u; bf16x8 b; } ch, cm, cl;
+    ch.u = make_uint4(pack16d(h[0], h[1]), pack16d(h[2], h[3]), pack16d(h[4], h[5]), pack16d(h[6], h[7]));
+    cm.u = make_uint4(pack16d(m[0], m[1]), pack16d(m[2], m[3]), pack16d(m[4], m[5]), pack16d(m[6], m[7]));
+    cl.u = make_uint4(pack16d(l[0], l[1]), pack16d(l[2], l[3]), pack16d(l[4], l[5]), pack16d(l[6], l[7]));
+    fh = ch.b; fm = cm.b; fl = cl.b;
+}
+
+template <int ACT>
+__device__ __forceinline__ float dual_act(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+// six products, small terms first (the order of gemm_x3.hip): w = weight fragments (A operand), x = activation fragments (B)
+__device__ __forceinline__ void mfma6d(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
+}
+
+// plan-time packing: block = [part 0 = Wpw | 1 = Wsc][kb][term][lane] 16-byte fragments, then a1[32], b1[32], as[32], bs[32]
+__global__ void __launch_bounds__(256) dual_pack_kernel(const float* __restrict__ Wpw, const float* __restrict__ Wsc,
+                                                        const float* __restrict__ a1, const float* __restrict__ b1,
+                                                        const float* __restrict__ as, const float* __restrict__ bs,
+                                                        unsigned char* __restrict__ out, int K, int N) {
+    const int K16 = K / 16, nblk = (N + 31) / 32;
+    const size_t blk_bytes = dual_x3_block_bytes(K);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nblk * 2 * K16 * 64) return;
+    const int lane = (int)(idx & 63);
+    size_t r = idx >> 6;
+    const int kb = (int)(r % K16); r /= K16;
+    const int part = (int)(r & 1), blk = (int)(r >> 1);
+    const int i = lane & 31, h = lane >> 5;
+    const int col = 32 * blk + i;
+    const float* W = part ? Wsc : Wpw;
+    unsigned char* base = out + (size_t)blk * blk_bytes;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col < N ? W[(size_t)col * K + 16 * kb + 8 * h + e] : 0.0f;
+    uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3d(v[e], hh[e], mm[e], ll[e]);
+    unsigned char* dst = base + ((size_t)((part * K16 + kb) * 3) * 64 + lane) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack16d(hh[0], hh[1]), pack16d(hh[2], hh[3]), pack16d(hh[4], hh[5]), pack16d(hh[6], hh[7]));
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16d(mm[0], mm[1]), pack16d(mm[2], mm[3]), pack16d(mm[4], mm[5]), pack16d(mm[6], mm[7]));
+    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16d(ll[0], ll[1]), pack16d(ll[2], ll[3]), pack16d(ll[4], ll[5]), pack16d(ll[6], ll[7]));
+    if (kb == 0 && part == 0 && lane < 32) {
+        float* aff = reinterpret_cast<float*>(base + (size_t)2 * K16 * 3072);
+        const bool ok = col < N;
+        aff[lane] = ok ? (a1 ? a1[col] : 1.0f) : 0.0f;
+        aff[32 + lane] = ok && b1 ? b1[col] : 0.0f;
+        aff[64 + lane] = ok ? (as ? as[col] : 1.0f) : 0.0f;
+        aff[96 + lane] = ok && bs ? bs[col] : 0.0f;
+    }
+}
+
+template <int K16, int ACT>
+__global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
+    constexpr int K = 16 * K16;
+    constexpr int FRAG_BYTES = 2 * K16 * 3072, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
+    // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
+    __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
+    __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int row = (int)blockIdx.x * 128 + wave * 32 + n;
+    const bool row_ok = row < a.M;
+    const size_t rr = (size_t)(row_ok ? row : a.M - 1);
+
+    auto fetch = [&](int blk, unsigned char* buf) {
+        const unsigned char* sp = a.packed + (size_t)blk * BLK + tid * 16;
+        unsigned char* dst = buf + wave * 1024;                          // wave-uniform
+#pragma unroll
+        for (int j = 0; j < BLK / 4096; ++j)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sp + j * 4096),
+                                             (void __attribute__((address_space(3)))*)(dst + j * 4096), 16, 0, 0);
+    };
+    fetch(0, wb0);
+
+    // ---- the lane's half rows (features 16kb + 8h + e) of d and xs -> fragments
+    bf16x8 xf[2][K16][3];
+    {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* xrow = (p ? a.xs : a.d) + rr * K;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb) {
+                const float4 p0 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h);
+                const float4 p1 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h + 4);
+                const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                split_frag_d(v, xf[p][kb][0], xf[p][kb][1], xf[p][kb][2]);
+            }
+        }
+    }
+
+    float* orow = a.out + rr * a.N;
+    auto block = [&](int blk, const unsigned char* wbuf) {
+        const unsigned char* wp = wbuf + lane * 16;
+        f32x16 acc[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        bf16x8 nw[2][3];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * 3 + t) * 1024);
+#pragma unroll
+        for (int kb = 0; kb < K16; ++kb) {
+            bf16x8 cw[2][3];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) cw[p][t] = nw[p][t];
+            if (kb + 1 < K16) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * 3 + t) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma6d(cw[0], xf[0][kb], acc[0]);
+            mfma6d(cw[1], xf[1][kb], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
+        if (!row_ok) return;
+        const float* aff = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 32 * blk + 8 * g + 4 * h;
+            if (col < a.N) {                                   // N % 4 == 0: the four channels are in or out together
+                const float4 a1 = *reinterpret_cast<const float4*>(aff + 8 * g), b1 = *reinterpret_cast<const float4*>(aff + 32 + 8 * g);
+                const float4 as = *reinterpret_cast<const float4*>(aff + 64 + 8 * g), bs = *reinterpret_cast<const float4*>(aff + 96 + 8 * g);
+                float4 o;
+                o.x = (acc[1][4 * g + 0] * as.x + bs.x) + dual_act<ACT>(acc[0][4 * g + 0] * a1.x + b1.x);
+                o.y = (acc[1][4 * g + 1] * as.y + bs.y) + dual_act<ACT>(acc[0][4 * g + 1] * a1.y + b1.y);
+                o.z = (acc[1][4 * g + 2] * as.z + bs.z) + dual_act<ACT>(acc[0][4 * g + 2] * a1.z + b1.z);
+                o.w = (acc[1][4 * g + 3] * as.w + bs.w) + dual_act<ACT>(acc[0][4 * g + 3] * a1.w + b1.w);
+                *reinterpret_cast<float4*>(orow + col) = o;
+            }
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nblk = a.nblk;
+    for (int blk = 0; blk < nblk; blk += 2) {
+        if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
+        block(blk, wb0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blk + 1 < nblk) {
+            if (blk + 2 < nblk) fetch(blk + 2, wb0);
+            block(blk + 1, wb1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+bool dual_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 128) && N % 4 == 0 && N >= 4; }
+
+size_t dual_x3_packed_bytes(int K, int N) { return (size_t)((N + 31) / 32) * dual_x3_block_bytes(K); }
+
+hipError_t launch_dual_x3_pack(const float* Wpw, const float* Wsc, const float* a1, const float* b1, const float* as,
+                               const float* bs, void* out, int K, int N, hipStream_t s) {
+    const size_t total = (size_t)((N + 31) / 32) * 2 * (K / 16) * 64;
+    hipLaunchKernelGGL(dual_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Wpw, Wsc, a1, b1, as, bs,
+                       reinterpret_cast<unsigned char*>(out), K, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
+    if (a0.M <= 0) return hipSuccess;
+    if (!dual_x3_supported(K, a0.N)) return hipErrorInvalidValue;
+    if (((reinterpret_cast<uintptr_t>(a0.d) | reinterpret_cast<uintptr_t>(a0.xs) | reinterpret_cast<uintptr_t>(a0.out)) & 15) != 0)
+        return hipErrorInvalidValue;
+    DualArgs a = a0;
+    a.nblk = (a.N + 31) / 32;
+    const dim3 grid((a.M + 127) / 128);
+#define DUAL_GO(K16V, ACTV) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV>), grid, dim3(256), 0, s, a);
+#define DUAL_ACT(K16V)                                                                                             \
+    switch (act) {                                                                                                 \
+        case ACT_RELU: DUAL_GO(K16V, ACT_RELU) break;                                                              \
+        case ACT_GELU: DUAL_GO(K16V, ACT_GELU) break;                                                              \
+        case ACT_SILU: DUAL_GO(K16V, ACT_SILU) break;                                                              \
+        default: return hipErrorInvalidValue;                                                                      \
+    }
+    switch (K) {
+        case 32: DUAL_ACT(2) break;
+        case 64: DUAL_ACT(4) break;
+        case 128: DUAL_ACT(8) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DUAL_ACT
+#undef DUAL_GO
+    return hipGetLastError();
+}

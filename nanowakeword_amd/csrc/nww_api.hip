@@ -17,6 +17,7 @@
 #include "trunk.h"
 #include "ffn_x3.h"
 #include "lin_x3.h"
+#include "dual_x3.h"
 #include "emb_stream.h"
 #include <dlfcn.h>
 
@@ -907,6 +908,22 @@ extern "C" int nww_finalize(nww_handle* h) {
                     const float *wsc = p.W(q + ".shortcut.0.weight"), *as = p.W(q + ".shortcut.1.alpha"), *bs = p.W(q + ".shortcut.1.beta");
                     const int rows = ho * wo;
                     p.need(outb, (size_t)rows * co);
+                    // both products from split operands on the bf16 matrix cores (dual_x3.hip) under the same arithmetic switch
+                    static const int dual_x3 = [] { const char* e = getenv("NWW_BC_DUAL_X3"); return e ? atoi(e) : 1; }();
+                    void* packed = nullptr;
+                    if (dual_x3 && p.h->conv_products == 6 && dual_x3_supported(ci, co) &&
+                        hipMalloc(&packed, dual_x3_packed_bytes(ci, co)) == hipSuccess) {
+                        if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream) == hipSuccess) {
+                            p.h->packed_weights.push_back(packed);
+                            p.add("dual_x3:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
+                                DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
+                                return launch_dual_x3(a, ci, act, r.stream);
+                            });
+                            hh = ho; ww = wo; cur = outb;
+                            continue;
+                        }
+                        (void)hipFree(packed);
+                    }
                     p.add("gemm2:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
                         GemmArgs g;
                         g.A = r.buf[dwb]; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;

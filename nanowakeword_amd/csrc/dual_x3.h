@@ -10,6 +10,9 @@ struct DualArgs {
     const unsigned char* packed;     // launch_dual_x3_pack output
     int M, N;
     int nblk = 0;                    // filled by the launcher
+    // x != nullptr: xs is not read; the shortcut's rows are gathered from the block input x [B][H][W][K] (channels last) at
+    // (oy * sh, ox * sw) of pixel m = (b, oy, ox), M = B * Ho * Wo
+    const float* x = nullptr; int H = 0, W = 0, Ho = 0, Wo = 0, sh = 1, sw = 1;
 };
 
 // one packed 32-output block: 2 x K/16 x 3 fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps

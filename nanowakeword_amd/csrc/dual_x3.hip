@@ -124,10 +124,18 @@ __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
 
     // ---- the lane's half rows (features 16kb + 8h + e) of d and xs -> fragments
     bf16x8 xf[2][K16][3];
+    const float* xs_row = nullptr;
+    if (a.x) {
+        const int per = a.Ho * a.Wo;
+        const int b = (int)(rr / per), r2 = (int)(rr - (size_t)b * per), oy = r2 / a.Wo, ox = r2 - oy * a.Wo;
+        xs_row = a.x + (((size_t)b * a.H + (size_t)oy * a.sh) * a.W + (size_t)ox * a.sw) * K;
+    }
     {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const float* xrow = (p ? a.xs : a.d) + rr * K;
+            // xs: its own [M][K] rows, or (a.x) the block input x [B][H][W][K] read at the strided centre of the pixel - the
+            // depthwise kernel then does not write a copy of those rows
+            const float* xrow = (p ? (a.x ? xs_row : a.xs + rr * K) : a.d + rr * K);
 #pragma unroll
             for (int kb = 0; kb < K16; ++kb) {
                 const float4 p0 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h);
@@ -221,8 +229,9 @@ hipError_t launch_dual_x3_pack(const float* Wpw, const float* Wsc, const float* 
 hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     if (a0.M <= 0) return hipSuccess;
     if (!dual_x3_supported(K, a0.N)) return hipErrorInvalidValue;
-    if (((reinterpret_cast<uintptr_t>(a0.d) | reinterpret_cast<uintptr_t>(a0.xs) | reinterpret_cast<uintptr_t>(a0.out)) & 15) != 0)
+    if (((reinterpret_cast<uintptr_t>(a0.d) | reinterpret_cast<uintptr_t>(a0.xs) | reinterpret_cast<uintptr_t>(a0.out) | reinterpret_cast<uintptr_t>(a0.x)) & 15) != 0)
         return hipErrorInvalidValue;
+    if (a0.x && (a0.Ho <= 0 || a0.Wo <= 0 || a0.M % (a0.Ho * a0.Wo) != 0)) return hipErrorInvalidValue;
     DualArgs a = a0;
     a.nblk = (a.N + 31) / 32;
     const dim3 grid((a.M + 127) / 128);

@@ -496,9 +496,69 @@ dwconv3x3_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ wt
     if (xs_out) xs_out[idx] = centre;
 }
 
+// Four outputs along x and four channels per thread: the 3 x ((4 - 1) sw + 3) input columns are loaded once as 16-byte pieces
+// (stride 1: 18 loads for 4 outputs instead of 36 four-byte ones per channel; stride 2: 27), the nine weights of the four
+// channels stay in registers.  Same tap order and fmaf chain as dwconv3x3_nhwc_kernel.  xs_out is not supported (the
+// split-operand block kernel gathers the shortcut rows itself).
+template <int SW>
+__global__ void __launch_bounds__(256)
+dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ d_out, int C, int H, int W,
+                         int Ho, int Wo, int sh, size_t total) {
+    constexpr int NX = 4, COLS = (NX - 1) * SW + 3;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // ((b*Ho + oy)*Wg + xg)*C4 + c4
+    if (idx >= total) return;
+    const int C4 = C / 4, Wg = (Wo + NX - 1) / NX;
+    const int c4 = (int)(idx % C4);
+    size_t t = idx / C4;
+    const int xg = (int)(t % Wg);
+    t /= Wg;
+    const int oy = (int)(t % Ho);
+    const size_t b = t / Ho;
+    const float* ip = in + b * (size_t)H * W * C + 4 * c4;
+    float4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(wt + (size_t)k * C + 4 * c4);
+    float4 acc[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int x_first = xg * NX * SW - 1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy * sh - 1 + dy;
+        const bool oky = yy >= 0 && yy < H;
+        float4 v[COLS];
+#pragma unroll
+        for (int cx = 0; cx < COLS; ++cx) {
+            const int xx = x_first + cx;
+            v[cx] = (oky && xx >= 0 && xx < W) ? *reinterpret_cast<const float4*>(ip + ((size_t)yy * W + xx) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const float4 p = v[j * SW + dx], q = w[dy * 3 + dx];
+                acc[j].x = fmaf(p.x, q.x, acc[j].x); acc[j].y = fmaf(p.y, q.y, acc[j].y);
+                acc[j].z = fmaf(p.z, q.z, acc[j].z); acc[j].w = fmaf(p.w, q.w, acc[j].w);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int ox = xg * NX + j;
+        if (ox < Wo) *reinterpret_cast<float4*>(d_out + ((b * Ho + oy) * (size_t)Wo + ox) * C + 4 * c4) = acc[j];
+    }
+}
+
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
                                  int W, int sh, int sw, hipStream_t s) {
     const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+    static const int x4 = [] { const char* e = getenv("NWW_DW_X4"); return e ? atoi(e) : 1; }();
+    if (x4 && !xs_out && C % 4 == 0 && (sw == 1 || sw == 2) &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0) {
+        const size_t total4 = (size_t)B * Ho * ((Wo + 3) / 4) * (C / 4);
+        if (sw == 1) hipLaunchKernelGGL(dwconv3x3_nhwc_x4_kernel<1>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, wt, d_out, C, H, W, Ho, Wo, sh, total4);
+        else hipLaunchKernelGGL(dwconv3x3_nhwc_x4_kernel<2>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, wt, d_out, C, H, W, Ho, Wo, sh, total4);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * Ho * Wo * C;
     hipLaunchKernelGGL(dwconv3x3_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, wt, d_out,
                        xs_out, C, H, W, Ho, Wo, sh, sw, total);

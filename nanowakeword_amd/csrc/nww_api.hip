@@ -421,6 +421,7 @@ struct PlanCtx {
         if (h->buf_per_clip[buf] < floats_per_clip) h->buf_per_clip[buf] = floats_per_clip;
     }
     void add(const std::string& name, std::function<hipError_t(Run&)> fn) { h->plan.push_back({name, std::move(fn)}); }
+    void pop_last() { if (!h->plan.empty()) h->plan.pop_back(); }        // a step just planned is re-planned in another form
     // the head's last Linear (-> embedding), deferred so that it can be fused with the classifier into one launch
     std::string tail_name; int tail_in = 99, tail_K = 0; const float *tail_W = nullptr, *tail_b = nullptr;
 };
@@ -915,8 +916,17 @@ extern "C" int nww_finalize(nww_handle* h) {
                         hipMalloc(&packed, dual_x3_packed_bytes(ci, co)) == hipSuccess) {
                         if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream) == hipSuccess) {
                             p.h->packed_weights.push_back(packed);
-                            p.add("dual_x3:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
+                            // when the block input is in HBM (every block but the one whose depthwise ran inside the fused front kernel) the
+                            // shortcut rows are gathered from it and the depthwise kernel planned just above writes no copy of them
+                            static const int xs_gather = [] { const char* e = getenv("NWW_BC_XS_GATHER"); return e ? atoi(e) : 1; }();
+                            const bool gather = xs_gather && !(front_fused && i == 1);
+                            if (gather) {
+                                p.pop_last();
+                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream); });
+                            }
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
+                                if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });
                             hh = ho; ww = wo; cur = outb;

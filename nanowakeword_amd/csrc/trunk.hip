@@ -719,6 +719,9 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
     }
 }
 
+// LDS budget of a workgroup: 80 KB = smaller strips (six depthwise rows), TWO workgroups per CU - one's MFMA / epilogue phases
+// under the other's depthwise phase: 1.14 -> 0.95 ms at 8192 clips (NWW_BC_FRONT_LDS_KB=160: one per CU; 100: 1.19, 56: 1.04)
+static int front_lds_kb() { static const int kb = [] { const char* e = getenv("NWW_BC_FRONT_LDS_KB"); const int v = e ? atoi(e) : 80; return v >= 32 && v <= 160 ? v : 160; }(); return kb; }
 // depthwise rows per strip such that input plane + strip planes fit LDS; 0 = does not fit
 int conv1_pool_dw_rows(int H, int W, int sh) {
     const int H1 = H / 2, W1 = W / 2, Ho = (H1 - 1) / sh + 1;
@@ -727,7 +730,7 @@ int conv1_pool_dw_rows(int H, int W, int sh) {
     for (int strips = 1; strips <= Ho; ++strips) {
         const int rows = (Ho + strips - 1) / strips;
         const size_t conv_rows = (size_t)sh * (rows - 1) + 3;
-        if (in_b + conv_rows * W1 * 32 * sizeof(float) <= 160 * 1024) return rows;
+        if (in_b + conv_rows * W1 * 32 * sizeof(float) <= (size_t)front_lds_kb() * 1024) return rows;
     }
     return 0;
 }
@@ -740,7 +743,8 @@ hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a0, int max_grid, hipStr
     a.Ho = (H1 - 1) / a.sh + 1; a.Wo = (W1 - 1) / a.sw + 1;
     const size_t in_f = (((size_t)(a.H + 2) * (a.W + 2) + 3) & ~(size_t)3);
     const size_t lds = (in_f + ((size_t)a.sh * (a.rows_dw - 1) + 3) * W1 * 32 + 16) * sizeof(float);
-    int grid = a.B < max_grid ? a.B : max_grid;
+    const int per_cu = front_lds_kb() <= 80 ? 2 : 1;
+    int grid = a.B < max_grid * per_cu ? a.B : max_grid * per_cu;
     if (grid < 1) grid = 1;
 #define C1DW_GO(ACTV)                                                                                              \
     {                                                                                                              \

@@ -134,7 +134,8 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_X3_WAVES": "4", "NWW_TRUNK_STRIPS": "3", "NWW_X3_V1": "1"}, [_CNN, _E2E], ["trunk_x3"], [], False),   # 4-wave trunk, conv1 on the VALU
     ({"NWW_X3_N0": "-1"}, [_CNN], ["trunk_x3"], [], False),                             # strips alternating over the workgroups
     ({"NWW_TAIL_REDUCE": "0"}, [_CNN], [], [], False),                                  # fc1's split-K partials reduced by their own launch
-    ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                     # BcResNet block products on the float32-MFMA dual GEMM
+    ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),
+    ({"NWW_BC_XS_GATHER": "0", "NWW_DW_X4": "0", "NWW_BC_FRONT_LDS_KB": "160"}, [_BC], ["dual_x3:"], ["xs gathered"], False),   # shortcut rows copied, scalar depthwise, one front workgroup per CU                     # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
     ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
     ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel

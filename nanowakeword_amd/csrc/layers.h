@@ -91,6 +91,8 @@ hipError_t launch_layernorm(const float* x, float* y, const float* w, const floa
                             hipStream_t s);
 // mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)
 hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s);
+// LayerNorm over D of every row of [B][L][D], then the mean over L -> out [B][D] (D <= 256)
+hipError_t launch_ln_mean(const float* x, float* out, const float* w, const float* b, int B, int L, int D, hipStream_t s);
 // AvgPool2d(kernel (kh,kw), stride (sh,sw)) on [B*C][H][W] -> [B*C][oh][ow]  (export form of AdaptiveAvgPool2d)
 hipError_t launch_avgpool(const float* in, float* out, int BC, int H, int W, int kh, int kw, int sh, int sw, int oh,
                           int ow, hipStream_t s);

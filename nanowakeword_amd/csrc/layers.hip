@@ -624,6 +624,47 @@ mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, in
     for (int l = 0; l < L; ++l) s += p[(size_t)l * D];
     out[idx] = s / (float)L;
 }
+// LayerNorm of every row of a clip followed by the mean over its rows, in one pass over [B][L][D] (the Conformer's last
+// block.layer_norm + x.mean(dim=1), architectures.py:536-541): one workgroup per clip, a wave normalises rows w, w + 4, ...
+// with the row in registers (layernorm_kernel's arithmetic) and keeps per-lane sums; the four waves' sums are added in wave
+// order.  D <= 256.
+__global__ void __launch_bounds__(256)
+ln_mean_kernel(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ w, const float* __restrict__ bvec,
+               int L, int D) {
+    __shared__ float part[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (size_t)blockIdx.x * L * D;
+    float wv[4], bv[4], acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        wv[j] = i < D ? w[i] : 0.0f; bv[j] = i < D ? bvec[i] : 0.0f; acc[j] = 0.0f;
+    }
+    for (int row = wave; row < L; row += 4) {
+        const float* xr = xb + (size_t)row * D;
+        float v[4];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = lane + 64 * j; v[j] = i < D ? xr[i] : 0.0f; s += v[j]; }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; if (lane + 64 * j < D) q = fmaf(d, d, q); }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (v[j] - mu) * rstd * wv[j] + bv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave][lane + 64 * j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) out[(size_t)blockIdx.x * D + i] = (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]) / (float)L;
+}
+hipError_t launch_ln_mean(const float* x, float* out, const float* w, const float* b, int B, int L, int D, hipStream_t s) {
+    if (D > 256 || B <= 0) return D > 256 ? hipErrorInvalidValue : hipSuccess;
+    hipLaunchKernelGGL(ln_mean_kernel, dim3(B), dim3(256), 0, s, x, out, w, b, L, D);
+    return hipGetLastError();
+}
+
 hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s) {
     const size_t total = (size_t)B * D;
     hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total);

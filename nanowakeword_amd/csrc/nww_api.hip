@@ -955,6 +955,7 @@ extern "C" int nww_finalize(nww_handle* h) {
         case NWW_HEAD_CONFORMER: {                // ConformerModel: architectures.py:441-543
             const int D = c.conformer_d_model, NH = c.conformer_n_head;
             const int hb = 0, t1 = 1, t3 = 2, big = 3;      // h, LN/glu/attn scratch, dwconv scratch, wide scratch
+            bool last_fused = false;
             p.need(t1, (size_t)T * D); p.need(t3, (size_t)T * D);
             if (!add_lin_x3(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), 0))
                 add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
@@ -1011,9 +1012,16 @@ extern "C" int nww_finalize(nww_handle* h) {
                 }
                 ffn(".ff2");
                 const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
-                p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[hb], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                // the last block's LayerNorm feeds only the mean over time: one pass for both (NWW_LN_MEAN=0: two launches)
+                static const int ln_mean = [] { const char* e = getenv("NWW_LN_MEAN"); return e ? atoi(e) : 1; }();
+                if (ln_mean && i == nb - 1 && D <= 256) {
+                    p.add("layernorm+mean:" + q + " + time", [=](Run& r) { return launch_ln_mean(r.buf[hb], r.buf[t1], lw, lb, r.B, T, D, r.stream); });
+                    last_fused = true;
+                } else {
+                    p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[hb], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                }
             }
-            p.add("mean:time", [=](Run& r) { return launch_mean_mid(r.buf[hb], r.buf[t1], r.B, T, D, r.stream); });
+            if (!last_fused) p.add("mean:time", [=](Run& r) { return launch_mean_mid(r.buf[hb], r.buf[t1], r.B, T, D, r.stream); });
             set_tail(p, "output_proj", t1, D, p.W("model.output_proj.weight"), p.W("model.output_proj.bias"));
             break;
         }

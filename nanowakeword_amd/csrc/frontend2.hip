@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, 3)
 fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad,
                 int n_mels, float amin, float db_mult, float floor_db, const FeTables* __restrict__ gtb,
                 const Fe2MelPlan* __restrict__ plan, float* __restrict__ out_db, float* __restrict__ out_mel,
-                int frames_major, int dbg, int skew_units) {
+                int frames_major, int dbg, int skew_units, int gsz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MFMA_MEL = MEL == 1;
     const int lane = threadIdx.x & 63;
@@ -118,8 +118,8 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
     uint32_t cur[8];                                         // samples of the S1 iteration about to run (lane's column)
     auto geom = [&](int item, int& b, int& t0, int& nf) {
         b = item / ngroups;
-        t0 = (item - b * ngroups) * FE2_G;
-        nf = min(FE2_G, T - t0);
+        t0 = (item - b * ngroups) * gsz;                     // gsz = frames per group: FE2_G, or fewer for a handful of clips
+        nf = min(gsz, T - t0);
     };
     // An item is "interior" when all its frames lie inside the clip and the clip is 4-byte aligned: S1 reads its
     // samples straight from global memory, one iteration ahead (and the first iteration of the NEXT item during
@@ -164,8 +164,9 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
             }
         }
         // ---- S1: window + radix-8 + twiddle -> Y[f][k1][n2]; two frames per iteration, next iteration's samples in flight
+        const int nit = (nf + 1) >> 1;                          // frame pairs that exist (a short group stops early)
 #pragma unroll 1
-        for (int it = 0; it < FE2_G / 2; ++it) {
+        for (int it = 0; it < nit; ++it) {
             const int f = 2 * it + slot, fn = f + 2;
             uint32_t nxt[8];
 #pragma unroll
@@ -292,7 +293,7 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
                 // are staged too - the copy-out takes nf rows only
                 const float* p0 = slab + mel_lo_lane;
 #pragma unroll 1
-                for (int f = 0; f < FE2_G; f += 2) {
+                for (int f = 0; f < nf; f += 2) {
                     const float* pa = p0 + f * FE2_FRAME_DW + FE2_PSHIFT(f);        // PSHIFT(f) == PSHIFT(f + 1) for even f
                     const float* pb = pa + FE2_FRAME_DW;
                     float ma = 0.0f, mb = 0.0f;
@@ -378,7 +379,7 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
                       int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream) {
     if (block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
     const int nwv = block / 64;
-    const int ngroups = (T + FE2_G - 1) / FE2_G;
+    int ngroups = (T + FE2_G - 1) / FE2_G;
     // mel_mode: 2 = register-resident filters (falls back to the MFMA tiles when the filterbank does not fit), 1, 0
     int mode = mel_mode;
     if (mode == 2 && (p.n_mels > 64 || max_taps > 28)) mode = 1;
@@ -395,12 +396,20 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
     }
     static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
     static const int skew = [] { const char* e = getenv("NWW_FE_SKEW"); return e ? atoi(e) : 0; }();   // experiment: x 4096 clocks per wave slot
+    // A handful of clips (the interpreter's calls) would put 8 frames on each of a few waves and leave the GPU empty: two
+    // frames per wave instead (S1 / S3 / S4 scale with the frames, S2 does not) - B = 1: 13 -> 7 us.  Register-filter mel only.
+    static const int small_g = [] { const char* e = getenv("NWW_FE_SMALL_G"); return e ? atoi(e) : 2; }();
+    int gsz = FE2_G;
+    if (mode == 2 && small_g >= 2 && small_g < FE2_G && (small_g % 2) == 0 && (long long)B * ngroups * 4 <= (long long)max_grid * nwv) {
+        gsz = small_g;
+        ngroups = (T + gsz - 1) / gsz;
+    }
     const long long total = (long long)B * ngroups;
     long long need = (total + nwv - 1) / nwv;
     int grid = (int)(need < max_grid ? need : max_grid);
     if (grid < 1) grid = 1;
     const int pad = p.center ? FE_NFFT / 2 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, d_pcm, row_stride, B, N, T, ngroups, p.hop, pad, p.n_mels,
-                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, skew);
+                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, skew, gsz);
     return hipGetLastError();
 }

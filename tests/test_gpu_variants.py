@@ -139,7 +139,8 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_BC_XS_GATHER": "0", "NWW_DW_X4": "0", "NWW_BC_FRONT_LDS_KB": "160"}, [_BC], ["dual_x3:"], ["xs gathered"], False),   # shortcut rows copied, scalar depthwise, one front workgroup per CU                     # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
     ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
-    ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel
+    ({"NWW_FE_MEL": "0"}, [], [], [], True),
+    ({"NWW_FE_SMALL_G": "0"}, [], [], [], True),                                        # eight frames per wave also for a handful of clips                                            # sparse VALU mel in the wave-private kernel
     ({"NWW_TRUNK_STRIPS": "3"}, [_CNN], ["trunk"], [], False),                          # three row strips
     ({"NWW_TAIL": "0"}, [_CNN, _GRU], [], ["tail:"], False),                            # separate GEMMs + sigmoid instead of the fused tail
 ], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else None)

@@ -175,6 +175,9 @@ def test_batch_invariance_full_size(hip, golden_frontend):
     assert np.isfinite(lg).all()
     l16, _ = m.forward_pcm(x[:16])
     assert np.array_equal(lg[:16], l16)
+    for nb in (1, 3, 8):                                       # the interpreter-sized calls take shortcuts (four trunk strips, two-frame
+        ls, _ = m.forward_pcm(x[:nb])                          # frontend groups, split-K reduce inside the tail): same bits
+        assert np.array_equal(lg[:nb], ls), nb
     perm = np.random.default_rng(0).permutation(4096)
     lp, _ = m.forward_pcm(np.ascontiguousarray(x[perm]))
     assert np.array_equal(lp, lg[perm])

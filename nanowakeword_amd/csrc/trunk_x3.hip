@@ -87,10 +87,12 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
 }
 
 // conv2 for tile t (and t+1 when TWO): 32 pixels (2 rows x 16 columns) x 32 output channels
+// wl != nullptr: the weight fragments come from LDS (wl = the lane's slot of the [27][64] x 16-byte table) instead of bw
 template <int ACT, int PRODUCTS, bool BN, bool TWO>
 __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane_off, int rowB, int nX, int t,
                                                const bf16x8 (&bw)[27], float bias2, float al2, float be2,
-                                               float* outb, int i, int hi, int H2, int W2, int blk_kt, int blk_k0) {
+                                               float* outb, int i, int hi, int H2, int W2, int blk_kt, int blk_k0,
+                                               const unsigned char* wl = nullptr) {
     const int R0 = t / nX, X0 = t - R0 * nX;
     const int t1 = TWO ? t + 1 : t;
     const int R1 = t1 / nX, X1 = t1 - R1 * nX;
@@ -99,29 +101,31 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    bf16x8 na[3], nb[3];
+    bf16x8 na[3], nb[3], nw[3];
 #pragma unroll
     for (int tm = 0; tm < 3; ++tm) {
         na[tm] = *reinterpret_cast<const bf16x8*>(pa + 32 * tm);
         if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + 32 * tm);
+        if (wl) nw[tm] = *reinterpret_cast<const bf16x8*>(wl + tm * 1024);
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        bf16x8 ca[3], cb[3];
+        bf16x8 ca[3], cb[3], cw[3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; }
+        for (int tm = 0; tm < 3; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; if (wl) cw[tm] = nw[tm]; }
         if (tap + 1 < 9) {
             const int off = ((tap + 1) / 3) * rowB + ((tap + 1) % 3) * PS;
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm) {
                 na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 32 * tm);
                 if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + off + 32 * tm);
+                if (wl) nw[tm] = *reinterpret_cast<const bf16x8*>(wl + (3 * (tap + 1) + tm) * 1024);
             }
         }
         // next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc otherwise sinks them to their first use)
         __builtin_amdgcn_sched_barrier(0);
-        tap_mfma<PRODUCTS>(ca, &bw[3 * tap], acc0);
-        if (TWO) tap_mfma<PRODUCTS>(cb, &bw[3 * tap], acc1);
+        tap_mfma<PRODUCTS>(ca, wl ? cw : &bw[3 * tap], acc0);
+        if (TWO) tap_mfma<PRODUCTS>(cb, wl ? cw : &bw[3 * tap], acc1);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -158,7 +162,7 @@ __device__ __forceinline__ void conv2_tiles_x3(const unsigned char* A1, int lane
 // BN: either conv carries a folded BatchNorm (a missing one is alpha = 1, beta = 0, which is exact).
 // A workgroup keeps ONE strip index for its whole life, so the zero halos written once stay valid.  (Walking whole clips
 // strip by strip instead - equal work per workgroup, halo rows re-zeroed per item - measured 0.417 vs 0.406 ms.)
-template <int ACT, int PRODUCTS, bool BN, int NW, bool V1 = false>
+template <int ACT, int PRODUCTS, bool BN, int NW, bool V1 = false, bool WLDS = false>
 __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     // conv2's bf16 MFMAs overlap with the SIMD's other wave's VALU / LDS work only when their accumulators live in
     // AGPRs (tools/ubench/mfma_valu_overlap.hip: max(a, b) instead of a + b).  hipcc picks the VGPR form for kernels
@@ -166,7 +170,9 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
     // budget 128 / 128 - too few VGPRs for the 108 registers of conv2 weight fragments (it then parks them in AGPRs and
     // copies them back before every MFMA: measured 0.46 vs 0.39 ms).  The 4-wave form has a 512-register budget, so
     // 224 VGPRs + 32 accumulator AGPRs = 256 registers, two workgroups per CU, works: the empty asm flips the form.
-    if constexpr (NW == 4) { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }
+    // WLDS (8-wave shape): conv2's weight fragments live in LDS (27 KB) instead of 108 VGPRs, which leaves room for the AGPR
+    // form inside the 128 + 128 split of a 256-register budget
+    if constexpr (NW == 4 || WLDS) { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }
     constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
@@ -208,12 +214,24 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
         const uint4 vh = make_uint4(pack_hi16(th[0], th[1]), pack_hi16(th[2], th[3]), pack_hi16(th[4], th[5]), pack_hi16(th[6], th[7]));
         const uint4 vm = make_uint4(pack_hi16(tm[0], tm[1]), pack_hi16(tm[2], tm[3]), pack_hi16(tm[4], tm[5]), pack_hi16(tm[6], tm[7]));
         const uint4 vl = make_uint4(pack_hi16(tl[0], tl[1]), pack_hi16(tl[2], tl[3]), pack_hi16(tl[4], tl[5]), pack_hi16(tl[6], tl[7]));
-        bw[3 * tap + 0] = __builtin_bit_cast(bf16x8, vh);
-        bw[3 * tap + 1] = __builtin_bit_cast(bf16x8, vm);
-        bw[3 * tap + 2] = __builtin_bit_cast(bf16x8, vl);
+        if constexpr (WLDS) {                                  // straight to the LDS table (wave 0; identical in every wave)
+            if (wave == 0) {
+                unsigned char* wt0 = lds_raw + (size_t)in_f * 4 + (((size_t)a1_bytes + 64 + 15) & ~(size_t)15) + lane * 16;
+                *reinterpret_cast<uint4*>(wt0 + (3 * tap + 0) * 1024) = vh;
+                *reinterpret_cast<uint4*>(wt0 + (3 * tap + 1) * 1024) = vm;
+                *reinterpret_cast<uint4*>(wt0 + (3 * tap + 2) * 1024) = vl;
+            }
+        } else {
+            bw[3 * tap + 0] = __builtin_bit_cast(bf16x8, vh);
+            bw[3 * tap + 1] = __builtin_bit_cast(bf16x8, vm);
+            bw[3 * tap + 2] = __builtin_bit_cast(bf16x8, vl);
+        }
     }
     const float bias2 = a.b2 ? a.b2[i] : 0.0f;
     const float al2 = a.al2 ? a.al2[i] : 1.0f, be2 = a.al2 ? a.be2[i] : 0.0f;
+    // WLDS: wave 0 parks the fragments (identical in every wave) behind A1; everyone reads them back per tap
+    unsigned char* Wt = A1 + (((size_t)a1_bytes + 64 + 15) & ~(size_t)15);
+    const unsigned char* wl = WLDS ? Wt + lane * 16 : nullptr;
 
     // conv1 weights -> B fragments of the 16x16x4 MFMA: lane (g = l>>4, channel = l&15), step st: tap 4*st + g
     float w1reg[3];
@@ -397,17 +415,17 @@ __device__ __forceinline__ void cnn_trunk_x3_body(const TrunkArgs& a) {
         if (!(a.dbg & 2)) {
             int t = t_begin;
             if (wave >= NW / 2 && t < t_end) {           // out of phase with the SIMD's other wave (see trunk.hip)
-                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
+                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0, wl);
                 t += 1;
             }
             if (NW == 8)                                     // the 4-wave shape has no registers for a second tile in flight
                 for (; t + 1 < t_end; t += 2)
-                    conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, true>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0, wl);
             else
                 for (; t + 1 < t_end; t += 1)
-                    conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
+                    conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0, wl);
             if (t < t_end)
-                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0);
+                conv2_tiles_x3<ACT, PRODUCTS, BN, false>(A1, lane_off, rowB, nX, t, bw, bias2, al2, be2, outb, i, hi, H2, W2, blk_kt, blk_k0, wl);
         }
         if (fetch) {
             if (vec_in) store_plane_regs(pre);
@@ -424,6 +442,10 @@ template <int ACT, int PRODUCTS, bool BN, int NW>
 __global__ void __launch_bounds__(512, 2) cnn_trunk_x3_kernel(TrunkArgs a) {
     static_assert(NW == 8, "8-wave shape");
     cnn_trunk_x3_body<ACT, PRODUCTS, BN, 8>(a);
+}
+template <int ACT, int PRODUCTS, bool BN>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_x3_kernel_wlds(TrunkArgs a) {
+    cnn_trunk_x3_body<ACT, PRODUCTS, BN, 8, false, true>(a);
 }
 template <int ACT, int PRODUCTS, bool BN, bool V1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) cnn_trunk_x3_kernel4(TrunkArgs a) {
@@ -473,6 +495,10 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     // ablation: conv1 0.17 + conv2 0.20 + skeleton 0.03 add up exactly, with either conv1): the two workgroups of a CU
     // stay in phase, and even in perfect anti-phase a lone VALU wave per SIMD issues at half the two-wave rate.
     static const int valu_conv1 = [] { const char* e = getenv("NWW_X3_V1"); return e ? atoi(e) : 0; }();
+    // NWW_X3_WLDS=1: conv2 weight fragments in LDS + AGPR accumulators in the 8-wave shape; parity-green, measured slower
+    // (0.403 vs 0.383 ms), kept for A/B
+    static const int wlds_env = [] { const char* e = getenv("NWW_X3_WLDS"); return e ? atoi(e) : 0; }();
+    const bool wlds = wlds_env && nw == 8 && lds + 27 * 1024 + 96 <= 160 * 1024;
     const int per_cu = (nw == 4 && lds <= 80 * 1024) ? 2 : 1;
     long want = (long)a.B * S, cap = (long)max_grid * per_cu;
     int grid = (int)(want < cap ? want : cap);
@@ -508,8 +534,14 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
     }
 #define X3T_LAUNCH4(ACTV, PRODV, BNV)                                                                              \
     if (valu_conv1) X3T_LAUNCH4V(ACTV, PRODV, BNV, true) else X3T_LAUNCH4V(ACTV, PRODV, BNV, false)
+#define X3T_LAUNCHW(ACTV, PRODV, BNV)                                                                              \
+    {                                                                                                              \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_x3_kernel_wlds<ACTV, PRODV, BNV>), lds + 27 * 1024 + 96);  \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((cnn_trunk_x3_kernel_wlds<ACTV, PRODV, BNV>), dim3(grid), dim3(512), lds + 27 * 1024 + 96, s, aa);   \
+    }
 #define X3T_NW(ACTV, PRODV, BNV)                                                                                   \
-    if (nw == 4) X3T_LAUNCH4(ACTV, PRODV, BNV) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
+    if (nw == 4) X3T_LAUNCH4(ACTV, PRODV, BNV) else if (wlds) X3T_LAUNCHW(ACTV, PRODV, BNV) else X3T_LAUNCH(ACTV, PRODV, BNV, 8)
 #define X3T_BN(ACTV, PRODV)                                                                                        \
     if (bn) X3T_NW(ACTV, PRODV, true) else X3T_NW(ACTV, PRODV, false)
 #define X3T_ACT(ACTV)                                                                                              \
@@ -523,6 +555,7 @@ hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, h
 #undef X3T_LAUNCH
 #undef X3T_LAUNCH4
 #undef X3T_LAUNCH4V
+#undef X3T_LAUNCHW
 #undef X3T_NW
 #undef X3T_BN
 #undef X3T_ACT

@@ -133,7 +133,7 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma"], False),   # init conv and block1 depthwise apart
     ({"NWW_CRNN_SEQ_FUSED": "0"}, [_CRNN, _CRNN_LSTM], ["crnn_seq"], ["conv3_x3+seq"], False),   # sequence layout by its own kernel
     ({"NWW_X3_WAVES": "4", "NWW_TRUNK_STRIPS": "3", "NWW_X3_V1": "1"}, [_CNN, _E2E], ["trunk_x3"], [], False),   # 4-wave trunk, conv1 on the VALU
-    ({"NWW_X3_N0": "-1"}, [_CNN], ["trunk_x3"], [], False),                             # strips alternating over the workgroups
+    ({"NWW_X3_N0": "-1", "NWW_X3_WLDS": "1"}, [_CNN], ["trunk_x3"], [], False),         # conv2 weight fragments in LDS + AGPR accumulators                             # strips alternating over the workgroups
     ({"NWW_TAIL_REDUCE": "0"}, [_CNN], [], [], False),                                  # fc1's split-K partials reduced by their own launch
     ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),
     ({"NWW_BC_XS_GATHER": "0", "NWW_DW_X4": "0", "NWW_BC_FRONT_LDS_KB": "160"}, [_BC], ["dual_x3:"], ["xs gathered"], False),   # shortcut rows copied, scalar depthwise, one front workgroup per CU                     # BcResNet block products on the float32-MFMA dual GEMM

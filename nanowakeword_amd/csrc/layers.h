@@ -107,7 +107,8 @@ hipError_t launch_dwconv1d_bn_swish(const float* x, const float* w /*[D][K]*/, c
 hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s);
 // the same on v_mfma_f32_32x32x2_f32 (mha_mfma.hip): T <= 128, head dim a multiple of 4 with a compiled instance
 bool mha_mfma_supported(int T, int D, int n_head);
-hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s);
+// head_major != 0: qkv is [q|k|v][B][n_head][T][D / n_head] (lin_x3's qkv store) instead of [B][T][3 D]
+hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s, int head_major = 0);
 bool mha_head_dim_supported(int head_dim);
 // [B][C][H][W] -> [B][W][C*H]  (CRNN: sequence over W, features C*H; architectures.py:272-276)
 hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);

@@ -12,6 +12,9 @@ struct LinArgs {
     const unsigned char* packed;     // launch_lin_x3_pack output
     int M, N;                        // N = output features written (for the GLU epilogue: of the gated product)
     int nblk = 0;                    // filled by the launcher
+    // epilogue 0 only, qkv_T > 0: N = 3 D outputs are stored head-major, out[which = q|k|v][clip][head][t][dh] (clip = row / qkv_T,
+    // t = row % qkv_T, head = (col % D) / qkv_dh) - every (clip, head) block of the attention kernel is then one contiguous run
+    int qkv_T = 0, qkv_dh = 0;
 };
 
 // bytes of one packed 32-output block: parts x K/16 x 3 fragments of 1 KB + parts x 32 biases, padded to whole 4 KB copy steps

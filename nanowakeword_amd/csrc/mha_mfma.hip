@@ -32,7 +32,7 @@ namespace {
 
 template <int DH, int UW>
 __global__ void __launch_bounds__(128 * UW, UW == 2 ? 2 : 1) mha_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int units, int T, int D,
-                                                       int n_head, float scale) {
+                                                       int n_head, float scale, int head_major) {
     constexpr int LD = DH;                                     // LDS rows are dense: the rows arrive by LDS-DMA in 16-byte pieces
     constexpr int MT = (DH + 31) / 32;                         // output tiles along the head dim
     constexpr int REGION = 2 * 128 * DH;                       // floats of one unit's K [128][DH] + V [128][DH]
@@ -51,21 +51,25 @@ __global__ void __launch_bounds__(128 * UW, UW == 2 ? 2 : 1) mha_mfma_kernel(con
     // the buffer the workgroup is NOT computing on: as a separate phase through registers the copy ran at 2.7 TB/s and took
     // half of the kernel's time.
     const int t2 = tid & 127, pieces = T * (DH / 4);
+    // head_major: qkv = [q|k|v][clip][head][T][DH] (lin_x3's qkv store) - a unit's K and V are one contiguous run each;
+    // else the rows of nn.Linear's [clip][T][3 D] output
+    const size_t hm_which = (size_t)units * T * DH;            // floats per q / k / v plane
     auto fetch_kv = [&](int g, int buf) {
         const int u = g * UW + ul;
         if (u >= units) return;
         const int ub = u / n_head, uh = u - ub * n_head;
-        const float* src = qkv + (size_t)ub * T * 3 * D + uh * DH;
+        const float* src = head_major ? qkv + hm_which + (size_t)u * T * DH : qkv + (size_t)ub * T * 3 * D + uh * DH;
         float* dst = lds_mha + (size_t)(buf * UW + ul) * REGION + w * 256;      // + 64 lanes x 4 floats per wave; wave-uniform
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int i = t2 + 128 * j;
             if (i < pieces) {
                 const int t = i / (DH / 4), c = 4 * (i - t * (DH / 4));
-                const float* p = src + (size_t)t * 3 * D + D + c;
+                const float* p = head_major ? src + 4 * i : src + (size_t)t * 3 * D + D + c;
+                const float* pv = head_major ? p + hm_which : p + D;
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)p,
                                                  (void __attribute__((address_space(3)))*)(dst + 512 * j), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(p + D),
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)pv,
                                                  (void __attribute__((address_space(3)))*)(dst + 128 * DH + 512 * j), 16, 0, 0);
             }
         }
@@ -79,13 +83,14 @@ __global__ void __launch_bounds__(128 * UW, UW == 2 ? 2 : 1) mha_mfma_kernel(con
     const int unit = grp * UW + ul;
     if (unit < units) {
     const int b = unit / n_head, head = unit - b * n_head;
-    const float* base = qkv + (size_t)b * T * 3 * D + head * DH;
+    const float* base = head_major ? qkv + (size_t)unit * T * DH : qkv + (size_t)b * T * 3 * D + head * DH;
+    const int qstride = head_major ? DH : 3 * D;
     const float* Ks = lds_mha + (size_t)(buf * UW + ul) * REGION;
     const float* Vs = Ks + 128 * DH;
     for (int qt = w; qt < NT; qt += 2) {
         // ---- the lane's query row, scaled; qs[s] = element 2s + half (the B operand of step s)
         const int query = 32 * qt + n;
-        const float* qrow = base + (size_t)min(query, T - 1) * 3 * D;
+        const float* qrow = base + (size_t)min(query, T - 1) * qstride;
         float qs[DH / 2];
 #pragma unroll
         for (int c4 = 0; c4 < DH / 4; ++c4) {
@@ -179,7 +184,7 @@ bool mha_mfma_supported(int T, int D, int n_head) {
     }
 }
 
-hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s) {
+hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s, int head_major) {
     if (!mha_mfma_supported(T, D, n_head)) return hipErrorInvalidValue;
     const int dh = D / n_head, units = B * n_head;
     if (units <= 0) return hipSuccess;
@@ -194,7 +199,7 @@ hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, in
     {                                                                                                              \
         hipError_t ea = nww_allow_lds(reinterpret_cast<const void*>(mha_mfma_kernel<DHV, UWV>), lds);              \
         if (ea != hipSuccess) return ea;                                                                           \
-        hipLaunchKernelGGL((mha_mfma_kernel<DHV, UWV>), grid, dim3(128 * UWV), lds, s, qkv, out, units, T, D, n_head, scale); \
+        hipLaunchKernelGGL((mha_mfma_kernel<DHV, UWV>), grid, dim3(128 * UWV), lds, s, qkv, out, units, T, D, n_head, scale, head_major); \
     }
 #define MHA_CASE(DHV) case DHV: if (uw == 4) MHA_GO(DHV, 4) else if (uw == 2) MHA_GO(DHV, 2) else MHA_GO(DHV, 1) break;
     switch (dh) {

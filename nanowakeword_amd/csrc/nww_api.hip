@@ -492,7 +492,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
 // epi 0: out = y + b; 1: out = res + rscale (y + b); 2: LayerNorm(ln_w, ln_b) first when given, W = [2N][K], out = a * sigmoid(b)
 bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K, const float* W,
                 const float* bias, int epi, int res_id = 99, float rscale = 1.f, const float* ln_w = nullptr,
-                const float* ln_b = nullptr) {
+                const float* ln_b = nullptr, int qkv_T = 0, int qkv_dh = 0) {
     static const int enabled = [] { const char* e = getenv("NWW_LIN_X3"); return e ? atoi(e) : 1; }();
     if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N)) return false;
     const int parts = epi == 2 ? 2 : 1;
@@ -506,7 +506,7 @@ bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int 
         a.x = src(r, in_id); a.ldx = K; a.out = dst(r, out_id); a.ldc = N;
         a.res = res_id == 99 ? nullptr : src(r, res_id); a.ldres = N; a.rscale = rscale;
         a.ln_w = ln_w; a.ln_b = ln_b; a.packed = static_cast<const unsigned char*>(packed);
-        a.M = r.B * rows_per_clip; a.N = N;
+        a.M = r.B * rows_per_clip; a.N = N; a.qkv_T = qkv_T; a.qkv_dh = qkv_dh;
         return launch_lin_x3(a, K, epi, ln_w != nullptr, r.stream);
     });
     return true;
@@ -986,11 +986,20 @@ extern "C" int nww_finalize(nww_handle* h) {
                     add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
                 };
                 ffn(".ff1");
-                if (!add_lin_x3(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), 0))
+                // in_proj writes q, k, v head-major when the matrix-core attention consumes them: every (clip, head) block is then
+                // one contiguous run for its LDS-DMA (NWW_QKV_HEAD_MAJOR=0: nn.Linear's [B][T][3 D] rows)
+                static const int mha_mfma0 = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
+                static const int qkv_hm = [] { const char* e = getenv("NWW_QKV_HEAD_MAJOR"); return e ? atoi(e) : 1; }();
+                const bool want_hm = qkv_hm && mha_mfma0 && mha_mfma_supported(T, D, NH) && 3 * D <= 1024;
+                bool head_major = false;
+                if (add_lin_x3(p, q + (want_hm ? ".attention.in_proj(head-major)" : ".attention.in_proj"), hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), 0,
+                               99, 1.f, nullptr, nullptr, want_hm ? T : 0, want_hm ? D / NH : 0))
+                    head_major = want_hm;
+                else
                     add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
                 static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
                 if (mha_mfma && mha_mfma_supported(T, D, NH))
-                    p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
+                    p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream, head_major ? 1 : 0); });
                 else
                     p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
                 if (!add_lin_x3(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), 1, hb, 1.0f))

@@ -127,7 +127,8 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_TRUNK_X3": "0"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),             # float32-MFMA fused trunk
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
-    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma"], False),
+    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),
+    ({"NWW_QKV_HEAD_MAJOR": "0"}, [_CONF], ["mha_mfma"], ["head-major"], False),           # q, k, v as nn.Linear's rows
     ({"NWW_LN_MEAN": "0"}, [_CONF], ["mean:time"], ["layernorm+mean"], False),            # last LayerNorm and the mean over time apart
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),       # short-K Linears on the general GEMM                # one-lane-per-query attention core
     ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma"], False),   # init conv and block1 depthwise apart

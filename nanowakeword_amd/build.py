@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "libnwwhip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
 EMU_LIB = os.path.join(EMU_DIR, "libfe_emu.so")
 
-HIP_SOURCES = ["nww_api.hip", "frontend.hip", "frontend2.hip", "layers.hip", "gemm_x3.hip", "gemm_x3s.hip", "trunk.hip", "trunk_x3.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "mha_mfma.hip", "emb_stream.hip", "fe_tables.cpp"]
+HIP_SOURCES = ["nww_api.hip", "frontend2.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_b.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "mha_mfma.hip", "emb_stream.hip", "fe_tables.cpp"]
 
 
 def _hipcc() -> str:
@@ -33,39 +33,43 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _all_deps():
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(ROOT, "include", "nww.h"))
-    return deps
-
-
 # hipcc's SLP pass pairs adjacent scalar f32 ops into v_pk_* instructions, which issue at half rate on gfx950 (no
 # gain) and cost a v_mov per operand to build the register pairs - measured on the 25-point DFT body: 532 VALU /
 # 120 VGPRs with it, 432 VALU / 62 VGPRs without.  Disabled for the VALU-bound files; NWW_SLP="all" / "none"
 # overrides for A/B builds (together with NWW_LIB_PATH to keep two libraries side by side).
-NO_SLP = {"frontend.hip", "frontend2.hip"}
+NO_SLP = {"frontend2.hip"}
 
 
 def build_hip(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
-    if not force and not _newer(out, _all_deps()):
-        return out
-    objs = []
+    """Compile every source whose object is older than it (or than any header) - up to NWW_BUILD_JOBS (default 6) hipcc
+    processes at a time - and link.  `force` recompiles everything."""
+    from concurrent.futures import ThreadPoolExecutor
     tag = "" if out == LIB else "_" + os.path.splitext(os.path.basename(out))[0]
     odir = os.path.join(PKG, "build" + tag)
     os.makedirs(odir, exist_ok=True)
     mode = os.environ.get("NWW_SLP", "")
+    extra = os.environ.get("NWW_HIPCC_FLAGS", "").split()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "nww.h")]
+    jobs, objs = [], []
     for src in HIP_SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
-        no_slp = mode == "none" or (mode != "all" and src in NO_SLP)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-fno-slp-vectorize"] if no_slp else []) + \
-              ["-I", CSRC, "-I", os.path.join(ROOT, "include"), "-x", "hip", "-c", sp, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
-    subprocess.run(cmd, check=True)
+        if not force and not _newer(obj, [sp] + headers):
+            continue
+        no_slp = mode == "none" or (mode != "all" and src in NO_SLP)
+        jobs.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-fno-slp-vectorize"] if no_slp else []) + extra +
+                    ["-I", CSRC, "-I", os.path.join(ROOT, "include"), "-x", "hip", "-c", sp, "-o", obj])
+    if not jobs and os.path.exists(out) and not _newer(out, objs):
+        return out
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("NWW_BUILD_JOBS", "6")))) as ex:
+        list(ex.map(run, jobs))
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
     return out
 
 

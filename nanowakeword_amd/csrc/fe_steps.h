@@ -1,6 +1,6 @@
 // fe_steps.h - per-lane task bodies of the fused frontend kernel (framing -> Hann -> 400-point
 // real FFT -> |X|^2 -> sparse mel -> 10 log10).  Written as host+device inline functions so the
-// same arithmetic is compiled by hipcc into the gfx950 kernel (frontend.hip) and by g++ into the
+// same arithmetic is compiled by hipcc into the gfx950 kernel (frontend2.hip) and by g++ into the
 // CPU emulator used by the non-GPU tests (tests/hostemu/): index maps, twiddles and butterflies are
 // validated without a GPU.
 //

@@ -59,12 +59,13 @@ __device__ __forceinline__ float fe2_db(float mel, float amin, float mult, float
 //   1  v_mfma_f32_16x16x4_f32 tiles (any n_mels <= 128, any filterbank)
 //   0  sparse loop over LDS tables (any filterbank; A/B reference)
 // FAST_OUT: frames-major log-mel only (the PCM -> logit path): branch-free S4 epilogue
+#define FE2_PARAMS                                                                                                      \
+    const int16_t *__restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad, int n_mels,    \
+        float amin, float db_mult, float floor_db, const FeTables *__restrict__ gtb, const Fe2MelPlan *__restrict__ plan,  \
+        float *__restrict__ out_db, float *__restrict__ out_mel, int frames_major, int dbg, int gsz
+#define FE2_ARGS pcm, row_stride, B, N, T, ngroups, hop, pad, n_mels, amin, db_mult, floor_db, gtb, plan, out_db, out_mel, frames_major, dbg, gsz
 template <int MEL, int FAST_OUT, int MAXT>
-__global__ void __launch_bounds__(256, 3)
-fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad,
-                int n_mels, float amin, float db_mult, float floor_db, const FeTables* __restrict__ gtb,
-                const Fe2MelPlan* __restrict__ plan, float* __restrict__ out_db, float* __restrict__ out_mel,
-                int frames_major, int dbg, int skew_units, int gsz) {
+__device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MFMA_MEL = MEL == 1;
     const int lane = threadIdx.x & 63;
@@ -136,13 +137,6 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
             fe2_load_column(pcm + (size_t)b * row_stride, (t0 + slot) * hop - pad, n2, cur);
     };
     int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * nwv + wv));
-    // All waves run identical items, so without help the three waves of a SIMD stay in the same stage forever and the
-    // matrix-pipe stage (S4) of one never overlaps the VALU stages of the others.  Skew them once by their hardware
-    // wave slot: a third of an item each (skew_units x 64 clocks per slot step).
-    if (skew_units > 0) {
-        const int slot_id = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)) % 3;
-        for (int i = 0; i < slot_id * skew_units; ++i) __builtin_amdgcn_s_sleep(64);
-    }
     if (item < total) prefetch_first(item);
     for (; item < total; item += stride) {
         int b, t0, nf;
@@ -370,6 +364,9 @@ fe2_wave_kernel(const int16_t* __restrict__ pcm, size_t row_stride, int B, int N
     }
 }
 
+template <int MEL, int FAST_OUT, int MAXT>
+__global__ void __launch_bounds__(256, 3) fe2_wave_kernel(FE2_PARAMS) { fe2_wave_body<MEL, FAST_OUT, MAXT>(FE2_ARGS); }
+
 int fe2_lds_bytes(int waves, int mel_mode) {
     return waves * FE2_G * FE2_FRAME_DW * 4 + (mel_mode == 0 ? (int)sizeof(Fe2MelLds) : 0);
 }
@@ -394,11 +391,14 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
         hipError_t e = nww_allow_lds(fn, (size_t)lds);
         if (e != hipSuccess) return e;
     }
-    static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();   // ablation only
-    static const int skew = [] { const char* e = getenv("NWW_FE_SKEW"); return e ? atoi(e) : 0; }();   // experiment: x 4096 clocks per wave slot
+#ifdef NWW_ABLATION      // stage-skipping builds for phase timing (results are garbage): never in the shipped library
+    static const int dbg = [] { const char* e = getenv("NWW_FE_DBG"); return e ? atoi(e) : 0; }();
+#else
+    const int dbg = 0;
+#endif
     // A handful of clips (the interpreter's calls) would put 8 frames on each of a few waves and leave the GPU empty: two
     // frames per wave instead (S1 / S3 / S4 scale with the frames, S2 does not) - B = 1: 13 -> 7 us.  Register-filter mel only.
-    static const int small_g = [] { const char* e = getenv("NWW_FE_SMALL_G"); return e ? atoi(e) : 2; }();
+    const int small_g = 2;
     int gsz = FE2_G;
     if (mode == 2 && small_g >= 2 && small_g < FE2_G && (small_g % 2) == 0 && (long long)B * ngroups * 4 <= (long long)max_grid * nwv) {
         gsz = small_g;
@@ -410,6 +410,6 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
     if (grid < 1) grid = 1;
     const int pad = p.center ? FE_NFFT / 2 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, d_pcm, row_stride, B, N, T, ngroups, p.hop, pad, p.n_mels,
-                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, skew, gsz);
+                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, gsz);
     return hipGetLastError();
 }

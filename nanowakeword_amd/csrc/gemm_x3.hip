@@ -283,7 +283,6 @@ bool gemm_x3_usable(const GemmArgs& g) {
 }
 
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
-    static const int force_cb = [] { const char* e = getenv("NWW_X3_CB"); return e ? atoi(e) : 0; }();
     const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
     GemmArgs a = g;
     a.splitk = sk;
@@ -307,7 +306,7 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
         X3_ACT(1, 8, grid1, lds1)
         return hipGetLastError();
     }
-    const int cb = (force_cb >= 2 && force_cb <= 6) ? force_cb : x3_pick_cb(g.N);
+    const int cb = x3_pick_cb(g.N);
     const int bn = 32 * cb;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
     const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;

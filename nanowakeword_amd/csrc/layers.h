@@ -56,16 +56,9 @@ struct GemmArgs {
     // product (shortcut branch) computed by the same workgroup instead of a separate GEMM + a residual round trip
     const float* A2 = nullptr; int lda2 = 0; const float* W2 = nullptr; int K2 = 0;
     const float* alpha2 = nullptr; const float* beta2 = nullptr;
-    // depthwise-fused form (whole BcResNet block in one kernel): when dw_x is set, the first product's A operand is
-    // depthwise3x3(dw_x, stride (dw_sh, dw_sw), pad 1) computed by the tile loader from the channels-last block input
-    // dw_x [B][dw_H][dw_W][K] with tap-major weights dw_wt [9][K], and the second product's A operand is dw_x sampled
-    // at the strided centres; row m = (b, oy, ox) of the dw_Ho x dw_Wo output grid.  A / A2 are ignored.
-    const float* dw_x = nullptr; const float* dw_wt = nullptr;
-    int dw_H = 0, dw_W = 0, dw_Ho = 0, dw_Wo = 0, dw_sh = 1, dw_sw = 1;
 };
 size_t gemm_x3_weight_bytes(int N, int K);
 // wave-specialised form (gemm_x3s.hip): producer waves stage + split, consumer waves multiply; same results bit for bit
-hipError_t launch_gemm_x3s(const GemmArgs& g, hipStream_t s);
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);
 bool gemm_x3_usable(const GemmArgs& g);
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s);

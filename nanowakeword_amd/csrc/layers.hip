@@ -53,7 +53,7 @@ __device__ __forceinline__ float act_ct(float v) {
 #define GT_LD 36
 // ACT is a template parameter: the run-time switch costs several scalar branches per output element, and for short-K
 // layers (Conformer: 4.5 K-tiles) the epilogue is a third of a workgroup's time.
-// KIND 0: plain GEMM; 1: dual product (BcResNet block); 2: dual product with the depthwise conv computed by the loader
+// KIND 0: plain GEMM; 1: dual product (BcResNet block)
 template <int ACT, int KIND = 0>
 __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     constexpr bool DUAL = KIND != 0;
@@ -67,23 +67,12 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
     const int arow_l = ((wave >> 1) * 32 + i) * GT_LD + 4 * h;
     const int wrow_l = ((wave & 1) * 32 + i) * GT_LD + 4 * h;
     // acc += A[bm.., k_begin..k_end) . W[bn.., k_begin..k_end)^T, K-tiles of 32 through the two LDS stages
-    // mode 0: A rows from memory; 1: A = depthwise 3x3 of the channels-last input g.dw_x, computed here (same tap order
-    // and fmaf chain as dwconv3x3_nhwc_kernel); 2: A = g.dw_x at the strided centre of the output pixel
-    auto contract = [&](int mode, const float* A, int lda, const float* W, int K, int k_begin, int k_end, f32x16& acc) {
+    auto contract = [&](const float* A, int lda, const float* W, int K, int k_begin, int k_end, f32x16& acc) {
         const float* arow[2];
         const float* wrow[2];
-        int iy0[2] = {0, 0}, ix0[2] = {0, 0};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int m = min(bm + lr + 32 * q, g.M - 1);
-            if (KIND != 2 || mode == 0) {
-                arow[q] = A + (size_t)m * lda + 4 * lq;
-            } else {
-                const int per = g.dw_Ho * g.dw_Wo;
-                const int b = m / per, r = m - b * per, oy = r / g.dw_Wo, ox = r - oy * g.dw_Wo;
-                iy0[q] = oy * g.dw_sh; ix0[q] = ox * g.dw_sw;
-                arow[q] = g.dw_x + (size_t)b * g.dw_H * g.dw_W * K + 4 * lq;            // image base (+ channel offset)
-            }
+            arow[q] = A + (size_t)min(bm + lr + 32 * q, g.M - 1) * lda + 4 * lq;
             wrow[q] = W + (size_t)min(bn + lr + 32 * q, g.N - 1) * K + 4 * lq;
         }
         auto gload = [&](int k0, float4 (&ra)[2], float4 (&rw)[2]) {
@@ -91,31 +80,7 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 rw[q] = ok ? *reinterpret_cast<const float4*>(wrow[q] + k0) : make_float4(0, 0, 0, 0);
-                if (KIND != 2 || mode == 0) {
-                    ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
-                } else if (mode == 2) {
-                    ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + ((size_t)iy0[q] * g.dw_W + ix0[q]) * K + k0)
-                               : make_float4(0, 0, 0, 0);
-                } else {
-                    float4 d = make_float4(0, 0, 0, 0);
-                    if (ok) {
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int yy = iy0[q] - 1 + dy;
-#pragma unroll
-                            for (int dx = 0; dx < 3; ++dx) {
-                                const int xx = ix0[q] - 1 + dx;
-                                if (yy >= 0 && yy < g.dw_H && xx >= 0 && xx < g.dw_W) {
-                                    const float4 v = *reinterpret_cast<const float4*>(arow[q] + ((size_t)yy * g.dw_W + xx) * K + k0);
-                                    const float4 w4 = *reinterpret_cast<const float4*>(g.dw_wt + (size_t)(dy * 3 + dx) * K + k0 + 4 * lq);
-                                    d.x = fmaf(v.x, w4.x, d.x); d.y = fmaf(v.y, w4.y, d.y);
-                                    d.z = fmaf(v.z, w4.z, d.z); d.w = fmaf(v.w, w4.w, d.w);
-                                }
-                            }
-                        }
-                    }
-                    ra[q] = d;
-                }
+                ra[q] = ok ? *reinterpret_cast<const float4*>(arow[q] + k0) : make_float4(0, 0, 0, 0);
             }
         };
         auto lstore = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
@@ -156,13 +121,8 @@ __global__ void __launch_bounds__(256) gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; if (DUAL) acc2[r] = 0.0f; }
     const bool dual = DUAL;
-    if (KIND == 2) {                                                     // whole BcResNet block: depthwise feeds the pointwise
-        contract(1, nullptr, 0, g.W, g.K, 0, g.K, acc);
-        contract(2, nullptr, 0, g.W2, g.K2, 0, g.K2, acc2);
-    } else {
-        contract(0, g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
-        if (DUAL) contract(0, g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);  // second product of a dual GEMM (never split)
-    }
+    contract(g.A, g.lda, g.W, g.K, k_begin, k_end, acc);
+    if (DUAL) contract(g.A2, g.lda2, g.W2, g.K2, 0, g.K2, acc2);         // second product of a dual GEMM (never split)
     const int m0 = bm + (wave >> 1) * 32, n = bn + (wave & 1) * 32 + i;
     if (m0 >= g.M || n >= g.N) return;
     if (g.splitk > 1) {
@@ -212,8 +172,7 @@ int gemm_recommended_splitk(long long M, int N, int K, int cu_count) {
     if (K < 2048 || N > 256) return 1;
     // K >= 4096 (fc1-like): chunks of ~3072; 2048 <= K < 4096 (DNN layer1 on (98,40): K = 3920, two column tiles
     // only): chunks of ~1024 so that small batches still spread over a few dozen CUs
-    static const int div = [] { const char* e = getenv("NWW_SPLITK_DIV"); return e ? atoi(e) : 0; }();
-    int s = K / (div > 0 ? div : (K >= 4096 ? 3072 : 1024));
+    int s = K / (K >= 4096 ? 3072 : 1024);
     return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
@@ -240,27 +199,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.A2 && !(aligned && g.K2 % 4 == 0 && g.lda2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(g.A2) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(g.W2) & 15) == 0) && g.splitk <= 1))
         return hipErrorInvalidValue;                           // the dual form exists on the LDS kernel only
-    if (g.dw_x) {                                              // depthwise-fused block
-        if (g.K % 32 != 0 || g.K2 != g.K || !g.W2 || g.splitk > 1 || ((reinterpret_cast<uintptr_t>(g.dw_x) & 15) != 0) ||
-            ((reinterpret_cast<uintptr_t>(g.dw_wt) & 15) != 0) || ((reinterpret_cast<uintptr_t>(g.W) & 15) != 0) ||
-            ((reinterpret_cast<uintptr_t>(g.W2) & 15) != 0))
-            return hipErrorInvalidValue;
-        GemmArgs a = g;
-        a.splitk = 1;
-        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, 1);
-        switch (a.act) {
-            case ACT_RELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_RELU, 2>), grid, dim3(256), 0, s, a); break;
-            case ACT_GELU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_GELU, 2>), grid, dim3(256), 0, s, a); break;
-            case ACT_SILU: hipLaunchKernelGGL((gemm_lds_kernel<ACT_SILU, 2>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((gemm_lds_kernel<ACT_NONE, 2>), grid, dim3(256), 0, s, a); break;
-        }
-        return hipGetLastError();
-    }
     if (!g.A2 && gemm_x3_usable(g)) {
-        // M <= 64: the latency-oriented instance of gemm_x3.hip.  NWW_X3S=1 runs larger M on the wave-specialised kernel
-        // (gemm_x3s.hip; bit-identical results, measured slower: fc1 0.104 vs 0.091 ms, Conformer linear1 0.42 vs 0.30).
-        static const int use_x3s = [] { const char* e = getenv("NWW_X3S"); return e ? atoi(e) : 0; }();
-        hipError_t e = (use_x3s && g.M > 64) ? launch_gemm_x3s(g, s) : launch_gemm_x3(g, s);
+        hipError_t e = launch_gemm_x3(g, s);
         if (e != hipSuccess) return e;
         if (g.splitk > 1 && g.splitk_ws && !g.defer_reduce) {
             const size_t total = (size_t)g.M * g.N;
@@ -289,6 +229,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         }
     } else {
+        if (g.defer_reduce) return hipErrorInvalidValue;       // this path writes C itself, not split-K partials: the consumer's reduce would read a stale workspace
         const size_t total = (size_t)g.M * g.N;
         hipLaunchKernelGGL(gemm_valu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
     }
@@ -457,9 +398,8 @@ hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s) {
 #undef C1_CALL
         return hipGetLastError();
     }
-    static const int cob_env = [] { const char* e = getenv("NWW_CONV_COB"); return e ? atoi(e) : 0; }();
     // pooled convs: 8 output channels per lane keep the 72 per-channel weights in SGPRs (16 spill them)
-    const int want = cob_env ? cob_env : (a.pool ? 8 : 16);
+    const int want = a.pool ? 8 : 16;
     if (want >= 16 && a.Cout % 16 == 0) return launch_conv3x3_cob<16>(a, s);
     if (a.Cout % 8 == 0) return launch_conv3x3_cob<8>(a, s);
     if (a.Cout % 4 == 0) return launch_conv3x3_cob<4>(a, s);
@@ -551,8 +491,7 @@ dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
                                  int W, int sh, int sw, hipStream_t s) {
     const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
-    static const int x4 = [] { const char* e = getenv("NWW_DW_X4"); return e ? atoi(e) : 1; }();
-    if (x4 && !xs_out && C % 4 == 0 && (sw == 1 || sw == 2) &&
+    if (!xs_out && C % 4 == 0 && (sw == 1 || sw == 2) &&
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0) {
         const size_t total4 = (size_t)B * Ho * ((Wo + 3) / 4) * (C / 4);
         if (sw == 1) hipLaunchKernelGGL(dwconv3x3_nhwc_x4_kernel<1>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, wt, d_out, C, H, W, Ho, Wo, sh, total4);

@@ -308,12 +308,9 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     if (c.device < 0 || c.device >= ndev) return fail(nullptr, NWW_ERR_INVALID, "device %d out of range (0..%d)", c.device, ndev - 1);
     nww_handle* h = new nww_handle();
     h->cfg = c;
-    {   // conv_arith: explicit config > environment > library default
+    {   // conv_arith: explicit config > library default
         int mode = c.conv_arith;
-        if (mode == NWW_ARITH_DEFAULT) {
-            const char* e = getenv("NWW_TRUNK_X3");
-            mode = e ? (atoi(e) == 6 ? NWW_ARITH_BF16X6 : atoi(e) == 9 ? NWW_ARITH_BF16X9 : NWW_ARITH_F32) : NWW_DEFAULT_CONV_ARITH;
-        }
+        if (mode == NWW_ARITH_DEFAULT) mode = NWW_DEFAULT_CONV_ARITH;
         h->conv_products = mode == NWW_ARITH_BF16X6 ? 6 : mode == NWW_ARITH_BF16X9 ? 9 : 0;
     }
     h->fe.sample_rate = c.sample_rate; h->fe.n_fft = c.n_fft; h->fe.win_length = c.win_length; h->fe.hop = c.hop_length;
@@ -536,13 +533,19 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
     const int max_grid = p.h->cu_count;
-    // conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip) or on the float32 MFMA (nww_config.conv_arith)
+    // both convolutions on the bf16 matrix cores by exact operand splitting (trunk_b.hip) or on the float32 MFMA (nww_config.conv_arith)
     const int x3 = p.h->conv_products;
-    if ((x3 == 6 || x3 == 9) && trunk_x3_pick_strips(H, W) > 0) {
+    if ((x3 == 6 || x3 == 9) && trunk_b_pick_strips(H, W) > 0) {
+        // both convolutions' weights as the MFMA register images, split into bf16 terms once (trunk_b.hip)
+        void* packed = nullptr;
+        if (hipMalloc(&packed, trunk_b_packed_bytes()) != hipSuccess) return false;
+        if (launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+        p.h->packed_weights.push_back(packed);
         p.add("trunk_x3:" + name, [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
-            return launch_cnn_trunk_x3(a, x3, max_grid, r.stream);
+            a.wpack = static_cast<const unsigned char*>(packed);
+            return launch_cnn_trunk_b(a, x3, max_grid, r.stream);
         });
         return true;
     }
@@ -738,10 +741,9 @@ extern "C" int nww_finalize(nww_handle* h) {
         }
         case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
             // trunk -> fc1 hand-over as the GEMM's own A tiles when both run on the split-operand path and the geometry allows
-            // 16-byte stores inside a 32-feature tile row (NWW_FC1_BLOCKED=0: plain [B][K] layout)
-            static const int want_blocked = [] { const char* e = getenv("NWW_FC1_BLOCKED"); return e ? atoi(e) : 1; }();
+            // 16-byte stores inside a 32-feature tile row
             const int H2 = T / 4, W2 = F / 4;
-            h->trunk_blocked = want_blocked && (h->conv_products == 6 || h->conv_products == 9) && trunk_x3_pick_strips(T, F) > 0 &&
+            h->trunk_blocked = (h->conv_products == 6 || h->conv_products == 9) && trunk_b_pick_strips(T, F) > 0 &&
                                (W2 % 4) == 0 && ((H2 * W2) % 4) == 0 && ((32 * H2 * W2) % 32) == 0;
             const bool fused = add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
                                          p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked);
@@ -750,11 +752,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                 add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
                 add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
             }
-            // fc1's split-K partials are reduced by the classifier tail itself when that is the fused kernel (NWW_TAIL_REDUCE=0: own launch)
+            // fc1's split-K partials are reduced by the classifier tail itself when that is the fused kernel
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
-            static const int tail_reduce = [] { const char* e = getenv("NWW_TAIL_REDUCE"); return e ? atoi(e) : 1; }();
             add_gemm(p, "fc1", 1, 0, 1, 128, 32 * H2 * W2, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, nullptr, nullptr, 99, 1.f,
-                     &h->trunk_blocked, tail_on && tail_reduce && tail_supported(128, E));
+                     &h->trunk_blocked, tail_on && tail_supported(128, E));
             set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
             break;
         }
@@ -775,8 +776,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 if (i == 2 && ww >= 4) {
                     // conv3 + AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form, fused when the MFMA kernel applies
                     const int sw4 = ww / 4, kw4 = ww - 3 * sw4;
-                    static const int fuse = [] { const char* e = getenv("NWW_E2E_FUSE_POOL"); return e ? atoi(e) : 1; }();
-                    if (fuse && add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4)) {
+                    if (add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4)) {
                         fused_pool = true; cin = ch[i]; cur = out;
                         continue;
                     }
@@ -815,8 +815,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
                 const int out = (i % 2 == 0) ? 0 : 1;
                 // the last conv stage may write the recurrent layers' [W][C * H] sequence layout itself (conv3_x3.hip)
-                static const int seq_fused = [] { const char* e = getenv("NWW_CRNN_SEQ_FUSED"); return e ? atoi(e) : 1; }();
-                bool seq = seq_fused && i == c.n_crnn_channels - 1;
+                bool seq = i == c.n_crnn_channels - 1;
                 if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq)) {
                     seq = false;
                     add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
@@ -846,8 +845,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             static const int ic_mfma = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
             // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
             static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
-            static const int bc_fuse0 = [] { const char* e = getenv("NWW_BC_FUSE"); return e ? atoi(e) : 0; }();
-            const bool front_fused = ic_mfma && bc_front && !bc_fuse0 && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
+            const bool front_fused = ic_mfma && bc_front && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
             if (front_fused) {
                 const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
                 const float* dwt1 = p.W("model.block1.depthwise.weight_t");
@@ -880,27 +878,6 @@ extern "C" int nww_finalize(nww_handle* h) {
                 p.need(dwb, (size_t)ci * ho * wo); p.need(xsb, (size_t)ci * ho * wo);
                 const float* dwt = p.W(q + ".depthwise.weight_t");
                 const int hin = hh, win = ww;
-                // NWW_BC_FUSE=1: the depthwise conv computed inside the dual GEMM's tile loader (no d / xs round trip).
-                // Measured slower (5.9 vs 4.4 ms per 8192 clips): every column tile recomputes the depthwise and the
-                // nine-tap loader outweighs the MFMA work, so the default keeps the depthwise as its own kernel.
-                static const int bc_fuse = [] { const char* e = getenv("NWW_BC_FUSE"); return e ? atoi(e) : 0; }();
-                if (bc_fuse && ci % 32 == 0) {
-                    const float *wpw = p.W(q + ".pointwise.weight"), *a1 = p.W(q + ".bn1.alpha"), *b1 = p.W(q + ".bn1.beta");
-                    const float *wsc = p.W(q + ".shortcut.0.weight"), *as = p.W(q + ".shortcut.1.alpha"), *bs = p.W(q + ".shortcut.1.beta");
-                    const int rows = ho * wo;
-                    p.need(outb, (size_t)rows * co);
-                    p.add("block:" + q + " dw3x3 -> pointwise+bn+act + shortcut+bn", [=](Run& r) {
-                        GemmArgs g;
-                        g.A = nullptr; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;
-                        g.W2 = wsc; g.K2 = ci; g.alpha2 = as; g.beta2 = bs;
-                        g.dw_x = r.buf[cur]; g.dw_wt = dwt; g.dw_H = hin; g.dw_W = win; g.dw_Ho = ho; g.dw_Wo = wo; g.dw_sh = sh; g.dw_sw = sw;
-                        g.C = r.buf[outb]; g.ldc = co; g.M = r.B * rows; g.N = co;
-                        g.res = nullptr; g.ldres = 0; g.rscale = 1.0f;
-                        return launch_gemm(g, r.stream);
-                    });
-                    hh = ho; ww = wo; cur = outb;
-                    continue;
-                }
                 if (!(front_fused && i == 1))
                     p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
                 // one dual GEMM per block: shortcut and pointwise products in the same workgroup, no residual round trip
@@ -918,8 +895,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                             p.h->packed_weights.push_back(packed);
                             // when the block input is in HBM (every block but the one whose depthwise ran inside the fused front kernel) the
                             // shortcut rows are gathered from it and the depthwise kernel planned just above writes no copy of them
-                            static const int xs_gather = [] { const char* e = getenv("NWW_BC_XS_GATHER"); return e ? atoi(e) : 1; }();
-                            const bool gather = xs_gather && !(front_fused && i == 1);
+                            const bool gather = !(front_fused && i == 1);
                             if (gather) {
                                 p.pop_last();
                                 p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream); });
@@ -989,8 +965,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 // in_proj writes q, k, v head-major when the matrix-core attention consumes them: every (clip, head) block is then
                 // one contiguous run for its LDS-DMA (NWW_QKV_HEAD_MAJOR=0: nn.Linear's [B][T][3 D] rows)
                 static const int mha_mfma0 = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
-                static const int qkv_hm = [] { const char* e = getenv("NWW_QKV_HEAD_MAJOR"); return e ? atoi(e) : 1; }();
-                const bool want_hm = qkv_hm && mha_mfma0 && mha_mfma_supported(T, D, NH) && 3 * D <= 1024;
+                const bool want_hm = mha_mfma0 && mha_mfma_supported(T, D, NH) && 3 * D <= 1024;
                 bool head_major = false;
                 if (add_lin_x3(p, q + (want_hm ? ".attention.in_proj(head-major)" : ".attention.in_proj"), hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), 0,
                                99, 1.f, nullptr, nullptr, want_hm ? T : 0, want_hm ? D / NH : 0))
@@ -1022,8 +997,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 ffn(".ff2");
                 const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
                 // the last block's LayerNorm feeds only the mean over time: one pass for both (NWW_LN_MEAN=0: two launches)
-                static const int ln_mean = [] { const char* e = getenv("NWW_LN_MEAN"); return e ? atoi(e) : 1; }();
-                if (ln_mean && i == nb - 1 && D <= 256) {
+                if (i == nb - 1 && D <= 256) {
                     p.add("layernorm+mean:" + q + " + time", [=](Run& r) { return launch_ln_mean(r.buf[hb], r.buf[t1], lw, lb, r.B, T, D, r.stream); });
                     last_fused = true;
                 } else {
@@ -1056,6 +1030,8 @@ extern "C" int nww_finalize(nww_handle* h) {
         add_gemm(p, "classifier.0", -2, -3, 1, E / 2, E, p.W("classifier.0.weight"), p.W("classifier.0.bias"), act);
         add_gemm(p, "classifier.3", -3, -4, 1, 1, E / 2, p.W("classifier.3.weight"), p.W("classifier.3.bias"), ACT_NONE);
     }
+    // the plan-time weight packings above were enqueued on own_stream; a forward may arrive on any caller stream
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
     h->finalized = true;
     return NWW_OK;
 }
@@ -1175,14 +1151,9 @@ static int frontend_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
     if (frames_out) *frames_out = T;
-    static const int fc_env = [] { const char* e = getenv("NWW_FE_FC"); return e ? atoi(e) : 16; }();
-    static const int blk_env = [] { const char* e = getenv("NWW_FE_BLOCK"); return e ? atoi(e) : 256; }();
-    static const int wg_env = [] { const char* e = getenv("NWW_FE_WGS_PER_CU"); return e ? atoi(e) : 3; }();
-    static const int ver_env = [] { const char* e = getenv("NWW_FE_V"); return e ? atoi(e) : 2; }();      // 1: barrier-per-stage kernel
     static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();    // 2: register filters, 1: MFMA tiles, 0: sparse LDS loop
-    hipError_t e = ver_env == 1
-        ? fe_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, d_db, d_mel, frames_major, fc_env, blk_env, h->cu_count * wg_env, s)
-        : fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * wg_env, s);
+    // three 4-wave workgroups per CU (frontend2.hip)
+    hipError_t e = fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * 3, s);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }

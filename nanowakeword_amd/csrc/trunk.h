@@ -11,11 +11,14 @@ struct TrunkArgs {
     int B, H, W, act;
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
     int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
-    int skew = 0;                                      // experiment: s_sleep(127) units for the CU's second workgroup
     // > 0: write the output as the split-operand GEMM's A tiles instead of [B][C2][H/4][W/4]: 128-clip row blocks x
     // out_blocked k-tiles of 32 features, each (row block, k-tile) a contiguous [128][32] float tile (gemm_x3.hip)
     int out_blocked = 0;
-    int n0 = 0;                                        // trunk_x3, two strips: workgroups [0, n0) take strip 0, the rest strip 1 (0 = alternate)
+    unsigned long long* trace = nullptr;               // tools/ubench/trunk_trace.hip only (-DNWW_TRACE): s_memtime stamps per wave and phase
+    // trunk_b: weight fragments packed once at plan time (launch_trunk_b_pack); workgroups [wg_end[s-1], wg_end[s]) own row
+    // strip s for life (wg_end[0] == 0: strip = blockIdx % strips instead)
+    const unsigned char* wpack = nullptr;
+    int wg_end[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
@@ -40,13 +43,6 @@ size_t trunk_lds_bytes(int C1, int H, int W, int strips);
 // strips needed for a workgroup to fit in LDS (0 = does not fit at all); *wgs_per_cu = 2 when two workgroups share a CU
 int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu);
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s);
-
-// Same trunk with conv2 on the bf16 matrix cores by exact operand splitting (trunk_x3.hip): conv1's output is kept in
-// LDS as three bf16 terms per value, channels last, and every float32 product is formed from `products` = 9 (all
-// partial products, exact) or 6 (the terms below 2^-23 of the product dropped) v_mfma_f32_32x32x16_bf16.
-size_t trunk_x3_lds_bytes(int H, int W, int strips);
-int trunk_x3_pick_strips(int H, int W);
-hipError_t launch_cnn_trunk_x3(const TrunkArgs& a, int products, int max_grid, hipStream_t s);
 
 // standalone 3x3 conv (pad 1, stride 1) + bias/BN + act (+ MaxPool2) on MFMA f32 for C1 = 32 input channels and
 // Cout a multiple of 32: in [B][32][H][W] -> out [B][Cout][H or H/2][W or W/2]; one workgroup per clip, input staged in LDS.
@@ -82,3 +78,13 @@ struct Conv1DwArgs {
 int conv1_pool_dw_rows(int H, int W, int sh);      // depthwise rows per LDS strip, 0 = does not fit
 hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a, int max_grid, hipStream_t s);
 hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s);
+
+// The same trunk with both convolutions on the bf16 matrix cores by exact operand splitting (trunk_b.hip): every float32
+// product is formed from `products` = 9 (all partial products, exact) or 6 (the terms below 2^-23 of the product dropped)
+// v_mfma_f32_32x32x16_bf16; conv1 as a transposed product per pooled pixel, conv1's output kept in LDS as three bf16 terms
+// per value, channels last.
+size_t trunk_b_lds_bytes(int H, int W, int strips);
+int trunk_b_pick_strips(int H, int W);
+size_t trunk_b_packed_bytes();
+hipError_t launch_trunk_b_pack(const float* w1, const float* w2, unsigned char* packed, hipStream_t s);   // a.wpack
+hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s);

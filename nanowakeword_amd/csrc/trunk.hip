@@ -396,9 +396,12 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
 
 hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hipStream_t s) {
     if (C1 != 16 || C2 != 32) return hipErrorInvalidValue;
+#ifdef NWW_ABLATION      // stage-skipping builds for phase timing (results are garbage): never in the shipped library
     static const int dbg = [] { const char* e = getenv("NWW_TRUNK_DBG"); return e ? atoi(e) : 0; }();
+#else
+    const int dbg = 0;
+#endif
     static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
-    static const int force_nw = [] { const char* e = getenv("NWW_TRUNK_WAVES"); return e ? atoi(e) : 0; }();
     TrunkArgs aa = a;
     aa.dbg = dbg;
     int per_cu = 0;
@@ -413,9 +416,6 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
     const size_t lds = trunk_lds_bytes(C1, a.H, a.W, S);
     // two workgroups per CU: 4 waves each (one per SIMD, 256 VGPRs); a lone workgroup: 8 waves (two per SIMD)
     int nw = per_cu == 2 ? 4 : 8;
-    if (force_nw == 4 || force_nw == 8) nw = force_nw;
-    static const int force_per_cu = [] { const char* e = getenv("NWW_TRUNK_WGS_PER_CU"); return e ? atoi(e) : 0; }();
-    if (force_per_cu > 0 && force_per_cu < per_cu) per_cu = force_per_cu;       // experiments: leave room for another kernel
     long want = (long)a.B * S, cap = (long)max_grid * per_cu;
     int grid = (int)(want < cap ? want : cap);
     grid -= grid % S;
@@ -720,8 +720,8 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
 }
 
 // LDS budget of a workgroup: 80 KB = smaller strips (six depthwise rows), TWO workgroups per CU - one's MFMA / epilogue phases
-// under the other's depthwise phase: 1.14 -> 0.95 ms at 8192 clips (NWW_BC_FRONT_LDS_KB=160: one per CU; 100: 1.19, 56: 1.04)
-static int front_lds_kb() { static const int kb = [] { const char* e = getenv("NWW_BC_FRONT_LDS_KB"); const int v = e ? atoi(e) : 80; return v >= 32 && v <= 160 ? v : 160; }(); return kb; }
+// under the other's depthwise phase: 1.14 -> 0.95 ms at 8192 clips (160 KB = one per CU: 1.14; 100: 1.19, 56: 1.04)
+static int front_lds_kb() { return 80; }
 // depthwise rows per strip such that input plane + strip planes fit LDS; 0 = does not fit
 int conv1_pool_dw_rows(int H, int W, int sh) {
     const int H1 = H / 2, W1 = W / 2, Ho = (H1 - 1) / sh + 1;

@@ -1,0 +1,564 @@
+// trunk_b.hip - the fused conv trunk with BOTH convolutions on the bf16 matrix cores (gfx950), software-pipelined.
+//
+//     x[H][W] -> Conv2d(1,16,3,p1) (+BN) + act + MaxPool2 -> Conv2d(16,32,3,p1) (+BN) + act + MaxPool2 -> [32][H/4][W/4]
+//     (reference: CNNModel / CRNNModel / E2E_MelSpectrogram_CNN stems, nanowakeword/modules/architectures.py:60-71,217-225,840-852)
+//
+// Arithmetic: every float32 operand v is hi + mid + lo, three bf16 numbers holding its 24 significant bits exactly; a
+// float32 product is the sum of nine bf16 x bf16 partial products, each exact in float32, accumulated in float32 by
+// v_mfma_f32_32x32x16_bf16.  PRODUCTS = 9 issues all of them, PRODUCTS = 6 drops the three below 2^-23 of the product.
+//
+// conv1 is a TRANSPOSED split-operand product per pooled pixel:
+//     M = 32 rows = (16 channels x 2 conv columns dx) for one conv row dy,   K = 16 = the pixel's 4 x 4 input patch,
+//     N = 32 pooled pixels of one A1 row
+// A = the conv1 weights scattered into the patch positions they touch (zeros elsewhere), B = the patch of the lane's
+// pixel (two 8-byte LDS reads per term from bf16 input planes).  In the C layout a lane then holds, for ITS pixel,
+// registers r = (channel 8 hi + r/2, dx = r & 1) of both conv rows: the 2 x 2 max-pool is three register maxima, and the
+// eight pooled channels leave as ONE 16-byte LDS store per term - exactly the fragment conv2 reads back.
+// conv2: tile = 32 pixels (2 rows x 16 columns, each 4-register group of the C layout a pooling window) x 32 output
+// channels, 9 taps x (K = 16 input channels = one MFMA per product); accumulators in AGPRs, weight fragments resident
+// in registers (24 of 27; the last tap's three come from LDS per tile).
+//
+// Schedule: an item is (clip, row strip); all eight waves run conv1 of the item (planes -> A1), a barrier, then its conv2
+// tiles while the next item's rows travel from HBM into registers, a barrier.  The weight fragments of both convolutions
+// are split and laid out ONCE at plan time (launch_trunk_b_pack; splitting them in every workgroup cost 20 us of a 380 us
+// launch).  What bounds the kernel (tools/ubench/trunk_trace.hip): with all 256 CUs busy the chip is
+// power-limited - the shader clock drops from 2.4 to 1.9-2.0 GHz while this kernel runs (2.37 GHz on 128 CUs, same clock
+// COUNT per item) - and schedules with very different overlap (conv1 of item k + 1 on four waves beside conv2 of item k
+// on the other four with double-buffered A1; the pooling epilogue of tile n inside tile n + 1's MFMA stream; wave
+// priorities) all land within 2 % of this one in wall time even where they save 5-8 % of the clocks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "layers.h"
+#include "trunk.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef NWW_TRACE      // phase stamps of the first items of the first and last eight workgroups (tools/ubench/trunk_trace.hip)
+#define TB_SLOT ((int)blockIdx.x < 8 ? (int)blockIdx.x : (int)blockIdx.x >= (int)gridDim.x - 8 ? (int)blockIdx.x - ((int)gridDim.x - 16) : -1)
+#define TB_STAMP(k)                                                                                                 \
+    do {                                                                                                            \
+        if (a.trace && TB_SLOT >= 0 && lane == 0 && item_no < 6)                                                    \
+            a.trace[(((size_t)TB_SLOT * 6 + item_no) * NW + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#define TB_STAMP_W(k)                                                                                               \
+    do {                                                                                                            \
+        if (a.trace && TB_SLOT >= 0 && lane == 0 && item_no < 6)                                                    \
+            a.trace[(((size_t)TB_SLOT * 6 + item_no) * NW + wave) * 8 + (k)] = wall_clock64();                      \
+    } while (0)
+#define TB_STAMP_WG(k)                                                                                              \
+    do {                                                                                                            \
+        if (a.trace && TB_SLOT >= 0 && threadIdx.x == 0) a.trace[16 * 6 * 8 * 8 + TB_SLOT * 4 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define TB_STAMP(k)
+#define TB_STAMP_W(k)
+#define TB_STAMP_WG(k)
+#endif
+
+#ifndef TB_ABL
+#define TB_ABL 0      // ablation mask of tools/ubench/trunk_trace.hip builds: 1 conv2 without per-tap LDS reads, 2 no conv2 epilogue,
+#endif                // 4 no conv1, 8 no conv2, 16 no conv1 epilogue (pool / split / A1 stores), 32 no input staging, 64 no input loads either
+namespace {
+constexpr int PS = 96;                  // bytes per A1 pixel: 3 terms x 16 channels x bf16
+constexpr int C1 = 16, C2 = 32;
+constexpr int NW = 8;                   // waves per workgroup
+constexpr int NTHR = 64 * NW;
+constexpr int NWL = 3;                  // conv2 weight fragments fetched from LDS per tile (the last tap's terms)
+constexpr int NWA = 27 - NWL;           // ... and the ones resident in registers
+constexpr int NFRAG = 27 + 6;           // packed fragments: conv2 (tap, term), then conv1 (dy, term); 1 KB each
+
+template <int ACT>
+__device__ __forceinline__ float tb_act(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+// v -> three float32 bit patterns whose upper 16 bits are the bf16 terms (lo has at most 8 significant bits left)
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+// (a >> 16) | (b & 0xffff0000): bf16 of a in the low half, of b in the high half
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const u32x4 v = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// pin a fragment into AGPRs: the compiler copies it there once and hands it to the MFMAs as an AGPR operand
+__device__ __forceinline__ bf16x8 to_agpr(bf16x8 f) {
+    u32x4 v = __builtin_bit_cast(u32x4, f);
+    asm volatile("" : "+a"(v[0]), "+a"(v[1]), "+a"(v[2]), "+a"(v[3]));
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc += the PRODUCTS largest partial products of x (MFMA A operand, terms hi/mid/lo) and y (B operand), smallest first
+template <int PRODUCTS>
+__device__ __forceinline__ void x3_mfma(const bf16x8* x, const bf16x8* y, f32x16& acc) {
+    if (PRODUCTS == 9) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[2], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], acc, 0, 0, 0);
+}
+
+// bias/BN/act of the four values of a pooling window, then their maximum.  Without BN and with ReLU the maximum
+// commutes with the (monotone) bias add and ReLU, bit for bit, and relu(m + b) = max(m, -b) + b exactly: two v_max3_f32
+// and one add (the asm also keeps hipcc from canonicalising every MFMA output with a v_max x, x first).
+template <int ACT, bool BN>
+__device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be) {
+    if (ACT == ACT_RELU && !BN) {
+        float t, u;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(t), "v"(v3), "v"(nbias));
+        return u + bias;
+    }
+    float m = -INFINITY;
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t = v[q] + bias;
+        if (BN) t = t * al + be;
+        m = fmaxf(m, tb_act<ACT>(t));
+    }
+    return m;
+}
+
+// conv2 of one tile: 32 pixels (2 rows x 16 columns) x 32 output channels, 9 taps x (K = 16 input channels = one MFMA
+// per product).  The lane's pixel contributes three 16-byte fragments per tap (8 channels of one term).  pa: the
+// lane's pixel of the tile, dst: where its four pooled columns of output channel i go, nv: how many of them exist.
+template <int ACT, int PRODUCTS, bool BN>
+__device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, const bf16x8 (&bw)[NWA], const unsigned char* wl,
+                                           float bias2, float nbias2, float al2, float be2, float* dst, int nv) {
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
+    bf16x8 na[3], wlast[NWL];
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + 32 * tm);
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) wlast[j] = *reinterpret_cast<const bf16x8*>(wl + j * 1024);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 ca[3];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) ca[tm] = na[tm];
+        if (tap + 1 < 9 && !(TB_ABL & 1)) {
+            const int off = ((tap + 1) / 3) * rowB + ((tap + 1) % 3) * PS;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 32 * tm);
+        }
+        // next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc otherwise sinks them to their first use)
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8* w = 3 * tap < NWA ? &bw[3 * tap] : &wlast[3 * tap - NWA];
+        x3_mfma<PRODUCTS>(ca, w, acc0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TB_ABL & 2) {
+        asm volatile("" ::"a"(acc0));
+        return;
+    }
+    float own[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                      // pooled column 8X + 2k + hi
+        own[k] = pool_quad<ACT, BN>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2);
+    // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7: v_permlane32_swap hands the upper half of
+    // its first operand to the lower half of the second and vice versa - after it both halves hold (x, y) and (z, w)
+    const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[1]), __float_as_uint(own[3]), false, false);
+    float4 o;
+    o.x = __uint_as_float(s02[0]); o.y = __uint_as_float(s02[1]); o.z = __uint_as_float(s13[0]); o.w = __uint_as_float(s13[1]);
+    if (nv >= 4) {
+        *reinterpret_cast<float4*>(dst) = o;
+    } else {
+        if (nv > 0) dst[0] = o.x;
+        if (nv > 1) dst[1] = o.y;
+        if (nv > 2) dst[2] = o.z;
+    }
+}
+
+// LDS map (bytes): [3 input planes: in_rows x Wp0 bf16 each][A1: a1_rows x (Wp1 x 96 + 16) (+64 slack)][conv1
+// weight fragments 6 KB][conv2 last-tap fragments 3 KB].  A workgroup keeps ONE strip index for its whole life, so the
+// zero halos written once stay valid.  The 16 bytes of padding per A1 row put the two pixel rows of a
+// conv2 tile on disjoint 16-byte bank slots (rows 3264 bytes apart land on the SAME eight slots of the 256-byte bank
+// row: every ds_read_b128 of the round-2 layout was a two-way conflict).
+struct TbGeom { int Wp0, Wp1, rowB, plane_b, a1_b; };
+__host__ __device__ inline TbGeom tb_geom(int W, const TrunkStrip& g) {
+    TbGeom r;
+    r.Wp0 = (W + 3) & ~1;                                  // W + 2 columns (zero halo), even so rows stay dword aligned
+    r.Wp1 = W / 2 + 2;
+    r.rowB = r.Wp1 * PS + 16;
+    r.plane_b = (g.in_rows * r.Wp0 * 2 + 15) & ~15;
+    r.a1_b = (g.a1_rows * r.rowB + 64 + 15) & ~15;
+    return r;
+}
+
+// Weight fragments, computed once per model: [conv2 (tap, term)][64 lanes] then [conv1 (dy, term)][64 lanes], 16 bytes
+// per lane - the register images the kernel's MFMAs consume.
+//   conv2: B fragment of tap, lane = (cout i = lane & 31, channels 8 hi .. 8 hi + 7)
+//   conv1: A fragment of conv row dy: row m = 8 q + 4 h + 2 cj + dx of the product is (channel 8 h + 2 q + cj, conv column
+//          dx) - so that C register r of lane half h is (channel 8 h + r / 2, dx = r & 1); k = 4 py + px is the patch
+//          position, and the weight of tap (py - dy, px - dx) sits there (0 where the tap falls outside 3 x 3)
+__global__ void __launch_bounds__(64) trunk_b_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, unsigned char* __restrict__ out) {
+    const int lane = threadIdx.x, i = lane & 31, hi = lane >> 5;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out);
+    for (int tap = 0; tap < 9; ++tap) {
+        uint32_t th[8], tm[8], tl[8];
+        for (int j = 0; j < 8; ++j) split3(w2[((size_t)i * C1 + 8 * hi + j) * 9 + tap], th[j], tm[j], tl[j]);
+        o[(3 * tap + 0) * 64 + lane] = frag4(pack_hi16(th[0], th[1]), pack_hi16(th[2], th[3]), pack_hi16(th[4], th[5]), pack_hi16(th[6], th[7]));
+        o[(3 * tap + 1) * 64 + lane] = frag4(pack_hi16(tm[0], tm[1]), pack_hi16(tm[2], tm[3]), pack_hi16(tm[4], tm[5]), pack_hi16(tm[6], tm[7]));
+        o[(3 * tap + 2) * 64 + lane] = frag4(pack_hi16(tl[0], tl[1]), pack_hi16(tl[2], tl[3]), pack_hi16(tl[4], tl[5]), pack_hi16(tl[6], tl[7]));
+    }
+    const int m = i, cw = 8 * ((m >> 2) & 1) + 2 * (m >> 3) + ((m >> 1) & 1), dxw = m & 1;
+    for (int dy = 0; dy < 2; ++dy) {
+        uint32_t th[8], tm[8], tl[8];
+        for (int kk = 0; kk < 8; ++kk) {
+            const int ty = 2 * hi + (kk >> 2) - dy, tx = (kk & 3) - dxw;
+            const bool in = ty >= 0 && ty < 3 && tx >= 0 && tx < 3;
+            const float v = in ? w1[cw * 9 + ty * 3 + tx] : 0.0f;
+            split3(v, th[kk], tm[kk], tl[kk]);
+        }
+        o[(27 + dy * 3 + 0) * 64 + lane] = frag4(pack_hi16(th[0], th[1]), pack_hi16(th[2], th[3]), pack_hi16(th[4], th[5]), pack_hi16(th[6], th[7]));
+        o[(27 + dy * 3 + 1) * 64 + lane] = frag4(pack_hi16(tm[0], tm[1]), pack_hi16(tm[2], tm[3]), pack_hi16(tm[4], tm[5]), pack_hi16(tm[6], tm[7]));
+        o[(27 + dy * 3 + 2) * 64 + lane] = frag4(pack_hi16(tl[0], tl[1]), pack_hi16(tl[2], tl[3]), pack_hi16(tl[4], tl[5]), pack_hi16(tl[6], tl[7]));
+    }
+}
+
+template <int ACT, int PRODUCTS, bool BN>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    TB_STAMP_WG(0);
+    const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
+    const int S = a.strips;
+    int n_a1, a1_shift, nR2, n_in, row_shift, Wp0, rowB, plane_b, a1_b, b0, bstep;
+    size_t in_off, out_off;
+    {
+        // strip of this workgroup (kept for life) and the clips it walks
+        int sidx;
+        if (a.wg_end[0] > 0) {
+            sidx = 0;
+            while (sidx + 1 < S && (int)blockIdx.x >= a.wg_end[sidx]) ++sidx;
+            const int first = sidx ? a.wg_end[sidx - 1] : 0;
+            b0 = (int)blockIdx.x - first;
+            bstep = a.wg_end[sidx] - first;
+        } else {
+            sidx = (int)blockIdx.x % S;
+            b0 = (int)blockIdx.x / S;
+            bstep = (int)gridDim.x / S;
+        }
+        const TrunkStrip sg = trunk_strip(H, S, sidx);
+        const TbGeom gg = tb_geom(W, sg);
+        Wp0 = gg.Wp0; rowB = gg.rowB; plane_b = gg.plane_b; a1_b = gg.a1_b;
+        n_a1 = sg.a1_hi - sg.a1_lo + 1;
+        a1_shift = sg.a1_lo - sg.a1_base;
+        nR2 = sg.R2b - sg.R2a;
+        n_in = (sg.y_hi - sg.y_lo + 1) * W;
+        row_shift = sg.y_lo - sg.iy0;
+        in_off = (size_t)sg.y_lo * W;
+        out_off = (size_t)sg.R2a * W2;
+    }
+    const int pitch0 = 2 * Wp0;
+    unsigned char* const In3 = lds_raw;
+    unsigned char* const A1 = lds_raw + 3 * plane_b;
+    unsigned char* const W1F = A1 + a1_b;
+    unsigned char* const W2L = W1F + 6 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+
+    // zero the planes and A1 once: halos stay zero, interiors are rewritten per item
+    for (int k = tid; k < (3 * plane_b + a1_b) / 4; k += NTHR) reinterpret_cast<uint32_t*>(lds_raw)[k] = 0u;
+
+    // weight fragments: conv2's first 24 stay in registers, its last three and conv1's six are parked in LDS by wave 0
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpack) + lane;
+    bf16x8 bw[NWA];
+#pragma unroll
+    for (int j = 0; j < NWA; ++j) bw[j] = wp[j * 64];
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) *reinterpret_cast<bf16x8*>(W2L + j * 1024 + lane * 16) = wp[(NWA + j) * 64];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<bf16x8*>(W1F + j * 1024 + lane * 16) = wp[(27 + j) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NWA; ++j) bw[j] = to_agpr(bw[j]);
+    const unsigned char* wl = W2L + lane * 16;
+    const float bias2 = a.b2 ? a.b2[i] : 0.0f;
+    const float al2 = a.al2 ? a.al2[i] : 1.0f, be2 = a.al2 ? a.be2[i] : 0.0f;
+    float b1v[8], nb1v[8], al1v[8], be1v[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        b1v[cc] = a.b1 ? a.b1[8 * hi + cc] : 0.0f;
+        nb1v[cc] = -b1v[cc];
+        al1v[cc] = (BN && a.al1) ? a.al1[8 * hi + cc] : 1.0f;
+        be1v[cc] = (BN && a.al1) ? a.be1[8 * hi + cc] : 0.0f;
+    }
+
+    // conv2 tiling of this strip (tile rows are local pooled rows).  SIMD s (waves s and s + 4) owns tiles s, s + 4, ...
+    const int nX = (W1 + 15) / 16, nT = nR2 * nX;
+    const int simd = wave & 3;
+    const int T_s = (nT - simd + 3) / 4, tA = T_s / 2, tB = T_s - tA;      // waves s + 4 / s take the first tB / the other tA of them
+    // lane's pixel inside a tile: i = 4*quad + 2*dy + dx (quad along x); its 8 channels of a term start at 16*hi bytes
+    const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
+    const int a1_lane = dyi * rowB + xi * PS + 16 * hi;
+    // output: lane = (channel i, pooled columns 8 X + 4 hi .. + 3)
+    const int blk_kt = a.out_blocked;
+    const int out_lane = i * H2 * W2 + 4 * hi;
+
+    // input rows -> the three bf16 planes (zero halo): value (y, x) at column x + 1 of local row y + row_shift
+    auto store4 = [&](unsigned char* planes, int idx, float4 v) {
+        const int y = idx / W, x = idx - y * W;
+        unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
+        uint32_t w[3][4];
+        split3(v.x, w[0][0], w[1][0], w[2][0]); split3(v.y, w[0][1], w[1][1], w[2][1]);
+        split3(v.z, w[0][2], w[1][2], w[2][2]); split3(v.w, w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            unsigned char* p = d + t * plane_b;
+            *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
+            *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
+            *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+        }
+    };
+    auto load_plane_sync = [&](unsigned char* planes, const float* xin) {
+        for (int idx = tid; idx < n_in; idx += NTHR) {
+            const int y = idx / W, x = idx - y * W;
+            uint32_t wh, wm, wlo;
+            split3(xin[idx], wh, wm, wlo);
+            unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
+            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
+            *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+        }
+    };
+    constexpr int NPRE = 2;                                     // float4 registers per thread for the rows of the next item
+    const bool vec_in = (W & 3) == 0 && n_in <= 4 * NPRE * NTHR;
+
+    [[maybe_unused]] int item_no = -1;                          // trace builds only
+    // conv1 groups: 32 consecutive pooled pixels of one A1 row; group g = (row g / ngx, block g % ngx)
+    const int ngx = (W1 + 31) / 32, nG = n_a1 * ngx;
+    // conv1 of one item: groups first, first + stride, ... from `planes` into `a1buf`
+    auto conv1_groups = [&](const unsigned char* planes, unsigned char* a1buf, int first, int stride) {
+        if (TB_ABL & 4) return;
+        bf16x8 wf[2][3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wf[q / 3][q % 3] = *reinterpret_cast<const bf16x8*>(W1F + q * 1024 + lane * 16);
+        const unsigned char* in_lane = planes + (2 * hi) * pitch0;
+        unsigned char* a1w_lane = a1buf + a1_shift * rowB + PS + 16 * hi;        // pixel x of A1 row R at + R * rowB + x * PS
+        auto load_patch = [&](int R, int gx, bf16x8 (&f)[3]) {
+            const int xc = min(32 * gx + i, W1 - 1);
+            const unsigned char* base = in_lane + (2 * R) * pitch0 + 4 * xc;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(base + t * plane_b);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(base + t * plane_b + pitch0);
+                f[t] = frag4(p[0], p[1], q[0], q[1]);
+            }
+        };
+        const int dR = stride / ngx, dX = stride - dR * ngx;
+        int R = first / ngx, X = first - R * ngx;
+        bf16x8 nf[3];
+        if (first < nG) load_patch(R, X, nf);
+        for (int g = first; g < nG; g += stride) {
+            bf16x8 cf[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) cf[t] = nf[t];
+            const int Rc = R, Xc = X;
+            R += dR; X += dX;
+            if (X >= ngx) { X -= ngx; ++R; }
+            if (g + stride < nG) load_patch(R, X, nf);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            x3_mfma<PRODUCTS>(wf[0], cf, acc0);
+            x3_mfma<PRODUCTS>(wf[1], cf, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TB_ABL & 16) { asm volatile("" ::"a"(acc0), "a"(acc1)); continue; }
+            uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                uint32_t th[2], tm[2], tl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int cc = 2 * c2 + e;
+                    const float m = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1],
+                                                       b1v[cc], nb1v[cc], al1v[cc], be1v[cc]);
+                    split3(m, th[e], tm[e], tl[e]);
+                }
+                ph[c2] = pack_hi16(th[0], th[1]); pm[c2] = pack_hi16(tm[0], tm[1]); pl[c2] = pack_hi16(tl[0], tl[1]);
+            }
+            const int x = 32 * Xc + i;
+            if (x < W1) {
+                unsigned char* wq = a1w_lane + Rc * rowB + x * PS;
+                *reinterpret_cast<uint4*>(wq) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                *reinterpret_cast<uint4*>(wq + 32) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+                *reinterpret_cast<uint4*>(wq + 64) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
+        }
+    };
+    // conv2 tiles t0, t0 + 4, ... (cnt of them) of the item whose A1 is a1buf and whose output block starts at outb
+    auto conv2_tiles = [&](const unsigned char* a1buf, float* outb, int t0, int cnt) {
+        if ((TB_ABL & 8) || cnt <= 0) return;
+        int R = t0 / nX, X = t0 - R * nX;
+        auto tile_dst = [&](int Rr, int Xx) -> float* {
+            const int rel = Rr * W2 + 8 * Xx;                                  // wave-uniform
+            if (!blk_kt) return outb + rel + out_lane;
+            const int k = out_lane + (int)out_off + rel;                       // feature index of (channel, row, column)
+            return outb + (size_t)(k >> 5) * (128 * 32) + (k & 31);
+        };
+        auto tile_nv = [&](int Xx) { return (W2 & 3) == 0 ? (8 * Xx + 4 * hi + 3 < W2 ? 4 : 0) : max(0, min(4, W2 - (8 * Xx + 4 * hi))); };
+        auto tile_pa = [&](int Rr, int Xx) { return a1buf + a1_lane + (2 * Rr) * rowB + (16 * Xx) * PS; };
+        auto step = [&](int& Rr, int& Xx) { Xx += 4; while (Xx >= nX) { Xx -= nX; ++Rr; } };
+        for (int n = 0; n < cnt; ++n) {
+            conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, tile_dst(R, X), tile_nv(X));
+            if (n < 4) TB_STAMP(2 + n);
+            step(R, X);
+        }
+    };
+
+    __syncthreads();
+    if (b0 < a.B) load_plane_sync(In3, a.in + (size_t)b0 * H * W + in_off);
+    __syncthreads();
+    // ---- two phases per item, all eight waves in each: conv1 -> A1 | conv2 (the next item's rows in flight) -> planes
+    TB_STAMP_WG(1);
+    for (int b = b0; b < a.B; b += bstep) {
+        const int b1 = b + bstep;
+        const bool has1 = b1 < a.B;
+        ++item_no;
+        TB_STAMP(0);
+        TB_STAMP_W(6);
+        conv1_groups(In3, A1, wave, NW);
+        TB_STAMP(1);
+        __syncthreads();
+        float* outb = blk_kt ? a.out + ((size_t)(b >> 7) * blk_kt * 128 + (b & 127)) * 32
+                             : a.out + (size_t)b * C2 * H2 * W2 + out_off;
+        float4 pre[NPRE];
+        if (has1 && vec_in && !(TB_ABL & 64)) {
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)b1 * H * W + in_off);
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int idx4 = tid + q * NTHR;
+                if (idx4 < n_in / 4) pre[q] = xin4[idx4];
+            }
+        }
+        if (wave < 4) conv2_tiles(A1, outb, simd + 4 * tB, tA);
+        else conv2_tiles(A1, outb, simd, tB);
+        if (has1 && !(TB_ABL & (32 | 64))) {
+            if (vec_in) {
+#pragma unroll
+                for (int q = 0; q < NPRE; ++q) {
+                    const int idx4 = tid + q * NTHR;
+                    if (idx4 < n_in / 4) store4(In3, idx4 * 4, pre[q]);
+                }
+            } else {
+                load_plane_sync(In3, a.in + (size_t)b1 * H * W + in_off);
+            }
+        }
+        __syncthreads();
+        TB_STAMP(7);
+    }
+    TB_STAMP_WG(2);
+}
+}  // namespace
+
+size_t trunk_b_packed_bytes() { return (size_t)NFRAG * 1024; }
+hipError_t launch_trunk_b_pack(const float* w1, const float* w2, unsigned char* packed, hipStream_t s) {
+    hipLaunchKernelGGL(trunk_b_pack_kernel, dim3(1), dim3(64), 0, s, w1, w2, packed);
+    return hipGetLastError();
+}
+
+size_t trunk_b_lds_bytes(int H, int W, int S) {
+    size_t worst = 0;
+    for (int s = 0; s < S; ++s) {
+        const TrunkStrip g = trunk_strip(H, S, s);
+        const TbGeom gg = tb_geom(W, g);
+        const size_t b = 3 * (size_t)gg.plane_b + (size_t)gg.a1_b + 6 * 1024 + NWL * 1024;
+        if (b > worst) worst = b;
+    }
+    return worst;
+}
+int trunk_b_pick_strips(int H, int W) {
+    const int H2 = H / 4;
+    for (int S = 1; S <= H2; ++S)
+        if (trunk_b_lds_bytes(H, W, S) <= 160 * 1024) return S;
+    return 0;
+}
+
+hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s) {
+    if (!a.wpack) return hipErrorInvalidValue;
+    TrunkArgs aa = a;
+    static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    int S = trunk_b_pick_strips(a.H, a.W);
+    if (S < 1) return hipErrorInvalidValue;
+    if (force_strips > S && force_strips <= a.H / 4) S = force_strips;
+    // a handful of clips (the interpreter's B = 1 .. 16 calls) would occupy a handful of CUs for a whole clip each: cut
+    // every clip into more row strips on more CUs instead.  Seam rows are recomputed by both neighbours with the same
+    // arithmetic, so the result does not depend on the strip count (bit for bit).
+    const int small_strips = 4;
+    if (!force_strips && small_strips > S && (long)a.B * small_strips * 4 <= max_grid && small_strips <= a.H / 4) S = small_strips;
+    aa.strips = S;
+    const size_t lds = trunk_b_lds_bytes(a.H, a.W, S);
+    long want = (long)a.B * S;
+    int grid = (int)(want < max_grid ? want : (long)max_grid);
+    for (int q = 0; q < 8; ++q) aa.wg_end[q] = 0;
+    if (S <= 8 && S > 1 && (long)a.B >= 2L * grid) {
+        // Full grid: the workgroups are divided over the strips in proportion to a strip's cost, each group of workgroups
+        // walking all clips.  Cost model fitted to the traces: the SIMD with the most conv2 tiles sets the pace of the
+        // conv2 phase (T4 tiles), everything else is worth about five tiles ((101,64): 7 + 5 : 6 + 5 -> 134 : 122).
+        const int W1 = a.W / 2, nX = (W1 + 15) / 16;
+        double cost[8], total = 0;
+        for (int q = 0; q < S; ++q) {
+            const TrunkStrip g = trunk_strip(a.H, S, q);
+            const int nT = (g.R2b - g.R2a) * nX, T4 = (nT + 3) / 4;
+            cost[q] = T4 + 5.0;
+            total += cost[q];
+        }
+        int used = 0;
+        for (int q = 0; q < S; ++q) {
+            int c = (int)(grid * cost[q] / total + 0.5);
+            if (c < 1) c = 1;
+            if (q == S - 1) c = grid - used;
+            used += c;
+            aa.wg_end[q] = used;
+        }
+        if (aa.wg_end[S - 1] != grid || (S > 1 && aa.wg_end[S - 1] <= aa.wg_end[S - 2]))
+            for (int q = 0; q < 8; ++q) aa.wg_end[q] = 0;
+    }
+    if (aa.wg_end[0] == 0) {
+        grid -= grid % S;
+        if (grid < S) grid = S;
+    }
+    const bool bn = a.al1 != nullptr || a.al2 != nullptr;
+#define TB_LAUNCH(ACTV, PRODV, BNV)                                                                                    \
+    {                                                                                                                  \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_b_kernel<ACTV, PRODV, BNV>), lds);        \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL((cnn_trunk_b_kernel<ACTV, PRODV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa);                \
+    }
+#define TB_BN(ACTV, PRODV)                                                                                             \
+    if (bn) TB_LAUNCH(ACTV, PRODV, true) else TB_LAUNCH(ACTV, PRODV, false)
+#define TB_ACT(ACTV)                                                                                                   \
+    if (products == 6) TB_BN(ACTV, 6) else TB_BN(ACTV, 9)
+    switch (a.act) {
+        case ACT_RELU: TB_ACT(ACT_RELU) break;
+        case ACT_GELU: TB_ACT(ACT_GELU) break;
+        case ACT_SILU: TB_ACT(ACT_SILU) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TB_LAUNCH
+#undef TB_BN
+#undef TB_ACT
+    return hipGetLastError();
+}

@@ -81,7 +81,7 @@ worst = 0.0
 for spec in heads:
     cfg = HeadConfig(**spec)
     sd = synth_state_dict(cfg)
-    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, **({"conv_arith": os.environ["TEST_CONV_ARITH"]} if "TEST_CONV_ARITH" in os.environ else {}))
     plan = m.describe_plan()
     for w in want_in_plan:
         assert w in plan, (w, plan)
@@ -123,25 +123,17 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_TRUNK": "0"}, [_CNN, _CRNN, _E2E], [], ["trunk"], False),                    # unfused conv1 / conv2 kernels
     ({"NWW_CONV_MFMA": "0"}, [_CRNN, _CRNN4, _E2E, _BC], [], ["conv3x3_mfma", "conv1_mfma"], False),   # VALU 3x3 convs
     ({"NWW_GRU16": "0"}, [_CRNN, _GRU, _CRNN_LSTM], [], [], False),                     # streaming recurrent kernels
-    ({"NWW_E2E_FUSE_POOL": "0"}, [_E2E], ["avgpool"], [], False),                       # stand-alone export-form pool
-    ({"NWW_TRUNK_X3": "0"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),             # float32-MFMA fused trunk
+    ({"TEST_CONV_ARITH": "f32"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),        # float32-MFMA fused trunk (nww_config.conv_arith)
+    ({"TEST_CONV_ARITH": "bf16x9"}, [_CNN, _E2E, _CRNN], ["trunk_x3"], [], False),      # all nine partial products
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
-    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),
-    ({"NWW_QKV_HEAD_MAJOR": "0"}, [_CONF], ["mha_mfma"], ["head-major"], False),           # q, k, v as nn.Linear's rows
-    ({"NWW_LN_MEAN": "0"}, [_CONF], ["mean:time"], ["layernorm+mean"], False),            # last LayerNorm and the mean over time apart
-    ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),       # short-K Linears on the general GEMM                # one-lane-per-query attention core
+    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),  # one-lane-per-query attention core
+    ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM
     ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma"], False),   # init conv and block1 depthwise apart
-    ({"NWW_CRNN_SEQ_FUSED": "0"}, [_CRNN, _CRNN_LSTM], ["crnn_seq"], ["conv3_x3+seq"], False),   # sequence layout by its own kernel
-    ({"NWW_X3_WAVES": "4", "NWW_TRUNK_STRIPS": "3", "NWW_X3_V1": "1"}, [_CNN, _E2E], ["trunk_x3"], [], False),   # 4-wave trunk, conv1 on the VALU
-    ({"NWW_X3_N0": "-1", "NWW_X3_WLDS": "1"}, [_CNN], ["trunk_x3"], [], False),         # conv2 weight fragments in LDS + AGPR accumulators                             # strips alternating over the workgroups
-    ({"NWW_TAIL_REDUCE": "0"}, [_CNN], [], [], False),                                  # fc1's split-K partials reduced by their own launch
-    ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),
-    ({"NWW_BC_XS_GATHER": "0", "NWW_DW_X4": "0", "NWW_BC_FRONT_LDS_KB": "160"}, [_BC], ["dual_x3:"], ["xs gathered"], False),   # shortcut rows copied, scalar depthwise, one front workgroup per CU                     # BcResNet block products on the float32-MFMA dual GEMM
+    ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                   # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
-    ({"NWW_FE_V": "1"}, [], [], [], True),                                              # barrier-per-stage frontend kernel
-    ({"NWW_FE_MEL": "0"}, [], [], [], True),
-    ({"NWW_FE_SMALL_G": "0"}, [], [], [], True),                                        # eight frames per wave also for a handful of clips                                            # sparse VALU mel in the wave-private kernel
+    ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel
+    ({"NWW_FE_MEL": "1"}, [], [], [], True),                                            # mel on MFMA tiles
     ({"NWW_TRUNK_STRIPS": "3"}, [_CNN], ["trunk"], [], False),                          # three row strips
     ({"NWW_TAIL": "0"}, [_CNN, _GRU], [], ["tail:"], False),                            # separate GEMMs + sigmoid instead of the fused tail
 ], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else None)

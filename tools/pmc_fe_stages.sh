@@ -1,5 +1,6 @@
 #!/bin/bash
 # VALU / LDS instruction counts of the frontend kernel per stage: PMC pass with each stage skipped (NWW_FE_DBG bits).
+# Needs an ablation build of the library: NWW_HIPCC_FLAGS=-DNWW_ABLATION python -c "from nanowakeword_amd import build; build.build_hip(force=True, out='nanowakeword_amd/libnwwhip_abl.so')" and NWW_LIB_PATH pointing at it.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/fe_stages
 mkdir -p $OUT

@@ -48,8 +48,8 @@ def parse():
                          "stream ~10 us: n = 1 slows the timed loop by ~10 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the self-audit legs (other conv arithmetics, sustained loop, PCIe-inclusive rate); N=1 only anyway")
-    ap.add_argument("--sustain-seconds", type=float, default=2.5)
+                    help="skip the self-audit legs (other conv arithmetics, the other BASELINE configs, PCIe-inclusive rate, sustained loop); N=1 only anyway")
+    ap.add_argument("--sustain-seconds", type=float, default=6.5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: split this many clips over the ranks (BASELINE config 3: 65536 over 8); default 0 = "
@@ -103,10 +103,91 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
                       f"(best of 1/8/{threads} threads; 1 thread = the reference interpreter's setting)"}
 
 
+def sustained_leg(a, torch, dev, model, pcm, logits, B, N):
+    """The headline step repeated for >= --sustain-seconds: the LAST thing the run does, long enough for an outside GPU-busy
+    sampler with a 5 s period to see it (the CPU baseline before it leaves the GPU idle for ~12 s)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(50):
+            model.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        n += 50
+        dt = time.perf_counter() - t0
+        if dt >= a.sustain_seconds:
+            break
+    return {"value": round(B * n / dt, 1), "unit": "clips/s", "seconds": round(dt, 2), "steps": n}
+
+
+def config_legs(torch, dev):
+    """The other BASELINE.json configs on this one GPU (the multi-GPU ones at their per-GPU batch), driver-observed:
+    10 timed steps each with PCM resident in HBM, and max |dlogit| of 8 clips against the oracle.  Never part of `value`."""
+    import oracle                                  # checker only
+    from nanowakeword_amd.config import FrontendConfig, HeadConfig
+    from nanowakeword_amd.session import HipModel, torchaudio_tables
+    from nanowakeword_amd.synth import synth_pcm, synth_state_dict
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    legs = {}
+    for key, name, cfg, fe, B in (
+            ("C1", "dnn head, (98,40) log-mel (40-mel, no centre), batch 32", HeadConfig("dnn", (98, 40)), FrontendConfig(n_mels=40, center=False), 32),
+            ("C3", "bcresnet head, (101,64), batch 8192 (= 65536 / 8 GPUs), fp32", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192),
+            ("C5", "conformer head, (101,64), batch 2048 (= 16384 / 8 GPUs), MFMA attention", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048)):
+        sd = synth_state_dict(cfg)
+        window, fb = torchaudio_tables(fe)
+        m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb)
+        pcm_h = synth_pcm("noise", B, 16000, seed=10)
+        pcm = torch.from_numpy(pcm_h).to(dev)
+        logits = torch.empty(B, dtype=torch.float32, device=dev)
+        m.reserve(B, 16000)
+        for _ in range(5):
+            m.forward_pcm_dev(pcm.data_ptr(), B, 16000, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        steps = 10
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.forward_pcm_dev(pcm.data_ptr(), B, 16000, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        lm = oracle.frontend_logmel(pcm_h[:8], window, fb, n_mels=fe.n_mels, center=fe.center).transpose(0, 2, 1)
+        ref = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+        legs[key] = {"workload": name, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "clips_per_s": round(B * steps / dt, 1),
+                     "max_abs_dlogit": float(np.abs(logits[:8].cpu().numpy() - ref).max())}
+        m.close()
+    # C4: CRNN-GRU head, 1024 lock-step 10 s streams, one 80 ms hop per step (the whole 1 s window re-scored per hop)
+    cfg, fe = HeadConfig("crnn", (101, 64), crnn_rnn_type="gru"), FrontendConfig()
+    sd = synth_state_dict(cfg)
+    window, fb = torchaudio_tables(fe)
+    m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb)
+    S, hop = 1024, 1280
+    m.stream_open(S, 16000, hop)
+    chunk_h = synth_pcm("noise", S, hop * 16, seed=1)
+    chunks = torch.from_numpy(chunk_h).to(dev)
+    parts = [chunks[:, k * hop:(k + 1) * hop].contiguous() for k in range(16)]
+    logits = torch.empty(S, dtype=torch.float32, device=dev)
+    for i in range(15):                                       # fill the windows (12.5 hops)
+        m.stream_push_dev(parts[i].data_ptr(), logits.data_ptr(), 0, stream)
+    torch.cuda.synchronize(dev)
+    steps = 10
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m.stream_push_dev(parts[(15 + i) % 16].data_ptr(), logits.data_ptr(), 0, stream)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    # the last window of stream s = its last 16000 pushed samples
+    order = [(15 + i) % 16 for i in range(steps)]
+    hist = np.concatenate([chunk_h[:8, k * hop:(k + 1) * hop] for k in (list(range(15)) + order)], axis=1)[:, -16000:]
+    lm = oracle.frontend_logmel(np.ascontiguousarray(hist), window, fb).transpose(0, 2, 1)
+    ref = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+    legs["C4"] = {"workload": "crnn (GRU) head, 1024 lock-step streams, 80 ms hop, 1 s window re-scored per hop", "steps": steps,
+                  "ms_per_step": round(dt / steps * 1e3, 4), "window_scores_per_s": round(S * steps / dt, 1),
+                  "max_abs_dlogit": float(np.abs(logits[:8].cpu().numpy() - ref).max())}
+    m.close()
+    return legs
+
+
 def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logits):
     """Self-audit legs of the N = 1 line (never part of `value`):
       arith      the same step with conv2 on the plain f32 MFMA and with all nine bf16 partial products
-      sustained  the headline step repeated for >= --sustain-seconds (long enough for an outside GPU-busy sampler)
       h2d_inclusive  PCM starting in pinned host memory: double-buffered uploads on a copy stream overlapped with the
                  previous batch's kernels, logits copied back to the host (the PCIe-inclusive rate; Gen5 x16 ceiling
                  = 63 GB/s / 32 kB per clip = 1.97 M clips/s)"""
@@ -135,17 +216,6 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     out["arith"] = arith
     m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=a.conv_arith)
     m.reserve(B, N)
-    # ---- sustained
-    n, t0 = 0, time.perf_counter()
-    while True:
-        for _ in range(50):
-            m.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
-        torch.cuda.synchronize(dev)
-        n += 50
-        dt = time.perf_counter() - t0
-        if dt >= a.sustain_seconds:
-            break
-    out["sustained"] = {"value": round(B * n / dt, 1), "unit": "clips/s", "seconds": round(dt, 2), "steps": n}
     # ---- PCIe-inclusive: pinned host PCM -> (copy stream) -> device double buffer -> kernels -> host logits
     host = [torch.from_numpy(pcm_host).pin_memory(), torch.from_numpy(np.roll(pcm_host, 1, axis=0).copy()).pin_memory()]
     dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
@@ -296,10 +366,9 @@ def main():
     lg = logits.cpu().numpy()
     if world > 1:       # every rank's shard must sit at its slot of the gathered vector
         assert np.array_equal(gathered.cpu().numpy()[rank * B:(rank + 1) * B], lg), "all-gather placed a shard wrongly"
-    if not any(os.environ.get(k, "0") not in ("", "0") for k in ("NWW_FE_DBG", "NWW_TRUNK_DBG")):   # ablation runs compute garbage
-        assert np.isfinite(lg).all()
-        l8, _ = model.forward_pcm(pcm_host[:8])
-        assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
+    assert np.isfinite(lg).all()
+    l8, _ = model.forward_pcm(pcm_host[:8])
+    assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -319,9 +388,8 @@ def main():
             algo["gemm:fc1"] = ("mfma", B * 2 * 32 * (T // 4) * (n_mels // 4) * 128 / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
             # fused trunk: conv1 on the 2*H1 x 2*W1 positions that survive the floor pooling + conv2 on 2*H2 x 2*W2
             algo["trunk:conv1+pool+conv2+pool"] = ("mfma", algo["conv3x3:conv1"][1] + algo["conv3x3:conv2"][1], "TFLOP/s", PEAK_F32_TFLOPS)
-            # trunk_x3: conv1 on the f32 MFMA, conv2's float32 products as P bf16 partial products on the bf16 MFMA.
-            # Its matrix-pipe speed of light is conv1/f32_peak + conv2/(bf16_peak/P); `peak` is the algorithmic
-            # (float32-equivalent) rate that corresponds to it.
+            # trunk_x3: float32 products as P bf16 partial products on the bf16 MFMA.  `peak` is the algorithmic
+            # (float32-equivalent) rate of conv1/f32_peak + conv2/(bf16_peak/P) - the round-2 definition, kept.
             P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
             f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
             peak_x3 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
@@ -344,8 +412,17 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(dom[1], 4),
-                    "launches": dom[2]}
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch "
+                                      "(tools/collect_profiles.py), not measured in this run" if traffic is not None else None,
+                    "avg_launch_ms": round(dom[1], 4), "launches": dom[2]}
+        if name.startswith("trunk_x3"):
+            # `peak` keeps the round-2 definition (conv1 priced at the f32 MFMA rate) so rounds stay comparable; conv1 now
+            # also runs as P bf16 products, so the matrix-pipe floor of the ISSUED mix is (f1 + f2) / (bf16_peak / P)
+            roofline["peak_definition"] = "algorithmic float32 flops / (conv1 / f32 MFMA peak + conv2 / (bf16 MFMA peak / P)) as in round 2"
+            roofline["frac_of_issued_bf16_mix"] = round(achieved / (PEAK_BF16_TFLOPS / P), 4)
+            roofline["note"] = ("peaks assume the 2.4 GHz boost clock; with all 256 CUs busy this kernel runs power-limited at "
+                                "1.9-2.0 GHz (tools/ubench/trunk_trace.hip, DESIGN.md 4.2)")
         fe_row = [r for r in per if r[0].startswith("frontend")]
         extra = {}
         if fe_row:
@@ -365,14 +442,21 @@ def main():
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
                                       "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)"}[arith],
                        "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via})" if world > 1 else "")},
+            "gather_via": gather_via,          # "capi" = RCCL all-gather inside the C-ABI on the kernels' stream; "none" at N = 1
             "roofline": roofline,
             "kernel_ms": kernel_ms,
         }
+        if world > 1 and a.gather == "capi" and gather_via != "capi":
+            out["gather_fallback"] = "the C-ABI communicator could not be created: torch.distributed all_gather_into_tensor was timed instead"
         out.update(extra)
-        if world == 1 and not a.no_extras and not any(os.environ.get(k, "0") not in ("", "0") for k in ("NWW_FE_DBG", "NWW_TRUNK_DBG")):
+        extras = world == 1 and not a.no_extras
+        if extras:
             out.update(audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, lg))
+            out["configs"] = config_legs(torch, dev)
         if not a.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0, the GPU box's host cores)
             out["cpu_baseline"] = cpu_baseline(cfg, sd, window, fb, a.cpu_seconds)
+        if extras:                                         # last: the GPU is busy for the final >= 6 s of the run
+            out["sustained"] = sustained_leg(a, torch, dev, model, pcm, logits, B, N)
         print(json.dumps(out))
     model.close()
     if world > 1:

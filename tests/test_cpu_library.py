@@ -12,7 +12,7 @@ import oracle
 from conftest import ROOT
 from nanowakeword_amd import build
 from nanowakeword_amd.config import FrontendConfig, HeadConfig, param_spec, head_macs
-from parity import assert_frontend_close
+from parity import assert_frontend_amplitude, assert_frontend_close
 
 
 def test_header_symbols_exported():
@@ -131,12 +131,14 @@ def test_wave_private_schedule_on_cpu_vs_reference(emu, golden_frontend, variant
     if variant == "64c":
         mel, db = emu.v2(g["pcm"], 64, 1, g["window"], g["fb64"], mfma_mel)
         assert_frontend_close(mel, db, g["mel64"], g["db64"], variant)
+        assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g["fb64"], dtype=np.float64), variant)
         mel1, _ = emu(g["pcm"], 64, 1, g["window"], g["fb64"])
         if not mfma_mel:                       # same bodies, same summation order: bit-identical to the first kernel
             assert np.array_equal(mel, mel1)
     else:
         mel, db = emu.v2(g["pcm"], 40, 0, g["window"], g["fb40"], mfma_mel)
         assert_frontend_close(mel, db, g["mel40"], g["db40"], variant)
+        assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g["fb40"], center=False, dtype=np.float64), variant)
     _, dbs = emu.v2(g["short_pcm"], 64, 1, g["window"], g["fb64"], mfma_mel)
     assert np.abs(dbs - g["short_db64"]).max() <= 1e-4
 

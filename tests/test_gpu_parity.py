@@ -6,7 +6,7 @@ import oracle
 from conftest import head_case_names
 from nanowakeword_amd.config import FrontendConfig, HeadConfig
 from nanowakeword_amd.synth import synth_features, synth_pcm, synth_state_dict
-from parity import assert_frontend_close, frontend_errors, logit_bounds
+from parity import assert_frontend_amplitude, assert_frontend_close, frontend_errors, logit_bounds
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,10 @@ def test_frontend_vs_reference_golden(hip, golden_frontend, variant):
     # and against the oracle (same tables)
     mo = oracle.mel_power(g["pcm"], g["window"], g["fb64"] if center else g["fb40"], center=center)
     assert_frontend_close(mel, db, mo, oracle.logmel_db(mo), variant + "/oracle")
+    # criterion C: every bin - the ones A excludes too - against the same graph in float64
+    exact = oracle.mel_power(g["pcm"], g["window"], g["fb64"] if center else g["fb40"], center=center, dtype=np.float64)
+    k_all, k_exc = assert_frontend_amplitude(mel, exact, variant)
+    print(f"frontend {variant}: amplitude error {k_all:.2f} (all bins) / {k_exc:.2f} (bins below 1e-4 x frame peak) x 2^-24 x frame peak amplitude")
     m.close()
 
 
@@ -69,6 +73,7 @@ def test_frame_law_and_edges(hip, golden_frontend):
     db, mel = mc.frontend(x, return_power=True)
     mo = oracle.mel_power(x, g["window"], g["fb64"])
     assert_frontend_close(mel, db, mo, oracle.logmel_db(mo), "odd-length")
+    assert_frontend_amplitude(mel, oracle.mel_power(x, g["window"], g["fb64"], dtype=np.float64), "odd-length")
     mc.close(); mn.close()
 
 

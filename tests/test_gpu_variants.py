@@ -94,13 +94,14 @@ for spec in heads:
     m.close()
 if check_fe:
     sys.path.insert(0, os.path.join(os.environ["NWW_ROOT"], "tests"))
-    from parity import assert_frontend_close
+    from parity import assert_frontend_amplitude, assert_frontend_close
     g = dict(np.load(os.path.join(os.environ["NWW_ROOT"], "tests", "golden", "frontend.npz")))
     for n_mels, center, mk, dk, fk in ((64, True, "mel64", "db64", "fb64"), (40, False, "mel40", "db40", "fb40")):
         cfg = HeadConfig("dnn", (101, 64) if center else (98, 40))
         m = HipModel(cfg, FrontendConfig(n_mels=n_mels, center=center), state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=g[fk])
         db, mel = m.frontend(g["pcm"], return_power=True)
         assert_frontend_close(mel, db, g[mk], g[dk], "knob")
+        assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g[fk], center=center, dtype=np.float64), "knob")
         lg, _ = m.forward_pcm(g["pcm"])                     # frames-major output path of the same kernel
         lm = np.ascontiguousarray(oracle.frontend_logmel(g["pcm"], g["window"], g[fk], center=center).transpose(0, 2, 1))
         assert np.abs(lg - oracle.model_forward(lm, synth_state_dict(cfg), cfg).ravel())[:4].max() <= 1e-4

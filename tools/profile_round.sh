@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile on the GPU box: parity tests, bench, rocprofv3 kernel stats, and separate PMC passes
 # (FETCH_SIZE / WRITE_SIZE cannot share a pass; no --stats/trace combined with --pmc).
-# usage: bash tools/profile_round.sh r02   (run through gpurun; outputs under gpurun_out/<tag>/)
+# usage: bash tools/profile_round.sh r03   (run through gpurun; outputs under gpurun_out/<tag>/)
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT

@@ -3,8 +3,12 @@
 variant, the fraction of mel bins EXCLUDED from the 1e-4 dB comparison (bins below 1e-4 x their frame's peak, where the
 reference's own float32 dense DFT is rounding noise), the worst dB error on the included bins, the worst dB error on the
 EXCLUDED bins, the reference's own distance from exact (float64) arithmetic on those excluded bins, and the absolute
-mel error relative to the frame peak (criterion B, applied to ALL bins).  GPU box; prints JSON.
-usage: python tools/tolerance_audit.py > profiles/r02_tolerance_audit.json"""
+mel error relative to the frame peak (criterion B, applied to ALL bins), and criterion C: the amplitude-domain distance from
+exact arithmetic in units of 2^-24 x the frame's peak mel amplitude, over all bins and over the excluded bins, for the HIP
+frontend and for the reference itself.  Also printed, not asserted: the "4 x the reference's dB error, at least 2e-3 dB"
+per-clip comparison on the excluded bins - see tools/fft_precision_floor.py for why no float32 FFT meets it
+on wav1.  GPU box; prints JSON.
+usage: python tools/tolerance_audit.py > profiles/r03_tolerance_audit.json"""
 import json
 import os
 import sys
@@ -22,7 +26,9 @@ def main():
     from nanowakeword_amd.session import HipModel
     from nanowakeword_amd.synth import synth_state_dict
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", "frontend.npz")))
-    out = {"criteria": {"A": "|d dB| <= 1e-4 on bins >= 1e-4 x frame peak", "B": "|d mel| <= 3e-6 x frame peak on all bins"}, "variants": {}}
+    from parity import amplitude_errors
+    out = {"criteria": {"A": "|d dB| <= 1e-4 on bins >= 1e-4 x frame peak", "B": "|d mel| <= 3e-6 x frame peak on all bins",
+                        "C": "|sqrt(mel) - sqrt(mel_float64)| <= 6 (all bins) / 2 (bins A excludes) x 2^-24 x sqrt(frame peak mel)"}, "variants": {}}
     for variant, n_mels, center, mk, dk, fk in (("64-mel centre", 64, True, "mel64", "db64", "fb64"), ("40-mel no-centre", 40, False, "mel40", "db40", "fb40")):
         cfg = HeadConfig("dnn", (101, 64) if center else (98, 40))
         m = HipModel(cfg, FrontendConfig(n_mels=n_mels, center=center), state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=g[fk])
@@ -44,7 +50,13 @@ def main():
                 "reference_vs_exact_db_on_excluded": float(np.abs(ref_db - db_exact[i])[exc].max()) if exc.any() else 0.0,
                 "hip_vs_exact_db_on_excluded": float(np.abs(db[i] - db_exact[i])[exc].max()) if exc.any() else 0.0,
                 "max_mel_err_over_frame_peak": float((np.abs(mel[i] - ref_mel) / np.maximum(fpk, 1e-30)).max()),
+                "C_kappa_hip_all_excluded": [round(v, 3) for v in amplitude_errors(mel[i:i + 1], exact[i:i + 1])],
+                "C_kappa_reference_all_excluded": [round(v, 3) for v in amplitude_errors(ref_mel[None], exact[i:i + 1])],
             })
+            r = rows[-1]
+            r["verdict_r02_rule_excluded_bins"] = {"allowed_db": max(4.0 * r["reference_vs_exact_db_on_excluded"], 2e-3),
+                                                   "hip_db": r["hip_vs_exact_db_on_excluded"],
+                                                   "met": bool(r["hip_vs_exact_db_on_excluded"] <= max(4.0 * r["reference_vs_exact_db_on_excluded"], 2e-3))}
         out["variants"][variant] = rows
         m.close()
     print(json.dumps(out, indent=1))

@@ -15,6 +15,11 @@
 // workgroups share a CU; the next k-tile's global loads travel in registers during the multiplication.  A is split
 // while it is staged into LDS (5.5 VALU ops per element, amortised over 32*CB columns); W is split once at
 // nww_finalize into the same [N][K/16][3][16] layout so its tiles are plain 16-byte copies.
+// Round 3, measured and not kept: an 8-wave version with two LDS stages, ONE barrier per k-tile, the split + store of tile
+// k + 1 placed between the MFMAs of tile k and global loads three tiles ahead (0 spills, parity-green, bit-identical
+// results) ran fc1 in 0.098 ms against 0.090 for this kernel.  The step draws 1350 W of the package's 1400 W cap
+// (tools/power_probe.sh): at the cap a kernel's time follows the energy of its instructions, and that version read every
+// A fragment from LDS twice (two waves per row block).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

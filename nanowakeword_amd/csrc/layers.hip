@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
 }
 
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
-    if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
+    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
@@ -1237,7 +1237,7 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
-    if (a.H % 4 != 0 || a.H > 512) return hipErrorInvalidValue;
+    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);

@@ -151,13 +151,17 @@ __global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
 
     float* orow = a.out + rr * a.ldc;
     // head-major qkv store (epilogue 0): column part of the destination from a table made once per workgroup, row part here
+    // (the q / k / v plane offset is added in size_t at the store: M x N may exceed 2^31 elements)
     __shared__ int qkv_lut[EPI == 0 ? 256 : 1];
+    __shared__ unsigned char qkv_which[EPI == 0 ? 256 : 1];
+    size_t per_which = 0;
     if (EPI == 0 && a.qkv_T > 0) {
         const int D = a.N / 3, dh = a.qkv_dh, NH = D / dh, T = a.qkv_T;
-        const long per_which = (long)(a.M / T) * NH * T * dh;
+        per_which = (size_t)(a.M / T) * NH * T * dh;
         for (int c4 = tid; c4 < a.N / 4; c4 += 256) {
             const int col = 4 * c4, which = col / D, rem = col - which * D, head = rem / dh, c = rem - head * dh;
-            qkv_lut[c4] = (int)(which * per_which + (long)head * T * dh + c);
+            qkv_lut[c4] = head * T * dh + c;
+            qkv_which[c4] = (unsigned char)which;
         }
         const int b = (int)(rr / T), t = (int)(rr - (size_t)b * T);
         orow = a.out + ((size_t)b * NH * T + t) * dh;
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
                     const float4 r4 = *reinterpret_cast<const float4*>(rrow + col);
                     o.x = r4.x + a.rscale * o.x; o.y = r4.y + a.rscale * o.y; o.z = r4.z + a.rscale * o.z; o.w = r4.w + a.rscale * o.w;
                 }
-                if (EPI == 0 && a.qkv_T > 0) *reinterpret_cast<float4*>(orow + qkv_lut[col >> 2]) = o;
+                if (EPI == 0 && a.qkv_T > 0) *reinterpret_cast<float4*>(orow + (size_t)qkv_which[col >> 2] * per_which + qkv_lut[col >> 2]) = o;
                 else *reinterpret_cast<float4*>(orow + col) = o;
             }
         }
@@ -251,8 +255,7 @@ hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int 
 hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t s) {
     if (a0.M <= 0) return hipSuccess;
     if (!lin_x3_supported(K, a0.N) || (ln && epi != 2) || (a0.ldx % 4) || (a0.ldc % 4)) return hipErrorInvalidValue;
-    if (a0.qkv_T > 0 && (epi != 0 || a0.N > 1024 || a0.N % 3 || a0.qkv_dh <= 0 || (a0.N / 3) % a0.qkv_dh || a0.qkv_dh % 4 || a0.M % a0.qkv_T ||
-                         (size_t)a0.M * a0.N >= ((size_t)1 << 31)))
+    if (a0.qkv_T > 0 && (epi != 0 || a0.N > 1024 || a0.N % 3 || a0.qkv_dh <= 0 || (a0.N / 3) % a0.qkv_dh || a0.qkv_dh % 4 || a0.M % a0.qkv_T))
         return hipErrorInvalidValue;
     // 16-byte row loads / stores (as the general GEMM's loaders): refuse a misaligned buffer loudly instead of faulting
     if (((reinterpret_cast<uintptr_t>(a0.x) | reinterpret_cast<uintptr_t>(a0.out) | reinterpret_cast<uintptr_t>(a0.res)) & 15) != 0) return hipErrorInvalidValue;

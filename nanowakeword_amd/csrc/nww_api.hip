@@ -84,6 +84,7 @@ struct nww_handle {
     EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
     void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
     unsigned char* pin_in = nullptr; unsigned char* pin_out = nullptr;   // pinned staging for small host-pointer calls
+    bool pin_in_busy = false;                                            // an async copy out of pin_in may still be in flight
     int comm_rank = 0, comm_world = 1;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
@@ -294,7 +295,7 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     if (c.head_type == NWW_HEAD_CRNN && (c.n_crnn_channels < 1 || c.n_crnn_channels > 4))
         return fail(nullptr, NWW_ERR_INVALID, "crnn_cnn_channels must have 1..4 stages");
     if ((c.head_type == NWW_HEAD_CRNN || c.head_type == NWW_HEAD_GRU) && (c.layer_dim % 4 != 0 || c.layer_dim > 256))
-        return fail(nullptr, NWW_ERR_UNSUPPORTED, "GRU hidden size must be a multiple of 4 and <= 256");
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be a multiple of 4 and <= 256", c.layer_dim);
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
     if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
@@ -1244,7 +1245,10 @@ constexpr size_t PIN_BYTES = 1 << 20;
 static int h2d_small(nww_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes <= PIN_BYTES) {
         if (!h->pin_in) HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), PIN_BYTES, hipHostMallocDefault));
-        std::memcpy(h->pin_in, src, bytes);      // host-pointer entry points synchronise before returning: the buffer is free again
+        // host-pointer entry points synchronise before returning, except on their error paths: wait for a copy a failed call left behind
+        if (h->pin_in_busy) { HIP_TRY(h, hipStreamSynchronize(s)); h->pin_in_busy = false; }
+        std::memcpy(h->pin_in, src, bytes);
+        h->pin_in_busy = true;
         HIP_TRY(h, hipMemcpyAsync(dst, h->pin_in, bytes, hipMemcpyHostToDevice, s));
         return NWW_OK;
     }
@@ -1263,6 +1267,7 @@ static int copy_out(nww_handle* h, int B, float* logits, float* probs, float* em
         if (probs) { pp = h->pin_out + off; off += nb; HIP_TRY(h, hipMemcpyAsync(pp, h->d_probs, nb, hipMemcpyDeviceToHost, s)); }
         if (emb) { pe = h->pin_out + off; off += ne; HIP_TRY(h, hipMemcpyAsync(pe, h->d_emb, ne, hipMemcpyDeviceToHost, s)); }
         HIP_TRY(h, hipStreamSynchronize(s));
+        h->pin_in_busy = false;
         if (logits) std::memcpy(logits, pl, nb);
         if (probs) std::memcpy(probs, pp, nb);
         if (emb) std::memcpy(emb, pe, ne);
@@ -1272,6 +1277,7 @@ static int copy_out(nww_handle* h, int B, float* logits, float* probs, float* em
     if (probs) HIP_TRY(h, hipMemcpyAsync(probs, h->d_probs, nb, hipMemcpyDeviceToHost, s));
     if (emb) HIP_TRY(h, hipMemcpyAsync(emb, h->d_emb, ne, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    h->pin_in_busy = false;
     return NWW_OK;
 }
 

@@ -233,3 +233,27 @@ def test_capi_communicator_world1(HipModel, golden_frontend):
     with pytest.raises(Exception, match="communicator"):
         m.forward_pcm_gather_dev(pcm.data_ptr(), 64, 16000, out.data_ptr(), stream)
     m.close()
+
+
+def test_capi_gather_two_ranks():
+    """The C-ABI RCCL path with a real second rank (rank > 0 slot offset, cross-rank agreement): needs two GPUs, skipped on
+    the 1-GPU box (the driver's multi-GPU node runs it)."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_wide_recurrent_layers_are_refused_loudly(HipModel):
+    """layer_dim in (256, 512] has no compiled recurrent kernel: nww_create must say so (not fail at the first launch)."""
+    for mt in ("gru", "crnn"):
+        with pytest.raises(Exception, match="256"):
+            HipModel(HeadConfig(mt, (16, 96), layer_dim=384), FrontendConfig())

@@ -128,13 +128,15 @@ def config_legs(torch, dev):
     from nanowakeword_amd.synth import synth_pcm, synth_state_dict
     stream = torch.cuda.current_stream(dev).cuda_stream
     legs = {}
-    for key, name, cfg, fe, B in (
-            ("C1", "dnn head, (98,40) log-mel (40-mel, no centre), batch 32", HeadConfig("dnn", (98, 40)), FrontendConfig(n_mels=40, center=False), 32),
-            ("C3", "bcresnet head, (101,64), batch 8192 (= 65536 / 8 GPUs), fp32", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192),
-            ("C5", "conformer head, (101,64), batch 2048 (= 16384 / 8 GPUs), MFMA attention", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048)):
+    for key, name, cfg, fe, B, act_dtype in (
+            ("C1", "dnn head, (98,40) log-mel (40-mel, no centre), batch 32", HeadConfig("dnn", (98, 40)), FrontendConfig(n_mels=40, center=False), 32, None),
+            ("C3", "bcresnet head, (101,64), batch 8192 (= 65536 / 8 GPUs), fp32", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, None),
+            ("C3_bf16", "bcresnet head, (101,64), batch 8192, bf16 activations between kernels (opt-in act_dtype; tolerance 2e-2)",
+             HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, "bf16"),
+            ("C5", "conformer head, (101,64), batch 2048 (= 16384 / 8 GPUs), MFMA attention", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048, None)):
         sd = synth_state_dict(cfg)
         window, fb = torchaudio_tables(fe)
-        m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb)
+        m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, act_dtype=act_dtype)
         pcm_h = synth_pcm("noise", B, 16000, seed=10)
         pcm = torch.from_numpy(pcm_h).to(dev)
         logits = torch.empty(B, dtype=torch.float32, device=dev)

@@ -81,13 +81,19 @@ typedef struct nww_config {
          NWW_ARITH_BF16X9 each float32 operand split into three bf16 terms (exact), all nine partial products on
                           v_mfma_f32_32x32x16_bf16 - exact products, float32 accumulation
          NWW_ARITH_BF16X6 the six largest partial products; the dropped ones are < 2^-23 of a product
-         NWW_ARITH_DEFAULT lets the library choose (environment NWW_TRUNK_X3 = 0 | 9 | 6 overrides)              */
+         NWW_ARITH_DEFAULT lets the library choose (NWW_ARITH_BF16X6)                                            */
     int32_t conv_arith;
     /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
        CRNNModel, modules/architectures.py:238-254)                                                               */
     int32_t crnn_rnn_lstm;
-    int32_t reserved[5];
+    /* storage type of the activation tensors BETWEEN the head's kernels: NWW_ACT_F32 (default) or NWW_ACT_BF16 (round to
+       nearest even on store; products and accumulation stay float32).  bf16 is an opt-in for the BcResNet head
+       (BASELINE.json config 3 "bf16 activations"): logits then agree with the float32 reference to ~1e-2, not 1e-4.      */
+    int32_t act_dtype;
+    int32_t reserved[4];
 } nww_config;
+#define NWW_ACT_F32 0
+#define NWW_ACT_BF16 1
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1
 #define NWW_ARITH_BF16X6 6

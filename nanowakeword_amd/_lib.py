@@ -27,7 +27,8 @@ class NwwConfig(C.Structure):
         ("mel_major_features", C.c_int32),
         ("conv_arith", C.c_int32),
         ("crnn_rnn_lstm", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("act_dtype", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -112,10 +113,11 @@ def load_library():
 
 
 ARITH_CODE = {None: 0, "default": 0, "f32": 1, "bf16x6": 6, "bf16x9": 9}
+ACT_DTYPE_CODE = {None: 0, "f32": 0, "bf16": 1}          # nww_config.act_dtype: storage of the activations between kernels
 
 
 def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major_features: bool | None = None,
-                conv_arith: str | None = None) -> NwwConfig:
+                conv_arith: str | None = None, act_dtype: str | None = None) -> NwwConfig:
     lib = load_library()
     c = NwwConfig()
     lib.nww_default_config(C.byref(c))
@@ -141,4 +143,7 @@ def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major
     if conv_arith not in ARITH_CODE:
         raise ValueError(f"conv_arith must be one of {sorted(k for k in ARITH_CODE if k)}")
     c.conv_arith = ARITH_CODE[conv_arith]
+    if act_dtype not in ACT_DTYPE_CODE:
+        raise ValueError("act_dtype must be 'f32' or 'bf16'")
+    c.act_dtype = ACT_DTYPE_CODE[act_dtype]
     return c

@@ -13,6 +13,9 @@ struct DualArgs {
     // x != nullptr: xs is not read; the shortcut's rows are gathered from the block input x [B][H][W][K] (channels last) at
     // (oy * sh, ox * sw) of pixel m = (b, oy, ox), M = B * Ho * Wo
     const float* x = nullptr; int H = 0, W = 0, Ho = 0, Wo = 0, sh = 1, sw = 1;
+    // bf16 activations (nww_config.act_dtype): d, xs / x and out are bf16 arrays; an activation is then ONE bf16 term, so a
+    // float32 weight needs three products (hi, mid, lo) instead of six
+    int bf16 = 0;
 };
 
 // one packed 32-output block: 2 x K/16 x 3 fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps

@@ -99,7 +99,20 @@ __global__ void __launch_bounds__(256) dual_pack_kernel(const float* __restrict_
     }
 }
 
-template <int K16, int ACT>
+// three products of a float32 weight (three bf16 terms) with a bf16 activation, small terms first
+__device__ __forceinline__ void mfma3d(const bf16x8 (&w)[3], const bf16x8& x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pk_bf16d(float a, float b) {      // round to nearest even
+    union { __bf16 h[2]; uint32_t u; } c;
+    c.h[0] = (__bf16)a; c.h[1] = (__bf16)b;
+    return c.u;
+}
+
+// BF: bf16 activations in and out (DualArgs::bf16)
+template <int K16, int ACT, bool BF>
 __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
     constexpr int FRAG_BYTES = 2 * K16 * 3072, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
@@ -123,14 +136,25 @@ __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
     fetch(0, wb0);
 
     // ---- the lane's half rows (features 16kb + 8h + e) of d and xs -> fragments
-    bf16x8 xf[2][K16][3];
+    bf16x8 xf[2][K16][BF ? 1 : 3];
     const float* xs_row = nullptr;
+    size_t xs_off = 0;                                         // element offset of the pixel's row in x (BF: 2-byte elements)
     if (a.x) {
         const int per = a.Ho * a.Wo;
         const int b = (int)(rr / per), r2 = (int)(rr - (size_t)b * per), oy = r2 / a.Wo, ox = r2 - oy * a.Wo;
-        xs_row = a.x + (((size_t)b * a.H + (size_t)oy * a.sh) * a.W + (size_t)ox * a.sw) * K;
+        xs_off = (((size_t)b * a.H + (size_t)oy * a.sh) * a.W + (size_t)ox * a.sw) * K;
+        xs_row = a.x + xs_off;
     }
-    {
+    if constexpr (BF) {
+        // a bf16 row IS the B fragment: eight channels = one 16-byte load
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const __bf16* xrow = p ? (a.x ? reinterpret_cast<const __bf16*>(a.x) + xs_off : reinterpret_cast<const __bf16*>(a.xs) + rr * K)
+                                   : reinterpret_cast<const __bf16*>(a.d) + rr * K;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb) xf[p][kb][0] = *reinterpret_cast<const bf16x8*>(xrow + 16 * kb + 8 * h);
+        }
+    } else {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             // xs: its own [M][K] rows, or (a.x) the block input x [B][H][W][K] read at the strided centre of the pixel - the
@@ -173,8 +197,13 @@ __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
                     for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * 3 + t) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma6d(cw[0], xf[0][kb], acc[0]);
-            mfma6d(cw[1], xf[1][kb], acc[1]);
+            if constexpr (BF) {
+                mfma3d(cw[0], xf[0][kb][0], acc[0]);
+                mfma3d(cw[1], xf[1][kb][0], acc[1]);
+            } else {
+                mfma6d(cw[0], xf[0][kb], acc[0]);
+                mfma6d(cw[1], xf[1][kb], acc[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
@@ -191,7 +220,8 @@ __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
                 o.y = (acc[1][4 * g + 1] * as.y + bs.y) + dual_act<ACT>(acc[0][4 * g + 1] * a1.y + b1.y);
                 o.z = (acc[1][4 * g + 2] * as.z + bs.z) + dual_act<ACT>(acc[0][4 * g + 2] * a1.z + b1.z);
                 o.w = (acc[1][4 * g + 3] * as.w + bs.w) + dual_act<ACT>(acc[0][4 * g + 3] * a1.w + b1.w);
-                *reinterpret_cast<float4*>(orow + col) = o;
+                if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) = make_uint2(pk_bf16d(o.x, o.y), pk_bf16d(o.z, o.w));
+                else *reinterpret_cast<float4*>(orow + col) = o;
             }
         }
     };
@@ -235,7 +265,9 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     DualArgs a = a0;
     a.nblk = (a.N + 31) / 32;
     const dim3 grid((a.M + 127) / 128);
-#define DUAL_GO(K16V, ACTV) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV>), grid, dim3(256), 0, s, a);
+#define DUAL_GO(K16V, ACTV)                                                                                        \
+    if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true>), grid, dim3(256), 0, s, a);                  \
+    else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false>), grid, dim3(256), 0, s, a);
 #define DUAL_ACT(K16V)                                                                                             \
     switch (act) {                                                                                                 \
         case ACT_RELU: DUAL_GO(K16V, ACT_RELU) break;                                                              \

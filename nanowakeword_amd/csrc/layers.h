@@ -77,13 +77,14 @@ hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
 
 // depthwise 3x3, pad 1, stride (sh, sw) on channels-last data: in [B][H][W][C], wt [9][C] (tap-major weights)
 // -> d_out [B][Ho][Wo][C]; xs_out (may be null) receives in[b][oy*sh][ox*sw][c], the input of a strided 1x1 conv.
+// bf16 = true: `in` and `d_out` are bf16 arrays (nww_config.act_dtype), xs_out must be null
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
-                                 int W, int sh, int sw, hipStream_t s);
+                                 int W, int sh, int sw, hipStream_t s, bool bf16 = false);
 // rows [R][D]: y = act(LayerNorm(x)*w + b), eps 1e-5, biased variance; in place allowed (y == x)
 hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
                             hipStream_t s);
 // mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)
-hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s);
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, bool bf16_in = false);
 // LayerNorm over D of every row of [B][L][D], then the mean over L -> out [B][D] (D <= 256)
 hipError_t launch_ln_mean(const float* x, float* out, const float* w, const float* b, int B, int L, int D, hipStream_t s);
 // AvgPool2d(kernel (kh,kw), stride (sh,sw)) on [B*C][H][W] -> [B*C][oh][ow]  (export form of AdaptiveAvgPool2d)

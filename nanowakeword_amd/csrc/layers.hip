@@ -440,6 +440,12 @@ dwconv3x3_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ wt
 // (stride 1: 18 loads for 4 outputs instead of 36 four-byte ones per channel; stride 2: 27), the nine weights of the four
 // channels stay in registers.  Same tap order and fmaf chain as dwconv3x3_nhwc_kernel.  xs_out is not supported (the
 // split-operand block kernel gathers the shortcut rows itself).
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // round to nearest even
+    union { __bf16 h[2]; uint32_t u; } c;
+    c.h[0] = (__bf16)a; c.h[1] = (__bf16)b;
+    return c.u;
+}
+
 template <int SW>
 __global__ void __launch_bounds__(256)
 dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ d_out, int C, int H, int W,
@@ -488,9 +494,78 @@ dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__
     }
 }
 
+// bf16 activations (nww_config.act_dtype): a thread owns EIGHT channels (one 16-byte load per input pixel) of two outputs
+// along x - 7.5 sixteen-byte loads per output where the float32 kernel above needs 13.5 per eight channels
+template <int SW>
+__global__ void __launch_bounds__(256)
+dwconv3x3_nhwc_bf16_kernel(const __bf16* __restrict__ in, const float* __restrict__ wt, __bf16* __restrict__ d_out, int C, int H, int W,
+                           int Ho, int Wo, int sh, size_t total) {
+    constexpr int NX = 2, COLS = (NX - 1) * SW + 3;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // ((b*Ho + oy)*Wg + xg)*C8 + c8
+    if (idx >= total) return;
+    const int C8 = C / 8, Wg = (Wo + NX - 1) / NX;
+    const int c8 = (int)(idx % C8);
+    size_t t = idx / C8;
+    const int xg = (int)(t % Wg);
+    t /= Wg;
+    const int oy = (int)(t % Ho);
+    const size_t b = t / Ho;
+    const __bf16* ip = in + b * (size_t)H * W * C + 8 * c8;
+    float acc[NX][8];
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.0f;
+    const int x_first = xg * NX * SW - 1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = oy * sh - 1 + dy;
+        const bool oky = yy >= 0 && yy < H;
+        uint4 v[COLS];
+#pragma unroll
+        for (int cx = 0; cx < COLS; ++cx) {
+            const int xx = x_first + cx;
+            v[cx] = (oky && xx >= 0 && xx < W) ? *reinterpret_cast<const uint4*>(ip + ((size_t)yy * W + xx) * C) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wt + (size_t)(dy * 3 + dx) * C + 8 * c8);
+            const float4 w1 = *reinterpret_cast<const float4*>(wt + (size_t)(dy * 3 + dx) * C + 8 * c8 + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const uint4 p = v[j * SW + dx];
+                const uint32_t u[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[j][2 * e] = fmaf(__uint_as_float(u[e] << 16), w[2 * e], acc[j][2 * e]);
+                    acc[j][2 * e + 1] = fmaf(__uint_as_float(u[e] & 0xffff0000u), w[2 * e + 1], acc[j][2 * e + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int ox = xg * NX + j;
+        if (ox < Wo)
+            *reinterpret_cast<uint4*>(d_out + ((b * Ho + oy) * (size_t)Wo + ox) * C + 8 * c8) =
+                make_uint4(pk_bf16(acc[j][0], acc[j][1]), pk_bf16(acc[j][2], acc[j][3]), pk_bf16(acc[j][4], acc[j][5]), pk_bf16(acc[j][6], acc[j][7]));
+    }
+}
+
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
-                                 int W, int sh, int sw, hipStream_t s) {
+                                 int W, int sh, int sw, hipStream_t s, bool bf16) {
     const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+    if (bf16) {                                                // bf16 activations: their own kernel, eight channels per thread
+        if (xs_out || C % 8 != 0 || (sw != 1 && sw != 2) || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(wt)) & 15) != 0)
+            return hipErrorInvalidValue;
+        const size_t total8 = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 8);
+        const __bf16* ib = reinterpret_cast<const __bf16*>(in);
+        __bf16* ob = reinterpret_cast<__bf16*>(d_out);
+        if (sw == 1) hipLaunchKernelGGL(dwconv3x3_nhwc_bf16_kernel<1>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8);
+        else hipLaunchKernelGGL(dwconv3x3_nhwc_bf16_kernel<2>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8);
+        return hipGetLastError();
+    }
     if (!xs_out && C % 4 == 0 && (sw == 1 || sw == 2) &&
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0) {
         const size_t total4 = (size_t)B * Ho * ((Wo + 3) / 4) * (C / 4);
@@ -554,13 +629,18 @@ hipError_t launch_layernorm(const float* x, float* y, const float* w, const floa
 
 // ------------------------------------------------------------------------------------------ reductions / pools
 __global__ void __launch_bounds__(256)
-mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total) {
+mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total, int bf16) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*D + d
     if (idx >= total) return;
     const size_t b = idx / D, d = idx - b * D;
-    const float* p = in + b * (size_t)L * D + d;
     float s = 0.0f;
-    for (int l = 0; l < L; ++l) s += p[(size_t)l * D];
+    if (bf16) {                                                     // bf16 activations in, float32 mean out
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(in) + b * (size_t)L * D + d;
+        for (int l = 0; l < L; ++l) s += __uint_as_float((uint32_t)p[(size_t)l * D] << 16);
+    } else {
+        const float* p = in + b * (size_t)L * D + d;
+        for (int l = 0; l < L; ++l) s += p[(size_t)l * D];
+    }
     out[idx] = s / (float)L;
 }
 // LayerNorm of every row of a clip followed by the mean over its rows, in one pass over [B][L][D] (the Conformer's last
@@ -604,9 +684,33 @@ hipError_t launch_ln_mean(const float* x, float* out, const float* w, const floa
     return hipGetLastError();
 }
 
-hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s) {
+// bf16 rows: a thread owns eight channels (16-byte loads)
+__global__ void __launch_bounds__(256)
+mean_mid_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ out, int L, int D, size_t total8) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*(D/8) + d8
+    if (idx >= total8) return;
+    const int D8 = D / 8;
+    const size_t b = idx / D8, d8 = idx - b * D8;
+    const __bf16* p = in + b * (size_t)L * D + 8 * d8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)l * D);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(u[e] << 16); s[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+    }
+    float* o = out + b * D + 8 * d8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s[e] / (float)L;
+}
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, bool bf16) {
+    if (bf16 && D % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const size_t total8 = (size_t)B * (D / 8);
+        hipLaunchKernelGGL(mean_mid_bf16_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), out, L, D, total8);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * D;
-    hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total);
+    hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total, bf16 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -298,6 +298,9 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be a multiple of 4 and <= 256", c.layer_dim);
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
+    if (c.act_dtype != NWW_ACT_F32 && c.act_dtype != NWW_ACT_BF16) return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_F32 or NWW_ACT_BF16");
+    if (c.act_dtype == NWW_ACT_BF16 && c.head_type != NWW_HEAD_BCRESNET)
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 is implemented for the BcResNet head only (BASELINE config 3)");
     if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d has no compiled kernel (multiples of 4 up to 72, or 18)",
                     c.conformer_d_model / c.conformer_n_head);
@@ -847,14 +850,20 @@ extern "C" int nww_finalize(nww_handle* h) {
             // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
             static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
             const bool front_fused = ic_mfma && bc_front && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
+            // nww_config.act_dtype = NWW_ACT_BF16: every activation tensor between the kernels of this head is stored as bf16
+            // (arithmetic and accumulation stay float32); implemented on the fused front + split-operand block path only
+            const bool act_bf16 = c.act_dtype == NWW_ACT_BF16;
+            if (act_bf16 && !(front_fused && p.h->conv_products == 6))
+                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 needs the fused BcResNet front kernel and conv_arith bf16x6 for this input shape");
             if (front_fused) {
                 const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
                 const float* dwt1 = p.W("model.block1.depthwise.weight_t");
                 const int ho1 = (T / 2 - 1) / 2 + 1, wo1 = (F / 2 - 1) / 2 + 1;
                 p.need(2, (size_t)32 * ho1 * wo1); p.need(3, (size_t)32 * ho1 * wo1);
                 const int max_grid = p.h->cu_count;
-                p.add("conv1_dw_mfma:init_conv + block1.depthwise (nhwc)", [=](Run& r) {
+                p.add(std::string("conv1_dw_mfma:init_conv + block1.depthwise (nhwc") + (act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
+                    a.bf16_out = act_bf16 ? 1 : 0;
                     return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);
                 });
             } else if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {
@@ -899,11 +908,12 @@ extern "C" int nww_finalize(nww_handle* h) {
                             const bool gather = !(front_fused && i == 1);
                             if (gather) {
                                 p.pop_last();
-                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream); });
+                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act_bf16); });
                             }
-                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
                                 if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
+                                a.bf16 = act_bf16 ? 1 : 0;
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });
                             hh = ho; ww = wo; cur = outb;
@@ -911,6 +921,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                         }
                         (void)hipFree(packed);
                     }
+                    if (act_bf16) return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16: block %d has no split-operand kernel (channels %d -> %d)", i, ci, co);
                     p.add("gemm2:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
                         GemmArgs g;
                         g.A = r.buf[dwb]; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;
@@ -925,7 +936,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             }
             const int hw = hh * ww;
             p.need(2, 256);
-            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream); });
+            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream, act_bf16); });
             set_tail(p, "fc", 2, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }

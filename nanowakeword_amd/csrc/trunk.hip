@@ -695,8 +695,13 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
                     }
                 }
                 const size_t oi = ((size_t)oy * Wo + ox) * 32 + dc;
-                db[oi] = acc;
-                xb[oi] = centre;
+                if (a.bf16_out) {                         // wave-uniform: bf16 activations (round to nearest even)
+                    reinterpret_cast<__bf16*>(a.d_out)[(size_t)b * Ho * Wo * 32 + oi] = (__bf16)acc;
+                    reinterpret_cast<__bf16*>(a.xs_out)[(size_t)b * Ho * Wo * 32 + oi] = (__bf16)centre;
+                } else {
+                    db[oi] = acc;
+                    xb[oi] = centre;
+                }
             }
             __syncthreads();
         }

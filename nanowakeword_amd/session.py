@@ -62,13 +62,15 @@ class HipModel:
 
     def __init__(self, head: HeadConfig, frontend: Optional[FrontendConfig] = None, device: int = 0,
                  state_dict: Optional[Mapping] = None, window=None, mel_fb=None, tables: str = "torchaudio",
-                 conv_arith: Optional[str] = None):
+                 conv_arith: Optional[str] = None, act_dtype: Optional[str] = None):
+        """act_dtype="bf16": the BcResNet head stores the activations between its kernels as bf16 (BASELINE config 3 as written;
+        float32 products and accumulation; logits then agree with the float32 reference to ~1e-2 instead of 1e-4)."""
         self.lib = _lib.load_library()      # ImportError if the HIP extension is missing - no fallback
         self.head = head
         self.fe = frontend or FrontendConfig()
         self.device = device
         self._h = C.c_void_p()
-        cfg = _lib.make_config(head, self.fe, device, conv_arith=conv_arith)      # None: library default
+        cfg = _lib.make_config(head, self.fe, device, conv_arith=conv_arith, act_dtype=act_dtype)      # None: library defaults
         rc = self.lib.nww_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             msg = self.lib.nww_last_error(None).decode()

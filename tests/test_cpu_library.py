@@ -41,7 +41,11 @@ def test_config_struct_mirrors_header():
         if m:
             names += [re.sub(r"\[.*\]", "", n).strip() for n in m.group(1).split(",")]
     assert names == [f[0] for f in _lib.NwwConfig._fields_]
-    assert ctypes.sizeof(_lib.NwwConfig) == 4 * (len(names) + 3 + 4) == 132   # crnn_channels[4] and reserved[5] arrays; size fixed across versions
+    assert ctypes.sizeof(_lib.NwwConfig) == 4 * (len(names) + 3 + 3) == 132   # crnn_channels[4] and reserved[4] arrays; size fixed across versions
+    assert int(re.search(r"#define NWW_ACT_BF16 (\d+)", hdr).group(1)) == _lib.ACT_DTYPE_CODE["bf16"] and _lib.ACT_DTYPE_CODE["f32"] == 0
+    assert _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="bf16").act_dtype == 1
+    with pytest.raises(ValueError):
+        _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="fp8")
     for key, code in (("f32", "NWW_ARITH_F32"), ("bf16x6", "NWW_ARITH_BF16X6"), ("bf16x9", "NWW_ARITH_BF16X9")):
         assert int(re.search(rf"#define {code} (\d+)", hdr).group(1)) == _lib.ARITH_CODE[key]
     cfg = _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="bf16x9")

@@ -565,6 +565,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv1_pool_nhwc_mfma_kernel(Conv1N
     }
 }
 
+// (Round 3, measured and not kept: this kernel with its convolution as the transposed split-operand bf16 product of trunk_b.hip
+// - 12 bf16 MFMAs per 32 pooled pixels and 16 channels, pooling in registers, float4 stores into P, four waves x two
+// workgroups per CU at 238 registers: correct (|dlogit| 2.6e-6) and SLOWER, 1.06 vs 0.93 ms per 8192 clips - the stage is
+// bound by its depthwise / staging phases, which want this version's sixteen waves per CU, not by the f32 MFMAs.)
 // The same first conv fused with the FIRST BLOCK'S depthwise 3x3 (stride sh x sw, padding 1; architectures.py:632-647):
 // the pooled 32-channel planes - 205 KB per clip, 1.7 GB per 8192 clips written and read back when the two stages are
 // separate launches - stay in LDS, one strip of rows at a time, and only the depthwise output d [B][Ho][Wo][32] and the

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     }
     TB_STAMP_WG(2);
 }
+
 }  // namespace
 
 size_t trunk_b_packed_bytes() { return (size_t)NFRAG * 1024; }
@@ -562,3 +563,4 @@ hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hi
 #undef TB_ACT
     return hipGetLastError();
 }
+

@@ -20,6 +20,11 @@
 // results) ran fc1 in 0.098 ms against 0.090 for this kernel.  The step draws 1350 W of the package's 1400 W cap
 // (tools/power_probe.sh): at the cap a kernel's time follows the energy of its instructions, and that version read every
 // A fragment from LDS twice (two waves per row block).
+// Also measured and not kept, for the small-M instance (fc1 at B = 1, 24 us event to event): one wave per (32 rows, 32 columns,
+// chunk) with no LDS and no barrier, loads four k-tiles ahead (27 us), and four waves sharing the staging of eight k-tiles per
+// barrier with weight fragments loaded straight from the split layout (31 us) - both bit-identical.  The call is bound by
+// streaming the 9.8 MB of split weights through the 64 sequential (column tile, split-K chunk) accumulation chains that
+// batch invariance fixes, not by the per-tile staging round.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -133,6 +133,10 @@ struct TailArgs {
     // z ascending (gemm_splitk_reduce_kernel's order and epilogue, bit for bit)
     const float* parts = nullptr; int nparts = 0; size_t part_stride = 0;
     const float *in_bias = nullptr, *in_alpha = nullptr, *in_beta = nullptr; int in_act = 0;
+    // completion word for the interpreter's small calls: when the launch is ONE workgroup (B <= 16), its last act is
+    // *done_flag = done_seq (system scope, after the logits / probabilities) - the host polls it instead of paying the
+    // runtime's stream synchronisation
+    unsigned int* done_flag = nullptr; unsigned int done_seq = 0;
 };
 bool tail_supported(int Kin, int E);
 hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s);

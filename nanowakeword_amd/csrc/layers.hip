@@ -1454,7 +1454,7 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
                 if (js[r] < Hd) hs[c * ldh + js[r]] = act_ct<ACT>(acc[r] + a.b0[js[r]]);
         }
         __syncthreads();
-        if (tid < 16 && b0 + tid < a.B) {
+        if (tid < 16 && b0 + tid < a.B) {                      // (tid 0 is among them when B >= 1: its stores precede the flag)
             const float* hr = hs + tid * ldh;
             float acc = 0.0f;
             for (int j = 0; j < Hd; ++j) acc = fmaf(hr[j], a.w3[j], acc);
@@ -1463,6 +1463,10 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
             if (a.probs) a.probs[b0 + tid] = 1.0f / (1.0f + expf(-l));
         }
         __syncthreads();
+    }
+    if (a.done_flag && gridDim.x == 1 && tid == 0) {           // everything above is visible system-wide before the word is
+        __threadfence_system();
+        __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

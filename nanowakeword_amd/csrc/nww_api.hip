@@ -1,5 +1,6 @@
 // nww_api.hip - the C-ABI of include/nww.h: handle, weights, plans (sequence of kernel launches per head).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +46,7 @@ struct Run {
     float* logits = nullptr;    // [B]
     float* probs = nullptr;     // [B] or null; a plan step that writes it clears `need_sigmoid`
     bool need_sigmoid = true;
+    unsigned int* done_flag = nullptr; unsigned int done_seq = 0; bool done_armed = false;   // zero-copy small calls (classifier tail's completion word)
     float* splitk_ws = nullptr; size_t splitk_floats = 0; int cu_count = 256;
     // a split-K GEMM that left its partials for the classifier tail to reduce (GemmArgs::defer_reduce)
     struct { bool active = false; int out_id = 0, parts = 0; size_t stride = 0; const float *bias = nullptr, *alpha = nullptr, *beta = nullptr; int act = 0; } deferred;
@@ -85,6 +87,7 @@ struct nww_handle {
     void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
     unsigned char* pin_in = nullptr; unsigned char* pin_out = nullptr;   // pinned staging for small host-pointer calls
     bool pin_in_busy = false;                                            // an async copy out of pin_in may still be in flight
+    unsigned int done_seq = 0;                                           // completion-word sequence of the zero-copy small calls
     int comm_rank = 0, comm_world = 1;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
@@ -1035,6 +1038,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             }
             r.deferred.active = false;
             r.need_sigmoid = false;
+            if (r.done_flag && r.B <= 16) { t.done_flag = r.done_flag; t.done_seq = r.done_seq; r.done_armed = true; }
             return launch_classifier_tail(t, r.stream);
         });
     } else {
@@ -1126,8 +1130,10 @@ extern "C" int nww_reserve(nww_handle* h, int32_t B, int32_t N) {
     return ensure_ws(h, B, N);
 }
 
-static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s) {
+static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s, unsigned int* done_flag = nullptr,
+                    unsigned int done_seq = 0, bool* done_armed = nullptr) {
     Run r;
+    r.done_flag = done_flag; r.done_seq = done_seq;
     r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
     r.probs = d_probs;
     r.splitk_ws = h->d_splitk; r.splitk_floats = h->splitk_per_clip * (size_t)h->cap_B; r.cu_count = h->cu_count;
@@ -1148,6 +1154,7 @@ static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, flo
         if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "launch 'sigmoid' failed: %s", hipGetErrorString(e));
     }
     prof_mark(h, s, -1);
+    if (done_armed) *done_armed = r.done_armed;
     return NWW_OK;
 }
 
@@ -1180,7 +1187,7 @@ extern "C" int nww_frontend_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, 
 }
 
 static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s,
-                           size_t row_stride = 0) {
+                           size_t row_stride = 0, unsigned int* done_flag = nullptr, unsigned int done_seq = 0, bool* done_armed = nullptr) {
     const nww_config& c = h->cfg;
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
@@ -1194,7 +1201,7 @@ static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, fl
     prof_mark(h, s, 0);
     rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr, row_stride);
     if (rc) return rc;
-    return run_head(h, h->d_logmel, B, d_logits, d_probs, s);
+    return run_head(h, h->d_logmel, B, d_logits, d_probs, s, done_flag, done_seq, done_armed);
 }
 
 extern "C" int nww_forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_logits,
@@ -1264,6 +1271,36 @@ static int h2d_small(nww_handle* h, void* dst, const void* src, size_t bytes, hi
         return NWW_OK;
     }
     HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    return NWW_OK;
+}
+
+// Zero-copy staging for the interpreter's small calls: the kernels read the input straight out of the pinned staging buffer
+// (device-visible host memory) and the classifier tail writes logits / probabilities straight into the pinned output buffer,
+// so a call is memcpy -> kernels -> stream sync -> memcpy: no hipMemcpyAsync command in either direction (each costs ~8 us
+// of a B = 1 call).  Returns false when the buffers do not fit the staging area.
+static bool zero_copy_ptrs(nww_handle* h, size_t in_bytes, int B, void** d_in, float** d_logits, float** d_probs) {
+    if (in_bytes > PIN_BYTES || (size_t)2 * B * sizeof(float) + 16 > PIN_BYTES) return false;
+    if (!h->pin_in && hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), PIN_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+    if (!h->pin_out && hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), PIN_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+    void *di = nullptr, *dout = nullptr;
+    if (hipHostGetDevicePointer(&di, h->pin_in, 0) != hipSuccess || hipHostGetDevicePointer(&dout, h->pin_out, 0) != hipSuccess) return false;
+    *d_in = di;
+    *d_logits = static_cast<float*>(dout);
+    *d_probs = static_cast<float*>(dout) + B;
+    return true;
+}
+
+// Wait for a zero-copy call: poll the completion word the classifier tail writes into the pinned output buffer (a few us
+// sooner than the runtime's stream synchronisation returns), falling back to the stream sync when no kernel was armed to
+// write it or it does not show up within ~2 ms.
+static int zero_copy_wait(nww_handle* h, hipStream_t s, bool armed, volatile unsigned int* flag, unsigned int seq) {
+    if (armed) {
+        for (int spin = 0; spin < 2000000; ++spin) {
+            if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); h->pin_in_busy = false; return NWW_OK; }
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->pin_in_busy = false;
     return NWW_OK;
 }
 
@@ -1712,6 +1749,25 @@ extern "C" int nww_forward_pcm(nww_handle* h, const int16_t* pcm, int32_t B, int
     rc = ensure_ws(h, B, N);
     if (rc) return rc;
     hipStream_t s = h->own_stream;
+    {
+        void* d_in = nullptr; float *zl = nullptr, *zp = nullptr;
+        const size_t bytes = (size_t)B * N * sizeof(int16_t);
+        if (zero_copy_ptrs(h, bytes, B, &d_in, &zl, &zp)) {
+            if (h->pin_in_busy) { HIP_TRY(h, hipStreamSynchronize(s)); h->pin_in_busy = false; }
+            std::memcpy(h->pin_in, pcm, bytes);
+            h->pin_in_busy = true;
+            unsigned int* flag = reinterpret_cast<unsigned int*>(zl) + (PIN_BYTES / sizeof(float) - 4);     // last words of the pinned output buffer
+            const unsigned int seq = ++h->done_seq;
+            bool armed = false;
+            rc = forward_pcm_dev(h, static_cast<const int16_t*>(d_in), B, N, zl, zp, s, 0, flag, seq, &armed);
+            if (rc) return rc;
+            rc = zero_copy_wait(h, s, armed, reinterpret_cast<volatile unsigned int*>(h->pin_out + PIN_BYTES - 16), seq);
+            if (rc) return rc;
+            if (logits) std::memcpy(logits, h->pin_out, (size_t)B * sizeof(float));
+            if (probs) std::memcpy(probs, h->pin_out + (size_t)B * sizeof(float), (size_t)B * sizeof(float));
+            return NWW_OK;
+        }
+    }
     rc = h2d_small(h, h->d_pcm, pcm, (size_t)B * N * sizeof(int16_t), s);
     if (rc) return rc;
     rc = forward_pcm_dev(h, h->d_pcm, B, N, h->d_logits, h->d_probs, s);
@@ -1727,6 +1783,26 @@ extern "C" int nww_forward_features_ex(nww_handle* h, const float* feats, int32_
     rc = ensure_ws(h, B, 0);
     if (rc) return rc;
     hipStream_t s = h->own_stream;
+    if (!emb) {
+        void* d_in = nullptr; float *zl = nullptr, *zp = nullptr;
+        const size_t bytes = (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float);
+        if (zero_copy_ptrs(h, bytes, B, &d_in, &zl, &zp)) {
+            if (h->pin_in_busy) { HIP_TRY(h, hipStreamSynchronize(s)); h->pin_in_busy = false; }
+            std::memcpy(h->pin_in, feats, bytes);
+            h->pin_in_busy = true;
+            prof_begin(h);
+            unsigned int* flag = reinterpret_cast<unsigned int*>(zl) + (PIN_BYTES / sizeof(float) - 4);
+            const unsigned int seq = ++h->done_seq;
+            bool armed = false;
+            rc = run_head(h, static_cast<const float*>(d_in), B, zl, zp, s, flag, seq, &armed);
+            if (rc) return rc;
+            rc = zero_copy_wait(h, s, armed, reinterpret_cast<volatile unsigned int*>(h->pin_out + PIN_BYTES - 16), seq);
+            if (rc) return rc;
+            if (logits) std::memcpy(logits, h->pin_out, (size_t)B * sizeof(float));
+            if (probs) std::memcpy(probs, h->pin_out + (size_t)B * sizeof(float), (size_t)B * sizeof(float));
+            return NWW_OK;
+        }
+    }
     rc = h2d_small(h, h->d_feats, feats, (size_t)B * h->cfg.in_rows * h->cfg.in_cols * sizeof(float), s);
     if (rc) return rc;
     prof_begin(h);

@@ -507,8 +507,9 @@ hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hi
     // a handful of clips (the interpreter's B = 1 .. 16 calls) would occupy a handful of CUs for a whole clip each: cut
     // every clip into more row strips on more CUs instead.  Seam rows are recomputed by both neighbours with the same
     // arithmetic, so the result does not depend on the strip count (bit for bit).
-    const int small_strips = 4;
-    if (!force_strips && small_strips > S && (long)a.B * small_strips * 4 <= max_grid && small_strips <= a.H / 4) S = small_strips;
+    if (!force_strips)
+        for (int small_strips : {8, 6, 4})
+            if (small_strips > S && (long)a.B * small_strips * 4 <= max_grid && small_strips <= a.H / 4) { S = small_strips; break; }
     aa.strips = S;
     const size_t lds = trunk_b_lds_bytes(a.H, a.W, S);
     long want = (long)a.B * S;

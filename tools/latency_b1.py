@@ -6,7 +6,7 @@ from nanowakeword_amd.config import FrontendConfig, HeadConfig
 from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_pcm, synth_state_dict
 
-for name, cfg in (("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("cnn", HeadConfig("cnn", (101, 64))),
+for name, cfg in (("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("cnn", HeadConfig("cnn", (101, 64))),
                   ("dnn", HeadConfig("dnn", (101, 64))), ("crnn", HeadConfig("crnn", (101, 64)))):
     m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
     for B in (1, 8):

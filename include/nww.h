@@ -86,14 +86,14 @@ typedef struct nww_config {
     /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
        CRNNModel, modules/architectures.py:238-254)                                                               */
     int32_t crnn_rnn_lstm;
-    /* storage type of the activation tensors BETWEEN the head's kernels: NWW_ACT_F32 (default) or NWW_ACT_BF16 (round to
+    /* storage type of the activation tensors BETWEEN the head's kernels: NWW_ACT_DTYPE_F32 (default) or NWW_ACT_DTYPE_BF16 (round to
        nearest even on store; products and accumulation stay float32).  bf16 is an opt-in for the BcResNet head
        (BASELINE.json config 3 "bf16 activations"): logits then agree with the float32 reference to ~1e-2, not 1e-4.      */
     int32_t act_dtype;
     int32_t reserved[4];
 } nww_config;
-#define NWW_ACT_F32 0
-#define NWW_ACT_BF16 1
+#define NWW_ACT_DTYPE_F32 0
+#define NWW_ACT_DTYPE_BF16 1
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1
 #define NWW_ARITH_BF16X6 6

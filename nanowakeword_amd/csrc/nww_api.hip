@@ -301,8 +301,8 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be a multiple of 4 and <= 256", c.layer_dim);
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
-    if (c.act_dtype != NWW_ACT_F32 && c.act_dtype != NWW_ACT_BF16) return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_F32 or NWW_ACT_BF16");
-    if (c.act_dtype == NWW_ACT_BF16 && c.head_type != NWW_HEAD_BCRESNET)
+    if (c.act_dtype != NWW_ACT_DTYPE_F32 && c.act_dtype != NWW_ACT_DTYPE_BF16) return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_DTYPE_F32 or NWW_ACT_DTYPE_BF16");
+    if (c.act_dtype == NWW_ACT_DTYPE_BF16 && c.head_type != NWW_HEAD_BCRESNET)
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 is implemented for the BcResNet head only (BASELINE config 3)");
     if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d has no compiled kernel (multiples of 4 up to 72, or 18)",
@@ -853,9 +853,9 @@ extern "C" int nww_finalize(nww_handle* h) {
             // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
             static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
             const bool front_fused = ic_mfma && bc_front && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
-            // nww_config.act_dtype = NWW_ACT_BF16: every activation tensor between the kernels of this head is stored as bf16
+            // nww_config.act_dtype = NWW_ACT_DTYPE_BF16: every activation tensor between the kernels of this head is stored as bf16
             // (arithmetic and accumulation stay float32); implemented on the fused front + split-operand block path only
-            const bool act_bf16 = c.act_dtype == NWW_ACT_BF16;
+            const bool act_bf16 = c.act_dtype == NWW_ACT_DTYPE_BF16;
             if (act_bf16 && !(front_fused && p.h->conv_products == 6))
                 return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 needs the fused BcResNet front kernel and conv_arith bf16x6 for this input shape");
             if (front_fused) {

@@ -74,7 +74,7 @@ struct Conv1DwArgs {
     float* d_out; float* xs_out;
     int B, H, W, act, sh, sw;
     int Ho = 0, Wo = 0, rows_dw = 0; // filled by the launcher
-    int bf16_out = 0;                // d_out / xs_out are bf16 arrays (nww_config.act_dtype = NWW_ACT_BF16)
+    int bf16_out = 0;                // d_out / xs_out are bf16 arrays (nww_config.act_dtype = NWW_ACT_DTYPE_BF16)
 };
 int conv1_pool_dw_rows(int H, int W, int sh);      // depthwise rows per LDS strip, 0 = does not fit
 hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a, int max_grid, hipStream_t s);

@@ -42,7 +42,7 @@ def test_config_struct_mirrors_header():
             names += [re.sub(r"\[.*\]", "", n).strip() for n in m.group(1).split(",")]
     assert names == [f[0] for f in _lib.NwwConfig._fields_]
     assert ctypes.sizeof(_lib.NwwConfig) == 4 * (len(names) + 3 + 3) == 132   # crnn_channels[4] and reserved[4] arrays; size fixed across versions
-    assert int(re.search(r"#define NWW_ACT_BF16 (\d+)", hdr).group(1)) == _lib.ACT_DTYPE_CODE["bf16"] and _lib.ACT_DTYPE_CODE["f32"] == 0
+    assert int(re.search(r"#define NWW_ACT_DTYPE_BF16 (\d+)", hdr).group(1)) == _lib.ACT_DTYPE_CODE["bf16"] and _lib.ACT_DTYPE_CODE["f32"] == 0
     assert _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="bf16").act_dtype == 1
     with pytest.raises(ValueError):
         _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="fp8")

@@ -338,7 +338,16 @@ def main():
             dist.all_gather_into_tensor(gathered, logits if not a.debug_single_gpu else logits.cpu())   # RCCL over xGMI: 4 B per clip
 
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < a.prewarm_seconds:      # clock ramp (untimed, not counted in W)
+    while True:                                                 # clock ramp (untimed, not counted in W)
+        # N > 1: every step holds a collective, so all ranks must run the SAME number of pre-warm steps - rank 0's clock decides
+        # (ranks deciding by their own clocks can disagree by a block of steps and dead-lock in the all-gather)
+        go = time.perf_counter() - t_pre < a.prewarm_seconds
+        if world > 1:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=gdev)
+            dist.broadcast(flag, 0)
+            go = bool(int(flag.item()))
+        if not go:
+            break
         for _ in range(10):
             step()
         torch.cuda.synchronize(dev)

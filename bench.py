@@ -90,14 +90,36 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
                 dt = time.perf_counter() - t0
                 if dt >= budget:
                     return n, dt
-    n1, dt1 = timed(1, seconds * 0.35)
+    n1, dt1 = timed(1, seconds * 0.25)
     best = (n1 / dt1, 1, n1, dt1)
     for nt in sorted({min(8, ncpu), threads} - {1}):
-        n, dt = timed(nt, seconds * 0.3)
+        n, dt = timed(nt, seconds * 0.2)
         if n / dt > best[0]:
             best = (n / dt, nt, n, dt)
+    # BASELINE config 1 exactly: DNN head on (98,40) no-centre log-mel, batches of 32, 1 thread and all cores (<= 32)
+    from nanowakeword_amd.config import FrontendConfig, HeadConfig
+    from nanowakeword_amd.session import torchaudio_tables
+    from nanowakeword_amd.synth import synth_state_dict
+    c1_cfg, c1_fe = HeadConfig("dnn", (98, 40)), FrontendConfig(n_mels=40, center=False)
+    c1_sd = synth_state_dict(c1_cfg)
+    c1_w, c1_fb = torchaudio_tables(c1_fe)
+    c1_pcm = synth_pcm("noise", 32, 16000, seed=123)
+
+    def c1_one():
+        lm = oracle.frontend_logmel(c1_pcm, c1_w, c1_fb, n_mels=40, center=False).transpose(0, 2, 1)
+        return oracle.model_forward(np.ascontiguousarray(lm), c1_sd, c1_cfg)
+    c1 = {}
+    for nt in (1, threads):
+        with threadpool_limits(limits=nt):
+            c1_one()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds * 0.15:
+                c1_one()
+                n += 32
+            c1[f"clips_per_s_{nt}_threads"] = round(n / (time.perf_counter() - t0), 1)
     return {"value": round(best[0], 1), "unit": "clips/s", "cores": int(best[1]), "kind": "port",
             "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu),
+            "config1_dnn_98x40_batch32": c1,
             "sample": f"{best[2]} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
                       f"dense-DFT frontend + {cfg.model_type} head) in {best[3]:.1f} s on {best[1]} BLAS thread(s) "
                       f"(best of 1/8/{threads} threads; 1 thread = the reference interpreter's setting)"}

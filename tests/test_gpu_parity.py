@@ -137,6 +137,38 @@ def test_head_vs_oracle_and_golden(hip, golden_heads, golden_frontend, name):
     m.close()
 
 
+def test_host_pointer_calls_equal_device_pointer_calls(hip, golden_frontend):
+    """Small host-pointer calls take the zero-copy path (kernels read the pinned staging buffer, the classifier tail writes into
+    pinned memory and a completion word the host polls; B <= 16 arms the word, inputs up to 1 MiB = 32 clips stay zero-copy,
+    larger ones go through copy commands): every size must give the device-pointer entry point's logits bit for bit, call after
+    call, and the features entry point (with and without the embedding output) likewise."""
+    import torch
+    HipModel, _ = hip
+    g = golden_frontend
+    cfg = HeadConfig("cnn", (101, 64))
+    m = _model(hip, cfg, _fe_cfg(64, True), g, 64)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    x = synth_pcm("noise", 40, 16000, seed=11)
+    xd = torch.from_numpy(x).to(dev)
+    want_l = torch.empty(40, dtype=torch.float32, device=dev)
+    want_p = torch.empty(40, dtype=torch.float32, device=dev)
+    m.forward_pcm_dev(xd.data_ptr(), 40, 16000, want_l.data_ptr(), want_p.data_ptr(), stream)
+    torch.cuda.synchronize()
+    wl, wp = want_l.cpu().numpy(), want_p.cpu().numpy()
+    for B in (1, 2, 16, 17, 32, 33, 40, 1, 16):                # 16 | 17: completion word armed or not; 32 | 33: 1 MiB staging limit
+        lg, pr = m.forward_pcm(x[:B])
+        assert np.array_equal(lg, wl[:B]) and np.array_equal(pr, wp[:B]), B
+    feats = synth_features(20, cfg.input_shape, seed=4)
+    l1, p1 = m.forward_features(feats)
+    l2, p2, e2 = m.forward_features(feats, return_embedding=True)      # the embedding output keeps the copy path
+    assert np.array_equal(l1, l2) and np.array_equal(p1, p2) and e2.shape == (20, cfg.embedding_dim)
+    for B in (1, 16, 17):
+        lb, _ = m.forward_features(feats[:B])
+        assert np.array_equal(lb, l1[:B]), B
+    m.close()
+
+
 def test_session_protocol_and_errors(hip, golden_frontend):
     HipModel, HipSession = hip
     g = golden_frontend

@@ -111,9 +111,11 @@ __device__ __forceinline__ uint32_t pk_bf16d(float a, float b) {      // round t
     return c.u;
 }
 
-// BF: bf16 activations in and out (DualArgs::bf16)
-template <int K16, int ACT, bool BF>
-__global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
+// BF: bf16 activations in and out (DualArgs::bf16).  NWV waves per workgroup (32 pixels each) share every weight block: a
+// workgroup streams ALL packed weights (K = 128: 8 x 52 KB) through LDS once per 32 NWV pixels, which at four waves was the
+// kernel's bound for the wide blocks (1.4 GB of L2 -> LDS traffic for block 3 at 8192 clips) - eight waves halve it.
+template <int K16, int ACT, bool BF, int NWV>
+__global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
     constexpr int FRAG_BYTES = 2 * K16 * 3072, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
@@ -121,11 +123,12 @@ __global__ void __launch_bounds__(256) dual_x3_kernel(DualArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int row = (int)blockIdx.x * 128 + wave * 32 + n;
+    const int row = (int)blockIdx.x * (32 * NWV) + wave * 32 + n;
     const bool row_ok = row < a.M;
     const size_t rr = (size_t)(row_ok ? row : a.M - 1);
 
     auto fetch = [&](int blk, unsigned char* buf) {
+        if (wave >= 4) return;                                           // the first four waves issue the copy (4 KB per step)
         const unsigned char* sp = a.packed + (size_t)blk * BLK + tid * 16;
         unsigned char* dst = buf + wave * 1024;                          // wave-uniform
 #pragma unroll
@@ -264,10 +267,20 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     if (a0.x && (a0.Ho <= 0 || a0.Wo <= 0 || a0.M % (a0.Ho * a0.Wo) != 0)) return hipErrorInvalidValue;
     DualArgs a = a0;
     a.nblk = (a.N + 31) / 32;
-    const dim3 grid((a.M + 127) / 128);
+    static const int wide = [] { const char* e = getenv("NWW_DUAL_WAVES"); return e ? atoi(e) : 8; }();
+    // eight waves per workgroup where it measured faster at 8192 clips: bf16 activations at K = 32 (0.255 -> 0.211 ms) and
+    // K = 128 (0.293 -> 0.229); K = 64 (0.161 -> 0.172) and every float32 shape (0.363 -> 0.395, 0.235 -> 0.248; K = 128
+    // needs 284 registers) stay at four
+    const bool w8 = wide == 8 && a.M >= 256 * 256 && a.bf16 && K != 64;
+    const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define DUAL_GO(K16V, ACTV)                                                                                        \
-    if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true>), grid, dim3(256), 0, s, a);                  \
-    else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false>), grid, dim3(256), 0, s, a);
+    if (w8) {                                                                                                      \
+        if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 8>), grid, dim3(512), 0, s, a);           \
+        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false, 8>), grid, dim3(512), 0, s, a);                 \
+    } else {                                                                                                       \
+        if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 4>), grid, dim3(256), 0, s, a);           \
+        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false, 4>), grid, dim3(256), 0, s, a);                 \
+    }
 #define DUAL_ACT(K16V)                                                                                             \
     switch (act) {                                                                                                 \
         case ACT_RELU: DUAL_GO(K16V, ACT_RELU) break;                                                              \

@@ -275,8 +275,7 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define DUAL_GO(K16V, ACTV)                                                                                        \
     if (w8) {                                                                                                      \
-        if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 8>), grid, dim3(512), 0, s, a);           \
-        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false, 8>), grid, dim3(512), 0, s, a);                 \
+        hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 8>), grid, dim3(512), 0, s, a);                       \
     } else {                                                                                                       \
         if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 4>), grid, dim3(256), 0, s, a);           \
         else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false, 4>), grid, dim3(256), 0, s, a);                 \

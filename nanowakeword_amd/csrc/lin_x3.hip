@@ -84,8 +84,9 @@ __global__ void __launch_bounds__(256) lin_pack_kernel(const float* __restrict__
 }
 
 // EPI: 0 = out = y + bias;  1 = out = res + rscale * (y + bias);  2 = GLU, out = (ya + bias_a) * sigmoid(yb + bias_b)
-template <int K16, int EPI, bool LN>
-__global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
+// NWV waves per workgroup (32 rows each) share every weight block streamed through LDS
+template <int K16, int EPI, bool LN, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
     constexpr int K = 16 * K16, PARTS = EPI == 2 ? 2 : 1;
     constexpr int FRAG_BYTES = PARTS * K16 * 3072, BLK = (FRAG_BYTES + PARTS * 128 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
@@ -93,12 +94,13 @@ __global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int row = (int)blockIdx.x * 128 + wave * 32 + n;
+    const int row = (int)blockIdx.x * (32 * NWV) + wave * 32 + n;
     const bool row_ok = row < a.M;
     const size_t rr = (size_t)(row_ok ? row : a.M - 1);
     const float* xrow = a.x + rr * a.ldx;
 
     auto fetch = [&](int blk, unsigned char* buf) {
+        if (wave >= 4) return;                                           // the first four waves issue the copy (4 KB per step)
         const unsigned char* sp = a.packed + (size_t)blk * BLK + tid * 16;
         unsigned char* dst = buf + wave * 1024;                          // wave-uniform
 #pragma unroll
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256, 2) lin_x3_kernel(LinArgs a) {
     if (EPI == 0 && a.qkv_T > 0) {
         const int D = a.N / 3, dh = a.qkv_dh, NH = D / dh, T = a.qkv_T;
         per_which = (size_t)(a.M / T) * NH * T * dh;
-        for (int c4 = tid; c4 < a.N / 4; c4 += 256) {
+        for (int c4 = tid; c4 < a.N / 4; c4 += 64 * NWV) {
             const int col = 4 * c4, which = col / D, rem = col - which * D, head = rem / dh, c = rem - head * dh;
             qkv_lut[c4] = head * T * dh + c;
             qkv_which[c4] = (unsigned char)which;
@@ -261,8 +263,14 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     if (((reinterpret_cast<uintptr_t>(a0.x) | reinterpret_cast<uintptr_t>(a0.out) | reinterpret_cast<uintptr_t>(a0.res)) & 15) != 0) return hipErrorInvalidValue;
     LinArgs a = a0;
     a.nblk = (a.N + 31) / 32;
-    const dim3 grid((a.M + 127) / 128);
-#define LIN_GO(K16V, EPIV, LNV) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV>), grid, dim3(256), 0, s, a);
+    // eight waves per workgroup for the GLU epilogue only: its four-wave instances need 212 - 264 registers and do not reach two
+    // workgroups per CU (LayerNorm + conv1 + GLU of the Conformer 0.155 -> 0.138 ms); the other epilogues measured slower with
+    // eight (in_proj 0.170 -> 0.199, out_proj / conv2 0.117 -> 0.125-0.129)
+    const bool w8 = epi == 2 && a.M >= 256 * 256;
+    const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
+#define LIN_GO(K16V, EPIV, LNV)                                                                                    \
+    if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4)>), grid, dim3(512), 0, s, a); \
+    else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4>), grid, dim3(256), 0, s, a);
 #define LIN_EPI(K16V)                                                                                              \
     if (epi == 0) LIN_GO(K16V, 0, false) else if (epi == 1) LIN_GO(K16V, 1, false) else if (ln) LIN_GO(K16V, 2, true) else LIN_GO(K16V, 2, false)
     switch (K) {

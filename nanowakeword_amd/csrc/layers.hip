@@ -1461,6 +1461,7 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
             const float l = acc + a.b3[0];
             a.logits[b0 + tid] = l;
             if (a.probs) a.probs[b0 + tid] = 1.0f / (1.0f + expf(-l));
+            if (a.done_flag) __threadfence_system();           // this thread's results reach the host before the barrier below
         }
         __syncthreads();
     }

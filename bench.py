@@ -456,9 +456,9 @@ def main():
             roofline["frac_of_issued_bf16_mix"] = round(achieved / (PEAK_BF16_TFLOPS / P), 4)
             roofline["note"] = ("peaks assume the 2.4 GHz boost clock; with all 256 CUs busy this kernel runs power-limited at "
                                 "1.9-2.0 GHz (tools/ubench/trunk_trace.hip, DESIGN.md 4.2b)")
-            # back-to-back bf16 MFMAs on all 256 CUs sustain 2.03 GHz at the 1400 W cap (tools/ubench/coresidency.hip): the
-            # matrix-pipe rate this package can actually hold is 2.03 / 2.4 of the nominal peak
-            roofline["frac_of_sustained_matrix_rate"] = round(achieved / peak / (2.03 / 2.4), 4)
+            # back-to-back bf16 MFMAs with toggling operands on all 256 CUs sustain 5.63e10 wave-instructions per second of the
+            # nominal 7.68e10 (1.85 GHz at the package's power limit; tools/ubench/power_mix.hip mode 4)
+            roofline["frac_of_sustained_matrix_rate"] = round(achieved / peak / (5.63 / 7.68), 4)
         fe_row = [r for r in per if r[0].startswith("frontend")]
         extra = {}
         if fe_row:

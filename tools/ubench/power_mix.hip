@@ -3,6 +3,8 @@
 //   mode 1: v_fma_f32, 8 independent chains per lane, 4 waves per SIMD
 //   mode 2: ds_read_b128 from conflict-free addresses, 4 waves per SIMD
 //   mode 3: v_mfma_f32_32x32x2_f32 back to back
+//   mode 4: as mode 0 with eight different pseudo-random operand pairs in rotation (operand toggling)
+//   mode 5: mode 4 on waves 0-7 and the v_fma_f32 chains of mode 1 on waves 8-15 of the same workgroup
 // Prints the sustained instruction rate; energy per wave-instruction = (power - idle power) / rate.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench/power_mix.hip -o tools/ubench/power_mix ; run: power_mix <mode> <seconds>
 #include <hip/hip_runtime.h>
@@ -22,6 +24,44 @@ __global__ void __launch_bounds__(512) k_mfma(float* out, int iters) {
         for (int u = 0; u < 8; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+__device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <bool MIX>
+__global__ void __launch_bounds__(MIX ? 1024 : 512) k_mfma_rand(float* out, int iters) {
+    if (MIX && threadIdx.x >= 512) {
+        float x[8];
+        for (int r = 0; r < 8; ++r) x[r] = (float)(threadIdx.x + r);
+        const float m = 1.0000001f, c = 0.5f;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(m), "v"(c));
+        float s = 0.f;
+        for (int r = 0; r < 8; ++r) s += x[r];
+        if (s == 12345.678f) out[threadIdx.x] = s;
+        return;
+    }
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    asm volatile("" : "+a"(acc0), "+a"(acc1));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 av[8], bv[8];
+    for (int p = 0; p < 8; ++p)
+        for (int r = 0; r < 4; ++r) {
+            // random mantissas and signs, exponents of both halves kept near 1 so that nothing overflows
+            av[p][r] = (hash32(threadIdx.x * 64 + p * 8 + r) & 0x807f807fu) | 0x3f003f00u;
+            bv[p][r] = (hash32(threadIdx.x * 64 + p * 8 + r + 4) & 0x807f807fu) | 0x3a003a00u;
+        }
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[u]), __builtin_bit_cast(bf16x8, bv[u]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[(u + 3) & 7]), __builtin_bit_cast(bf16x8, bv[(u + 5) & 7]), acc1, 0, 0, 0);
         }
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
@@ -71,7 +111,7 @@ int main(int argc, char** argv) {
     float* out; hipMalloc(&out, 1 << 20);
     const int iters = 20000;
     const double per_wave = mode == 0 || mode == 3 ? 16.0 * iters : mode == 1 ? 16.0 * iters : 16.0 * iters;      // instructions of interest per wave and launch
-    const int threads = mode == 0 || mode == 3 ? 512 : 1024;
+    const int threads = mode == 0 || mode == 3 || mode == 4 || mode == 5 ? 512 : 1024;      // mode 5 counts its MFMA waves
     double launches = 0;
     auto t0 = std::chrono::steady_clock::now();
     double el = 0;
@@ -80,6 +120,8 @@ int main(int argc, char** argv) {
             if (mode == 0) hipLaunchKernelGGL(k_mfma, dim3(256), dim3(512), 0, 0, out, iters);
             else if (mode == 1) hipLaunchKernelGGL(k_valu, dim3(256), dim3(1024), 0, 0, out, iters);
             else if (mode == 2) hipLaunchKernelGGL(k_lds, dim3(256), dim3(1024), 0, 0, out, iters);
+            else if (mode == 4) hipLaunchKernelGGL(k_mfma_rand<false>, dim3(256), dim3(512), 0, 0, out, iters);
+            else if (mode == 5) hipLaunchKernelGGL(k_mfma_rand<true>, dim3(256), dim3(1024), 0, 0, out, iters);
             else hipLaunchKernelGGL(k_mfma_f32, dim3(256), dim3(512), 0, 0, out, iters);
         }
         hipDeviceSynchronize();
@@ -88,6 +130,7 @@ int main(int argc, char** argv) {
     }
     const double wave_instr = launches * 256.0 * (threads / 64) * per_wave;
     printf("mode %d: %.3e wave-instructions per second (%s)\n", mode, wave_instr / el,
-           mode == 0 ? "v_mfma_f32_32x32x16_bf16" : mode == 1 ? "v_fma_f32" : mode == 2 ? "ds_read_b128" : "v_mfma_f32_32x32x2_f32");
+           mode == 0 ? "v_mfma_f32_32x32x16_bf16" : mode == 4 ? "v_mfma_f32_32x32x16_bf16, operands toggling" :
+           mode == 5 ? "v_mfma_f32_32x32x16_bf16 toggling, beside v_fma_f32 waves" : mode == 1 ? "v_fma_f32" : mode == 2 ? "ds_read_b128" : "v_mfma_f32_32x32x2_f32");
     return 0;
 }

@@ -4,6 +4,7 @@
 //   mode 2: ds_read_b128 from conflict-free addresses, 4 waves per SIMD
 //   mode 3: v_mfma_f32_32x32x2_f32 back to back
 //   mode 4: as mode 0 with eight different pseudo-random operand pairs in rotation (operand toggling)
+//   mode 6 / 7 / 8: mode 4 with A constant / A held for four consecutive instructions / a single accumulator
 //   mode 5: mode 4 on waves 0-7 and the v_fma_f32 chains of mode 1 on waves 8-15 of the same workgroup
 // Prints the sustained instruction rate; energy per wave-instruction = (power - idle power) / rate.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench/power_mix.hip -o tools/ubench/power_mix ; run: power_mix <mode> <seconds>
@@ -30,7 +31,9 @@ __global__ void __launch_bounds__(512) k_mfma(float* out, int iters) {
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 __device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-template <bool MIX>
+// ORD 0: A and B both change with every instruction; 1: A constant, B rotating; 2: A held for four consecutive
+// instructions (both accumulators, two B's each); 3: as 0 on ONE accumulator (dependent chain)
+template <bool MIX, int ORD = 0>
 __global__ void __launch_bounds__(MIX ? 1024 : 512) k_mfma_rand(float* out, int iters) {
     if (MIX && threadIdx.x >= 512) {
         float x[8];
@@ -60,8 +63,10 @@ __global__ void __launch_bounds__(MIX ? 1024 : 512) k_mfma_rand(float* out, int 
     for (int i = 0; i < iters; ++i)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[u]), __builtin_bit_cast(bf16x8, bv[u]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[(u + 3) & 7]), __builtin_bit_cast(bf16x8, bv[(u + 5) & 7]), acc1, 0, 0, 0);
+            const int a0 = ORD == 1 ? 0 : ORD == 2 ? (u & ~1) : u, a1 = ORD == 1 ? 0 : ORD == 2 ? (u & ~1) : (u + 3) & 7;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a0]), __builtin_bit_cast(bf16x8, bv[u]), acc0, 0, 0, 0);
+            if (ORD == 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a1]), __builtin_bit_cast(bf16x8, bv[(u + 5) & 7]), acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[a1]), __builtin_bit_cast(bf16x8, bv[(u + 5) & 7]), acc1, 0, 0, 0);
         }
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
@@ -111,7 +116,7 @@ int main(int argc, char** argv) {
     float* out; hipMalloc(&out, 1 << 20);
     const int iters = 20000;
     const double per_wave = mode == 0 || mode == 3 ? 16.0 * iters : mode == 1 ? 16.0 * iters : 16.0 * iters;      // instructions of interest per wave and launch
-    const int threads = mode == 0 || mode == 3 || mode == 4 || mode == 5 ? 512 : 1024;      // mode 5 counts its MFMA waves
+    const int threads = mode == 0 || mode >= 3 ? 512 : 1024;      // mode 5 counts its MFMA waves
     double launches = 0;
     auto t0 = std::chrono::steady_clock::now();
     double el = 0;
@@ -121,6 +126,9 @@ int main(int argc, char** argv) {
             else if (mode == 1) hipLaunchKernelGGL(k_valu, dim3(256), dim3(1024), 0, 0, out, iters);
             else if (mode == 2) hipLaunchKernelGGL(k_lds, dim3(256), dim3(1024), 0, 0, out, iters);
             else if (mode == 4) hipLaunchKernelGGL(k_mfma_rand<false>, dim3(256), dim3(512), 0, 0, out, iters);
+            else if (mode == 6) hipLaunchKernelGGL((k_mfma_rand<false, 1>), dim3(256), dim3(512), 0, 0, out, iters);
+            else if (mode == 7) hipLaunchKernelGGL((k_mfma_rand<false, 2>), dim3(256), dim3(512), 0, 0, out, iters);
+            else if (mode == 8) hipLaunchKernelGGL((k_mfma_rand<false, 3>), dim3(256), dim3(512), 0, 0, out, iters);
             else if (mode == 5) hipLaunchKernelGGL(k_mfma_rand<true>, dim3(256), dim3(1024), 0, 0, out, iters);
             else hipLaunchKernelGGL(k_mfma_f32, dim3(256), dim3(512), 0, 0, out, iters);
         }
@@ -131,6 +139,8 @@ int main(int argc, char** argv) {
     const double wave_instr = launches * 256.0 * (threads / 64) * per_wave;
     printf("mode %d: %.3e wave-instructions per second (%s)\n", mode, wave_instr / el,
            mode == 0 ? "v_mfma_f32_32x32x16_bf16" : mode == 4 ? "v_mfma_f32_32x32x16_bf16, operands toggling" :
-           mode == 5 ? "v_mfma_f32_32x32x16_bf16 toggling, beside v_fma_f32 waves" : mode == 1 ? "v_fma_f32" : mode == 2 ? "ds_read_b128" : "v_mfma_f32_32x32x2_f32");
+           mode == 5 ? "v_mfma_f32_32x32x16_bf16 toggling, beside v_fma_f32 waves" :
+           mode == 6 ? "bf16 MFMA, A constant, B toggling" : mode == 7 ? "bf16 MFMA, A held for four instructions" :
+           mode == 8 ? "bf16 MFMA toggling, one accumulator" : mode == 1 ? "v_fma_f32" : mode == 2 ? "ds_read_b128" : "v_mfma_f32_32x32x2_f32");
     return 0;
 }

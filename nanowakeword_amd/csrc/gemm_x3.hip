@@ -265,6 +265,110 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
     }
 }
 
+// Small M with split-K (fc1 / layer1 of an interpreter call: M = 1 .. 64, K >= 4096): the call is one round trip to memory
+// plus ONE dependent MFMA chain per (32 columns, split-K chunk) - batch invariance fixes the chunk and the order of the
+// 6 x 2 products of each of its k-tiles, so a chunk of 25 k-tiles costs 300 x 32 matrix-pipe clocks whatever else happens.
+// gemm_x3_kernel<1, 8> spends ~1500 clocks per k-tile on that (stage, barrier, multiply, barrier; eight k-tiles of loads
+// in flight).  Here the eight waves of a workgroup put the WHOLE chunk in flight at once - every wave loads the weight
+// fragments (16-byte pieces of the split layout, straight into MFMA operand registers) and the A rows of its own
+// CH_TPW k-tiles - and then the accumulator walks through the waves in k order, handed on
+// through 4 KB of LDS: no staging, one barrier per CH_TPW k-tiles.  Same products, same order, same chunks as every
+// other instance: results are bit-identical.
+constexpr int CH_NW = 8, CH_TPW = 4;
+__global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float4 hand[4 * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.x * 32, bn = blockIdx.y * 32;
+    const int KB = (g.K + 15) >> 4, KT = (g.K + 31) >> 5;
+    const int kc = (KT + g.splitk - 1) / g.splitk;
+    const int kt_begin = blockIdx.z * kc, kt_end = min(KT, kt_begin + kc);
+    const int mrow = min(bm + i, g.M - 1);
+    const uint4* wrow = reinterpret_cast<const uint4*>(g.Wx3) + (size_t)min(bn + i, g.N - 1) * KB * 6 + h;
+    const float* abase = g.a_blocked ? g.A + ((size_t)(mrow >> 7) * g.a_blocked * 128 + (mrow & 127)) * 32 + 8 * h
+                                     : g.A + (size_t)mrow * g.lda + 8 * h;
+    const size_t a_kstep = g.a_blocked ? 128 * 32 : 32;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int round = kt_begin; round < kt_end; round += CH_NW * CH_TPW) {
+        const int t0 = round + wave * CH_TPW;
+        const int nt = max(0, min(CH_TPW, kt_end - t0));                      // this wave's k-tiles (wave-uniform)
+        uint4 wf[CH_TPW][2][3];
+        float4 ar[CH_TPW][2][2];
+        // straight-line loads: k-tiles beyond the wave's share repeat its last valid one (never multiplied)
+#pragma unroll
+        for (int t = 0; t < CH_TPW; ++t) {
+            const int kt = min(t0 + t, kt_end - 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bool in_k = kt * 32 + 16 * kk + 8 * h < g.K;            // K % 8 == 0: a lane's eight k are all inside or all outside
+                const float* ap = in_k ? abase + (size_t)kt * a_kstep + 16 * kk : g.A;
+                ar[t][kk][0] = *reinterpret_cast<const float4*>(ap);
+                ar[t][kk][1] = *reinterpret_cast<const float4*>(ap + 4);
+                if (!in_k) { ar[t][kk][0] = make_float4(0.f, 0.f, 0.f, 0.f); ar[t][kk][1] = ar[t][kk][0]; }
+                const int kb = min(2 * kt + kk, KB - 1);                      // a k-block beyond KB meets zeros of A
+#pragma unroll
+                for (int term = 0; term < 3; ++term) wf[t][kk][term] = wrow[(size_t)kb * 6 + 2 * term];
+            }
+        }
+        const int active = min(CH_NW, (kt_end - round + CH_TPW - 1) / CH_TPW);    // waves that hold k-tiles of this round
+        const bool last_round = round + CH_NW * CH_TPW >= kt_end;
+        for (int s = 0; s < active; ++s) {
+            if (wave == s) {
+                if (s > 0 || round > kt_begin) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = hand[q * 64 + lane];
+                        acc[4 * q] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < CH_TPW; ++t) {
+                    if (t >= nt) continue;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        // A is split here, one k-block at a time, in the shadow of the previous block's MFMAs (all of A's
+                        // fragments beside all of W's would not fit the register file)
+                        const float x[8] = {ar[t][kk][0].x, ar[t][kk][0].y, ar[t][kk][0].z, ar[t][kk][0].w,
+                                            ar[t][kk][1].x, ar[t][kk][1].y, ar[t][kk][1].z, ar[t][kk][1].w};
+                        uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) split3(x[j], hi[j], mid[j], lo[j]);
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7])));
+                        const bf16x8 am = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7])));
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7])));
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[t][kk][0]), wm = __builtin_bit_cast(bf16x8, wf[t][kk][1]),
+                                     wl = __builtin_bit_cast(bf16x8, wf[t][kk][2]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);      // gemm_x3_kernel's order
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+                    }
+                }
+                if (last_round && s == active - 1) {                          // the chunk's partial sums
+                    const int n = bn + i;
+                    float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+                    if (n < g.N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = bm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (m < g.M) part[(size_t)m * g.N + n] = acc[r];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hand[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * ((K + 15) / 16) * 96; }
 
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s) {
@@ -309,6 +413,10 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
         case ACT_SILU: X3_GO(CBV, NSTV, ACT_SILU, GRID, LDSB) break;                                               \
         case ACT_SIGMOID: X3_GO(CBV, NSTV, ACT_SIGMOID, GRID, LDSB) break;                                         \
         default: X3_GO(CBV, NSTV, ACT_NONE, GRID, LDSB) break;                                                     \
+    }
+    if (g.M <= 64 && sk > 1 && g.K % 8 == 0) {                                 // one memory round trip + one MFMA chain per chunk
+        hipLaunchKernelGGL(gemm_x3_chain_kernel, dim3((g.M + 31) / 32, (g.N + 31) / 32, sk), dim3(64 * CH_NW), 0, s, a);
+        return hipGetLastError();
     }
     if (g.M <= 64) {                                           // small batches: latency, not throughput (see the kernel comment)
         dim3 grid1(1, (g.N + 31) / 32, sk);

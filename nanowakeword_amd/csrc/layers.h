@@ -115,8 +115,12 @@ struct GruArgs {
     const float* xg; const float* w_hh; const float* b_hh;
     float* seq_out; int ld_seq; float* last_out; int ld_last; int col_off;
     int B, T, H, reverse, steps;
+    int products = 0;      // 6 / 9: recurrent product from split operands on the bf16 matrix cores (rnn_x3.hip), 0: float32 MFMA
 };
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
+// rnn_x3.hip: gates = 3 (GRU) / 4 (LSTM), H in {32, 64, 128}
+bool rnn_x3_usable(const GruArgs& a);
+hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s);
 // LSTM recurrence for one direction, same arguments (xg is [B][T][4H], gate order i, f, g, o)
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s);
 

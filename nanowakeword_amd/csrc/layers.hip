@@ -962,6 +962,11 @@ bool mha_head_dim_supported(int dh) {
 }
 
 // ------------------------------------------------------------------------------------------ GRU recurrence
+// Gate functions of the register-resident recurrences on the hardware exp2 and reciprocal (1 ulp each): absolute error
+// <= 2e-7 against ~30 (sigmoid: expf + IEEE division) and ~40 (tanhf) instructions each - the gate arithmetic of a step was
+// as long as its matrix products.  tanh x = 1 - 2 / (1 + e^2x) saturates correctly through exp2 = 0 / inf.
+__device__ __forceinline__ float rnn_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float rnn_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
 // One workgroup = 32 clips x all H hidden units; wave w owns hidden units [32w, 32w+32) and computes, per
 // step, the three 32x32 gate tiles (r, z, n columns j, H+j, 2H+j) of  hg = h W_hh^T  on MFMA f32, with h as the
 // A operand read from LDS ([32][H+4] floats) and W_hh rows streamed from L2.  Gate math runs in the MFMA C
@@ -1095,6 +1100,20 @@ __global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) hprev[bl][r] = 0.0f;
     const float* arow = hs + n * LDH + g * KS;                // A operand: clip n, k slice g
+    // input-side pre-activations (independent of h) are fetched ONE STEP AHEAD: a row per clip from HBM takes longer than a step's
+    // recurrent product
+    float xq[3][2][4], xnext[3][2][4];
+    auto fetch = [&](int step, float (&x)[3][2][4]) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 3 * H + 32 * wave + n;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { x[q][0][r] = xg[q * H]; x[q][1][r] = xg[q * H + 16]; }
+        }
+    };
+    fetch(0, xq);
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
@@ -1103,15 +1122,7 @@ __global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int bl = 0; bl < 2; ++bl) acc[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // input-side pre-activations of this step (independent of h): in flight during the recurrent product
-        float xq[3][2][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 4 * g + r;
-            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 3 * H + 32 * wave + n;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { xq[q][0][r] = xg[q * H]; xq[q][1][r] = xg[q * H + 16]; }
-        }
+        if (step + 1 < a.steps) fetch(step + 1, xnext);
         if (step > 0) {                                       // h == 0 on the first step
 #pragma unroll
             for (int s4 = 0; s4 < KS / 4; ++s4) {
@@ -1135,9 +1146,9 @@ __global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
                 const int c = 4 * g + r, b = b0 + c;
                 float hn = 0.0f;
                 if (b < a.B) {
-                    const float rg = 1.0f / (1.0f + expf(-(xq[0][bl][r] + acc[0][bl][r] + bh[0][bl])));
-                    const float zg = 1.0f / (1.0f + expf(-(xq[1][bl][r] + acc[1][bl][r] + bh[1][bl])));
-                    const float ng = tanhf(xq[2][bl][r] + rg * (acc[2][bl][r] + bh[2][bl]));
+                    const float rg = rnn_sigmoid(xq[0][bl][r] + acc[0][bl][r] + bh[0][bl]);
+                    const float zg = rnn_sigmoid(xq[1][bl][r] + acc[1][bl][r] + bh[1][bl]);
+                    const float ng = rnn_tanh(xq[2][bl][r] + rg * (acc[2][bl][r] + bh[2][bl]));
                     hn = (1.0f - zg) * ng + zg * hprev[bl][r];
                     if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                     if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
@@ -1146,6 +1157,12 @@ __global__ void __launch_bounds__(64 * (H / 32), 1) gru16_kernel(GruArgs a) {
                 hs[c * LDH + j] = hn;
             }
         }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xq[q][bl][r] = xnext[q][bl][r];
         __syncthreads();
     }
 }
@@ -1269,20 +1286,25 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hprev[r] = 0.0f; cprev[r] = 0.0f; }
     const float* arow = hs + n * LDH + g * KS;
+    float xq[4][4], xnext[4][4];                              // input-side pre-activations, fetched one step ahead (gru16_kernel)
+    auto fetch = [&](int step, float (&x)[4][4]) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 4 * H + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q][r] = xg[q * H];
+        }
+    };
+    fetch(0, xq);
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float xq[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 4 * g + r;
-            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * 4 * H + j;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xq[q][r] = xg[q * H];
-        }
+        if (step + 1 < a.steps) fetch(step + 1, xnext);
         if (step > 0) {
 #pragma unroll
             for (int s4 = 0; s4 < KS / 4; ++s4) {
@@ -1301,18 +1323,22 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
             const int c = 4 * g + r, b = b0 + c;
             float hn = 0.0f, cn = 0.0f;
             if (b < a.B) {
-                const float ig = 1.0f / (1.0f + expf(-(xq[0][r] + acc[0][r] + bh[0])));
-                const float fg = 1.0f / (1.0f + expf(-(xq[1][r] + acc[1][r] + bh[1])));
-                const float gg = tanhf(xq[2][r] + acc[2][r] + bh[2]);
-                const float og = 1.0f / (1.0f + expf(-(xq[3][r] + acc[3][r] + bh[3])));
+                const float ig = rnn_sigmoid(xq[0][r] + acc[0][r] + bh[0]);
+                const float fg = rnn_sigmoid(xq[1][r] + acc[1][r] + bh[1]);
+                const float gg = rnn_tanh(xq[2][r] + acc[2][r] + bh[2]);
+                const float og = rnn_sigmoid(xq[3][r] + acc[3][r] + bh[3]);
                 cn = fg * cprev[r] + ig * gg;
-                hn = og * tanhf(cn);
+                hn = og * rnn_tanh(cn);
                 if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                 if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
             }
             hprev[r] = hn; cprev[r] = cn;
             hs[c * LDH + j] = hn;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xq[q][r] = xnext[q][r];
         __syncthreads();
     }
 }
@@ -1320,6 +1346,7 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    if (use16 && rnn_x3_usable(a)) return launch_rnn_x3(a, 4, s);
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
         const dim3 grid((a.B + 15) / 16);
@@ -1343,6 +1370,7 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    if (use16 && rnn_x3_usable(a)) return launch_rnn_x3(a, 3, s);
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
         const dim3 grid((a.B + 15) / 16);

@@ -630,8 +630,10 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                 add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
             }
             const int in_T = T;
+            const int products = p.h->conv_products;          // the recurrent product follows the handle's arithmetic switch
             p.add((G == 4 ? "lstm:" : "gru:") + prefix + sfx, [=](Run& r) {
                 GruArgs a;
+                a.products = products;
                 a.xg = r.buf[xg_id]; a.w_hh = whh; a.b_hh = bhh;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
                 a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H; a.col_off = dir ? H : 0;

@@ -1,0 +1,187 @@
+// rnn_x3.hip - GRU / LSTM recurrences with the recurrent product h W_hh^T on the bf16 matrix cores (gfx950).
+//
+// nn.GRU / nn.LSTM cell semantics as layers.hip states them (CRNNModel / GRU head: nanowakeword/modules/architectures.py:
+// 238-254, 731-760): xg = x W_ih^T + b_ih is precomputed for every frame, the kernel walks the T steps of one direction.
+//
+// One workgroup = 16 clips x all H hidden units for all T steps; wave w owns 16 (H = 128: 32) hidden units of every gate.
+// float32 operands are split exactly into three bf16 terms (gemm_x3.hip): W_hh once per launch, into MFMA B fragments that
+// stay in registers for all steps (G gates x H/32 k-blocks x 3 terms x 4 registers = 144 for the GRU at H = 128); h once
+// per step by the lane that produced it, into three bf16 planes in LDS that every wave reads back as A fragments (three
+// 16-byte reads per k-block, shared by the gates).  The 6 (or 9) partial products of a k-block go to
+// v_mfma_f32_16x16x32_bf16 - 16 matrix-pipe clocks for K = 32 against 8 x 32 for the same K on v_mfma_f32_16x16x4_f32,
+// which is what the float32 instances in layers.hip spend: 6144 of their ~11 000 clocks per step at H = 128.
+// C layout = column: hidden unit, rows 4g .. 4g + 3: clips, so xg loads and h stores are coalesced along the hidden dimension.
+// xg rows are requested two steps ahead; gate functions on the hardware exp2 / reciprocal (layers.hip: rnn_sigmoid).
+// Clips are independent rows of every product: results do not depend on batch size or position.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "layers.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+__device__ __forceinline__ void split3r(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    mid = __float_as_uint(r) & 0xffff0000u;
+    lo = __float_as_uint(r - __uint_as_float(mid));
+}
+__device__ __forceinline__ uint32_t pack_hi16r(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ float sigmoid_r(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float tanh_r(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
+
+// G = 3: GRU (r, z, n), G = 4: LSTM (i, f, g, o); NP = 6 or 9 partial products per operand pair; NB = 16-wide column blocks per
+// wave (2 at H = 128: four waves, one per SIMD, so that each has the whole 512-register file - 288 of them weight fragments)
+template <int G, int H, int NP, int NB>
+__global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a) {
+    constexpr int KS = H / 32;                                // MFMA k-blocks
+    constexpr int LDP = H + 8;                                // bf16 per LDS row: +16 bytes keeps the 16-byte fragment reads conflict-free
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_r);       // [3 terms][16 clips][LDP]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int j0 = 16 * NB * wave + n;                        // this lane's hidden units j0 + 16 bl (B-operand column, C-layout column)
+    for (int idx = threadIdx.x; idx < 3 * 16 * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
+
+    // W_hh rows q*H + j, k = 32 ks + 8 g .. + 7 -> B fragments, split once
+    uint4 wf[G][NB][KS][3];
+    float bh[G][NB];
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int bl = 0; bl < NB; ++bl) {
+            const float* src = a.w_hh + (size_t)(q * H + j0 + 16 * bl) * H + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + 32 * ks), v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split3r(x[e], hi[e], mid[e], lo[e]);
+                wf[q][bl][ks][0] = make_uint4(pack_hi16r(hi[0], hi[1]), pack_hi16r(hi[2], hi[3]), pack_hi16r(hi[4], hi[5]), pack_hi16r(hi[6], hi[7]));
+                wf[q][bl][ks][1] = make_uint4(pack_hi16r(mid[0], mid[1]), pack_hi16r(mid[2], mid[3]), pack_hi16r(mid[4], mid[5]), pack_hi16r(mid[6], mid[7]));
+                wf[q][bl][ks][2] = make_uint4(pack_hi16r(lo[0], lo[1]), pack_hi16r(lo[2], lo[3]), pack_hi16r(lo[4], lo[5]), pack_hi16r(lo[6], lo[7]));
+            }
+            bh[q][bl] = a.b_hh[q * H + j0 + 16 * bl];
+            __builtin_amdgcn_sched_barrier(0);                // one row at a time: all rows' raw loads in flight at once would not fit beside the fragments
+        }
+    float hprev[NB][4], cprev[NB][4];
+#pragma unroll
+    for (int bl = 0; bl < NB; ++bl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { hprev[bl][r] = 0.0f; cprev[bl][r] = 0.0f; }
+    const unsigned char* arow = smem_r + (size_t)(n * LDP + 8 * g) * 2;          // A fragment: clip n, k = 32 ks + 8 g .. + 7
+    constexpr int PLANE = 16 * LDP * 2;                                           // bytes per term plane
+    // input-side pre-activations (independent of h) are requested PF steps ahead: with the products on the bf16 pipe a step is
+    // shorter than the trip of a row per clip from HBM
+    constexpr int PF = (G == 4 && H == 128) ? 0 : 2;      // (the LSTM at H = 128 holds 384 registers of weight fragments: no room)
+    float xpf[PF + 1][G][NB][4];                              // [0]: this step's
+    auto fetch = [&](int step, float (&x)[G][NB][4]) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 4 * g + r;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * G * H + j0;
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int bl = 0; bl < NB; ++bl) x[q][bl][r] = xg[q * H + 16 * bl];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (d < a.steps) fetch(d, xpf[d]);
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        f32x4 acc[G][NB];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int bl = 0; bl < NB; ++bl) acc[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step + PF < a.steps) fetch(step + PF, xpf[PF]);
+        {                                                     // (first step: the planes hold zeros)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + 64 * ks), am = *reinterpret_cast<const bf16x8*>(arow + PLANE + 64 * ks),
+                             al = *reinterpret_cast<const bf16x8*>(arow + 2 * PLANE + 64 * ks);
+                // small terms first, the dominant hi*hi last (gemm_x3.hip's order); every product feeds all of the wave's accumulators
+#define RNN_PROD(AF, WT)                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < G; ++q)                                                                     \
+        _Pragma("unroll") for (int bl = 0; bl < NB; ++bl)                                                             \
+            acc[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF, __builtin_bit_cast(bf16x8, wf[q][bl][ks][WT]), acc[q][bl], 0, 0, 0);
+                if (NP == 9) { RNN_PROD(al, 2) RNN_PROD(al, 1) RNN_PROD(am, 2) }
+                RNN_PROD(am, 1) RNN_PROD(ah, 2) RNN_PROD(al, 0) RNN_PROD(ah, 1) RNN_PROD(am, 0) RNN_PROD(ah, 0)
+#undef RNN_PROD
+            }
+        }
+        __syncthreads();                                      // every wave has finished reading the h planes
+#pragma unroll
+        for (int bl = 0; bl < NB; ++bl) {
+            const int j = j0 + 16 * bl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * g + r, b = b0 + c;
+                // rows beyond B repeat the last clip (clamped xg row): straight-line gate arithmetic, only the stores are predicated
+                float hn, cn = 0.0f;
+                if (G == 3) {
+                    const float rg = sigmoid_r(xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
+                    const float zg = sigmoid_r(xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
+                    const float ng = tanh_r(xpf[0][2][bl][r] + rg * (acc[2][bl][r] + bh[2][bl]));
+                    hn = (1.0f - zg) * ng + zg * hprev[bl][r];
+                } else {
+                    const float ig = sigmoid_r(xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
+                    const float fg = sigmoid_r(xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
+                    const float gg = tanh_r(xpf[0][2][bl][r] + acc[2][bl][r] + bh[2][bl]);
+                    const float og = sigmoid_r(xpf[0][G - 1][bl][r] + acc[G - 1][bl][r] + bh[G - 1][bl]);
+                    cn = fg * cprev[bl][r] + ig * gg;
+                    hn = og * tanh_r(cn);
+                }
+                if (b < a.B) {
+                    if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                    if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+                }
+                hprev[bl][r] = hn; cprev[bl][r] = cn;
+                uint32_t hi, mid, lo;
+                split3r(hn, hi, mid, lo);
+                uint16_t* d = hp + c * LDP + j;
+                d[0] = (uint16_t)(hi >> 16); d[16 * LDP] = (uint16_t)(mid >> 16); d[2 * 16 * LDP] = (uint16_t)(lo >> 16);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < PF; ++d)
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int bl = 0; bl < NB; ++bl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xpf[d][q][bl][r] = xpf[d + 1][q][bl][r];
+        __syncthreads();
+    }
+}
+}  // namespace
+
+bool rnn_x3_usable(const GruArgs& a) {
+    return (a.products == 6 || a.products == 9) && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0;
+}
+
+hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
+    if (!rnn_x3_usable(a) || (gates != 3 && gates != 4)) return hipErrorInvalidValue;
+    const dim3 grid((a.B + 15) / 16), block(a.H == 128 ? 256 : 64 * (a.H / 16));
+    const size_t lds = (size_t)3 * 16 * (a.H + 8) * sizeof(uint16_t);
+#define RNN_GO(GV, HV)                                                                                                \
+    if (a.products == 9) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 9, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a);  \
+    else hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 6, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a);
+#define RNN_H(GV)                                                                                                     \
+    switch (a.H) {                                                                                                    \
+        case 32: RNN_GO(GV, 32) break;                                                                                \
+        case 64: RNN_GO(GV, 64) break;                                                                                \
+        default: RNN_GO(GV, 128) break;                                                                               \
+    }
+    if (gates == 3) { RNN_H(3) } else { RNN_H(4) }
+#undef RNN_H
+#undef RNN_GO
+    return hipGetLastError();
+}

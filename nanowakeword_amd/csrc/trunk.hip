@@ -582,8 +582,9 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, Wp0 = W + 2;
     const int in_f = ((H + 2) * Wp0 + 3) & ~3;
-    float* In = lds;
-    float* P = lds + in_f;                                     // [strip conv rows][W1][32]
+    float* Wd = lds;                                           // depthwise weights, tap-major [9][32]
+    float* In = lds + 288;
+    float* P = In + in_f;                                      // [strip conv rows][W1][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < in_f; k += NTHR) In[k] = 0.0f;
     const int i1 = lane & 15, g1 = lane >> 4;
@@ -607,11 +608,11 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
     const int nX1 = (2 * W1 + 7) / 8, ngx = (nX1 + 3) / 4;
     const int pix_off = ((i1 >> 1) & 1) * Wp0 + 2 * (i1 >> 2) + (i1 & 1);
     const int Ho = a.Ho, Wo = a.Wo, sh = a.sh, sw = a.sw;
-    // depthwise: thread -> (channel c, output column slot); the nine weights of the channel stay in registers
-    const int dc = tid & 31, dslot = tid >> 5;                 // NTHR / 32 column slots
-    float dwt[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dwt[k] = a.dw_wt[k * 32 + dc];
+    // depthwise: thread -> (four channels 4 cq .. 4 cq + 3, output slot); P and the weights (LDS: 36 registers more would cost
+    // the second workgroup of the CU) are read 16 bytes at a time - 18 LDS reads and one index computation per four outputs
+    // instead of 9 and one per output
+    const int cq = tid & 7, dslot = tid >> 3;                  // NTHR / 8 output slots
+    for (int k = tid; k < 288; k += NTHR) Wd[k] = a.dw_wt[k];
     const bool vec_in = (W & 3) == 0 && H * W <= 16 * NTHR;
     auto load_sync = [&](const float* xin) {
         for (int idx = tid; idx < H * W; idx += NTHR) {
@@ -624,18 +625,21 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
     __syncthreads();
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int bnext = b + gridDim.x;
-        float4 pre[4];
         const bool fetch = bnext < a.B;
-        if (fetch && vec_in) {
-            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx4 = tid + q * NTHR;
-                if (idx4 < H * W / 4) pre[q] = xin4[idx4];
-            }
-        }
         for (int oy0 = 0; oy0 < Ho; oy0 += a.rows_dw) {
             const int oy1 = min(Ho, oy0 + a.rows_dw);                              // depthwise rows [oy0, oy1)
+            // the next clip's plane travels in registers during the LAST strip's convolution only (after it nobody reads In):
+            // sixteen registers live through the depthwise phase would cost the CU's second workgroup
+            float4 pre[4];
+            const bool prefetch = fetch && vec_in && oy1 >= Ho;
+            if (prefetch) {
+                const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)bnext * H * W);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx4 = tid + q * NTHR;
+                    if (idx4 < H * W / 4) pre[q] = xin4[idx4];
+                }
+            }
             const int r_lo = max(0, sh * oy0 - 1), r_hi = min(H1 - 1, sh * (oy1 - 1) + 1);   // conv (pooled) rows kept in P
             // ---- conv + BN + act + pool of rows r_lo .. r_hi -> P
             const int nG = (r_hi - r_lo + 1) * ngx;
@@ -667,12 +671,24 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
                         float* dst = P + ((size_t)Rl * W1 + col) * 32 + i1;
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb) {
-                            float m = -INFINITY;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float v = acc[cb][u][q] + bias[cb];
+                            float m;
+                            if (ACT == ACT_RELU) {
+                                // bias + BN affine + ReLU is monotone in the accumulator (rising for alpha >= 0, falling below): the
+                                // window's max or min goes through it ONCE - 8 instead of 16 operations, bit-identical (trunk_b.hip)
+                                const f32x4 c4 = acc[cb][u];
+                                const float mx = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
+                                const float mn = fminf(fminf(c4[0], c4[1]), fminf(c4[2], c4[3]));
+                                float v = ((bn && al[cb] < 0.0f) ? mn : mx) + bias[cb];
                                 if (bn) v = v * al[cb] + be[cb];
-                                m = fmaxf(m, trunk_act<ACT>(v));
+                                m = fmaxf(v, 0.0f);
+                            } else {
+                                m = -INFINITY;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    float v = acc[cb][u][q] + bias[cb];
+                                    if (bn) v = v * al[cb] + be[cb];
+                                    m = fmaxf(m, trunk_act<ACT>(v));
+                                }
                             }
                             dst[16 * cb] = m;
                         }
@@ -680,37 +696,7 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
                 }
             }
             __syncthreads();
-            // ---- depthwise 3x3 of the strip's rows out of P
-            float* db = a.d_out + (size_t)b * Ho * Wo * 32;
-            float* xb = a.xs_out + (size_t)b * Ho * Wo * 32;
-            for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 32) {
-                const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
-                float acc = 0.0f, centre = 0.0f;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int yy = oy * sh - 1 + dy;
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int xx = ox * sw - 1 + dx;
-                        const bool ok = yy >= 0 && yy < H1 && xx >= 0 && xx < W1;
-                        const float v = ok ? P[((size_t)(yy - r_lo) * W1 + xx) * 32 + dc] : 0.0f;
-                        if (dy == 1 && dx == 1) centre = v;
-                        acc = fmaf(v, dwt[dy * 3 + dx], acc);
-                    }
-                }
-                const size_t oi = ((size_t)oy * Wo + ox) * 32 + dc;
-                if (a.bf16_out) {                         // wave-uniform: bf16 activations (round to nearest even)
-                    reinterpret_cast<__bf16*>(a.d_out)[(size_t)b * Ho * Wo * 32 + oi] = (__bf16)acc;
-                    reinterpret_cast<__bf16*>(a.xs_out)[(size_t)b * Ho * Wo * 32 + oi] = (__bf16)centre;
-                } else {
-                    db[oi] = acc;
-                    xb[oi] = centre;
-                }
-            }
-            __syncthreads();
-        }
-        if (fetch) {
-            if (vec_in) {
+            if (prefetch) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int idx4 = tid + q * NTHR;
@@ -720,10 +706,41 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
                         d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
                     }
                 }
-            } else {
-                load_sync(a.in + (size_t)bnext * H * W);
             }
+            // ---- depthwise 3x3 of the strip's rows out of P
+            for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 8) {
+                const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), centre = acc;
+#pragma unroll 1
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = oy * sh - 1 + dy;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int xx = ox * sw - 1 + dx;
+                        const bool ok = yy >= 0 && yy < H1 && xx >= 0 && xx < W1;
+                        const float4 v = ok ? *reinterpret_cast<const float4*>(P + ((size_t)(yy - r_lo) * W1 + xx) * 32 + 4 * cq)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (dy == 1 && dx == 1) centre = v;
+                        const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cq);
+                        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
+                        acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+                    }
+                }
+                const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cq;
+                if (a.bf16_out) {                         // wave-uniform: bf16 activations (round to nearest even)
+                    union { __bf16 h[4]; uint2 u; } pd, px;
+                    pd.h[0] = (__bf16)acc.x; pd.h[1] = (__bf16)acc.y; pd.h[2] = (__bf16)acc.z; pd.h[3] = (__bf16)acc.w;
+                    px.h[0] = (__bf16)centre.x; px.h[1] = (__bf16)centre.y; px.h[2] = (__bf16)centre.z; px.h[3] = (__bf16)centre.w;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.d_out) + oi) = pd.u;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.xs_out) + oi) = px.u;
+                } else {
+                    *reinterpret_cast<float4*>(a.d_out + oi) = acc;
+                    *reinterpret_cast<float4*>(a.xs_out + oi) = centre;
+                }
+            }
+            __syncthreads();
         }
+        if (fetch && !vec_in) load_sync(a.in + (size_t)bnext * H * W);
         __syncthreads();
     }
 }
@@ -734,7 +751,7 @@ static int front_lds_kb() { return 80; }
 // depthwise rows per strip such that input plane + strip planes fit LDS; 0 = does not fit
 int conv1_pool_dw_rows(int H, int W, int sh) {
     const int H1 = H / 2, W1 = W / 2, Ho = (H1 - 1) / sh + 1;
-    const size_t in_b = ((((size_t)(H + 2) * (W + 2) + 3) & ~(size_t)3) + 16) * sizeof(float);
+    const size_t in_b = ((((size_t)(H + 2) * (W + 2) + 3) & ~(size_t)3) + 16 + 288) * sizeof(float);
     if (H < 4 || W < 4) return 0;
     for (int strips = 1; strips <= Ho; ++strips) {
         const int rows = (Ho + strips - 1) / strips;
@@ -751,7 +768,7 @@ hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a0, int max_grid, hipStr
     const int H1 = a.H / 2, W1 = a.W / 2;
     a.Ho = (H1 - 1) / a.sh + 1; a.Wo = (W1 - 1) / a.sw + 1;
     const size_t in_f = (((size_t)(a.H + 2) * (a.W + 2) + 3) & ~(size_t)3);
-    const size_t lds = (in_f + ((size_t)a.sh * (a.rows_dw - 1) + 3) * W1 * 32 + 16) * sizeof(float);
+    const size_t lds = (288 + in_f + ((size_t)a.sh * (a.rows_dw - 1) + 3) * W1 * 32 + 16) * sizeof(float);
     const int per_cu = front_lds_kb() <= 80 ? 2 : 1;
     int grid = a.B < max_grid * per_cu ? a.B : max_grid * per_cu;
     if (grid < 1) grid = 1;

@@ -252,6 +252,30 @@ def test_capi_gather_two_ranks():
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
+def test_recurrent_kernels_every_size_and_arithmetic(HipModel):
+    """rnn_x3.hip (split-operand recurrent product, H = 32 / 64 / 128, 6 and 9 partial products) and the float32-MFMA
+    recurrences behind conv_arith = f32, GRU head (T = 30 steps, two directions) and CRNN with the LSTM backend, against the
+    oracle; batches that leave the last 16-clip workgroup ragged.  Each arithmetic is batch invariant."""
+    worst = 0.0
+    for H in (32, 64, 128):
+        for cfg in (HeadConfig("gru", (30, 64), layer_dim=H), HeadConfig("crnn", (16, 96), layer_dim=H, crnn_rnn_type="lstm"),
+                    HeadConfig("crnn", (32, 64), layer_dim=H)):
+            sd = synth_state_dict(cfg)
+            x = synth_features(37, cfg.input_shape, seed=H)
+            want = oracle.model_forward(x, sd, cfg).ravel()
+            for arith in (None, "f32", "bf16x9"):
+                m = HipModel(cfg, FrontendConfig(), state_dict=sd, **({"conv_arith": arith} if arith else {}))
+                names = m.describe_plan()
+                assert ("gru:" in names) or ("lstm:" in names), names
+                lg, _ = m.forward_features(x)
+                worst = max(worst, float(np.abs(lg - want).max()))
+                assert np.abs(lg - want).max() <= 1e-4, (H, cfg.model_type, arith, float(np.abs(lg - want).max()))
+                l5, _ = m.forward_features(x[:5])
+                assert np.array_equal(l5, lg[:5]), (H, cfg.model_type, arith)
+                m.close()
+    print("worst |dlogit| over recurrent instances:", worst)
+
+
 def test_wide_recurrent_layers_are_refused_loudly(HipModel):
     """layer_dim in (256, 512] has no compiled recurrent kernel: nww_create must say so (not fail at the first launch)."""
     for mt in ("gru", "crnn"):

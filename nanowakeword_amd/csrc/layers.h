@@ -116,10 +116,14 @@ struct GruArgs {
     float* seq_out; int ld_seq; float* last_out; int ld_last; int col_off;
     int B, T, H, reverse, steps;
     int products = 0;      // 6 / 9: recurrent product from split operands on the bf16 matrix cores (rnn_x3.hip), 0: float32 MFMA
+    // rnn_x3 only: the FIRST step of the opposite direction (all that rnn_out[:, -1] needs of it; h = 0, so no recurrent product)
+    // computed in the same launch from its gate pre-activations xg2 [B][xg2_bstride] and recurrent bias -> last_out[:, col_off2 + j]
+    const float* xg2 = nullptr; size_t xg2_bstride = 0; const float* b_hh2 = nullptr; int col_off2 = 0;
 };
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
 // rnn_x3.hip: gates = 3 (GRU) / 4 (LSTM), H in {32, 64, 128}
 bool rnn_x3_usable(const GruArgs& a);
+bool rnn_x3_enabled(const GruArgs& a);   // ... and not switched off (NWW_GRU16 = 0)
 hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s);
 // LSTM recurrence for one direction, same arguments (xg is [B][T][4H], gate order i, f, g, o)
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s);

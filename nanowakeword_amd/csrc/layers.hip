@@ -1343,10 +1343,17 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
     }
 }
 
+// the split-operand recurrence serves this layer (plan time: the plan folds the reverse direction's single step into it)
+bool rnn_x3_enabled(const GruArgs& a) {
+    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    return use16 && rnn_x3_usable(a);
+}
+
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
-    if (use16 && rnn_x3_usable(a)) return launch_rnn_x3(a, 4, s);
+    if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 4, s);
+    if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
         const dim3 grid((a.B + 15) / 16);
@@ -1370,7 +1377,8 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
-    if (use16 && rnn_x3_usable(a)) return launch_rnn_x3(a, 3, s);
+    if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 3, s);
+    if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
         const size_t lds16 = (size_t)16 * (a.H + 4) * sizeof(float);
         const dim3 grid((a.B + 15) / 16);

@@ -601,13 +601,20 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
 // xg_id, seqA, seqB.
 void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int I, int H, int layers, int xg_id,
                     int seqA, int seqB, int last_id, int G = 3) {
-    p.need(xg_id, (size_t)T * G * H);
+    p.need(xg_id, (size_t)(T + 1) * G * H);                  // + one row per clip: the reverse direction's last-frame projection
     p.need(last_id, (size_t)2 * H);
+    const int products = p.h->conv_products;                 // the recurrent product follows the handle's arithmetic switch
+    GruArgs probe; probe.H = H; probe.products = products; probe.w_hh = nullptr;
+    const bool x3 = rnn_x3_enabled(probe);                    // (weights come from hipMalloc: 16-byte aligned)
     int cur_in = in_id, cur_I = I;
     for (int l = 0; l < layers; ++l) {
         const bool last = l == layers - 1;
         const int seq_out = (l % 2 == 0) ? seqA : seqB;
         if (!last) p.need(seq_out, (size_t)T * 2 * H);
+        // rnn_out[:, -1] needs ONE step of the last layer's reverse direction, hence the input projection of frame T-1 only (a
+        // strided GEMM over M = B rows instead of B*T, into the row behind the forward direction's xg) - and with h = 0 that
+        // step has no recurrent product: rnn_x3 computes it in the forward direction's launch.
+        const bool fold = last && x3;
         for (int dir = 0; dir < 2; ++dir) {
             const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
             const float* wih = p.W(prefix + ".weight_ih" + sfx);
@@ -615,13 +622,12 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
             const float* bih = p.W(prefix + ".bias_ih" + sfx);
             const float* bhh = p.W(prefix + ".bias_hh" + sfx);
             if (last && dir) {
-                // rnn_out[:, -1] needs ONE step of the reverse direction, hence the input projection of frame T-1 only:
-                // a strided GEMM over M = B rows instead of B*T
                 const int Iin = cur_I, in_buf = cur_in;
                 p.add("gemm:" + prefix + ".ih" + sfx + "(last frame)", [=](Run& r) {
                     GemmArgs g;
                     g.A = src(r, in_buf) + (size_t)(T - 1) * Iin; g.lda = T * Iin; g.W = wih;
-                    g.C = r.buf[xg_id] + (size_t)(T - 1) * G * H; g.ldc = T * G * H;
+                    if (fold) { g.C = r.buf[xg_id] + (size_t)r.B * T * G * H; g.ldc = G * H; }      // behind the forward direction's rows
+                    else { g.C = r.buf[xg_id] + (size_t)(T - 1) * G * H; g.ldc = T * G * H; }       // in place (the forward recurrence is done)
                     g.M = r.B; g.N = G * H; g.K = Iin; g.bias = bih; g.alpha = nullptr; g.beta = nullptr; g.act = ACT_NONE;
                     g.res = nullptr; g.ldres = 0; g.rscale = 1.f;
                     return launch_gemm(g, r.stream);
@@ -629,16 +635,26 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
             } else {
                 add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
             }
+            if (fold && dir == 0) continue;                  // the forward recurrence is launched after the reverse projection
             const int in_T = T;
-            const int products = p.h->conv_products;          // the recurrent product follows the handle's arithmetic switch
-            p.add((G == 4 ? "lstm:" : "gru:") + prefix + sfx, [=](Run& r) {
+            const float* whh_f = fold ? p.W(prefix + ".weight_hh_l" + std::to_string(l)) : whh;
+            const float* bhh_f = fold ? p.W(prefix + ".bias_hh_l" + std::to_string(l)) : bhh;
+            const std::string nm = fold ? (G == 4 ? "lstm:" : "gru:") + prefix + "_l" + std::to_string(l) + " + first reverse step"
+                                        : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
+            p.add(nm, [=](Run& r) {
                 GruArgs a;
                 a.products = products;
-                a.xg = r.buf[xg_id]; a.w_hh = whh; a.b_hh = bhh;
+                a.xg = r.buf[xg_id]; a.w_hh = whh_f; a.b_hh = bhh_f;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
-                a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H; a.col_off = dir ? H : 0;
-                a.B = r.B; a.T = in_T; a.H = H; a.reverse = dir;
-                a.steps = (last && dir) ? 1 : in_T;          // reverse half of rnn_out[:, -1] is its first step
+                a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H;
+                a.B = r.B; a.T = in_T; a.H = H;
+                if (fold) {
+                    a.col_off = 0; a.reverse = 0; a.steps = in_T;
+                    a.xg2 = r.buf[xg_id] + (size_t)r.B * in_T * G * H; a.xg2_bstride = (size_t)G * H; a.b_hh2 = bhh; a.col_off2 = H;
+                } else {
+                    a.col_off = dir ? H : 0; a.reverse = dir;
+                    a.steps = (last && dir) ? 1 : in_T;      // reverse half of rnn_out[:, -1] is its first step
+                }
                 return G == 4 ? launch_lstm(a, r.stream) : launch_gru(a, r.stream);
             });
         }

@@ -141,7 +141,25 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 }
                 if (b < a.B) {
                     if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
-                    if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+                    if (a.last_out && step == a.steps - 1) {
+                        a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+                        if (a.xg2) {          // the opposite direction's first step: h = c = 0, the recurrent product vanishes
+                            const float* x2 = a.xg2 + (size_t)b * a.xg2_bstride + j;
+                            float h2;
+                            if (G == 3) {
+                                const float rg = sigmoid_r(x2[0] + a.b_hh2[j]);
+                                const float zg = sigmoid_r(x2[H] + a.b_hh2[H + j]);
+                                const float ng = tanh_r(x2[2 * H] + rg * a.b_hh2[2 * H + j]);
+                                h2 = (1.0f - zg) * ng;
+                            } else {
+                                const float ig = sigmoid_r(x2[0] + a.b_hh2[j]);
+                                const float gg = tanh_r(x2[2 * H] + a.b_hh2[2 * H + j]);
+                                const float og = sigmoid_r(x2[(G - 1) * H] + a.b_hh2[(G - 1) * H + j]);
+                                h2 = og * tanh_r(ig * gg);
+                            }
+                            a.last_out[(size_t)b * a.ld_last + a.col_off2 + j] = h2;
+                        }
+                    }
                 }
                 hprev[bl][r] = hn; cprev[bl][r] = cn;
                 uint32_t hi, mid, lo;

@@ -10,7 +10,7 @@ from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_pcm, synth_state_dict
 
 dev = torch.device("cuda", 0)
-for name, cfg in (("cnn (first in process)", HeadConfig("cnn", (101, 64))), ("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("dnn", HeadConfig("dnn", (101, 64)))):
+for name, cfg in (("cnn (first in process)", HeadConfig("cnn", (101, 64))), ("cnn", HeadConfig("cnn", (101, 64))), ("e2e_dnn", HeadConfig("e2e_dnn", (64, 101))), ("dnn", HeadConfig("dnn", (101, 64))), ("crnn", HeadConfig("crnn", (101, 64))), ("gru", HeadConfig("gru", (101, 64)))):
     m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
     for B in (1, 16):
         pcm = synth_pcm("noise", B, 16000, seed=3)

@@ -693,20 +693,57 @@ mean_mid_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ out, int
     const size_t b = idx / D8, d8 = idx - b * D8;
     const __bf16* p = in + b * (size_t)L * D + 8 * d8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < L; ++l) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)l * D);
+    auto add_row = [&](const uint4 v) {
         const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(u[e] << 16); s[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+    };
+    int l = 0;
+    for (; l + 8 <= L; l += 8) {                                    // eight rows in flight, added in ascending l
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const uint4*>(p + (size_t)(l + q) * D);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) add_row(v[q]);
     }
+    for (; l < L; ++l) add_row(*reinterpret_cast<const uint4*>(p + (size_t)l * D));
     float* o = out + b * D + 8 * d8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = s[e] / (float)L;
+}
+// float32 rows: a thread owns four channels (16-byte loads, eight rows in flight); per channel the same ascending-l sum
+__global__ void __launch_bounds__(256)
+mean_mid_f32x4_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*(D/4) + d4
+    if (idx >= total4) return;
+    const int D4 = D / 4;
+    const size_t b = idx / D4, d4 = idx - b * D4;
+    const float* p = in + b * (size_t)L * D + 4 * d4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int l = 0;
+    for (; l + 8 <= L; l += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(l + u) * D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; l < L; ++l) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)l * D);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float fl = (float)L;
+    *reinterpret_cast<float4*>(out + b * D + 4 * d4) = make_float4(s.x / fl, s.y / fl, s.z / fl, s.w / fl);
 }
 hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, bool bf16) {
     if (bf16 && D % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
         const size_t total8 = (size_t)B * (D / 8);
         hipLaunchKernelGGL(mean_mid_bf16_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), out, L, D, total8);
+        return hipGetLastError();
+    }
+    if (!bf16 && D % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const size_t total4 = (size_t)B * (D / 4);
+        hipLaunchKernelGGL(mean_mid_f32x4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out, L, D, total4);
         return hipGetLastError();
     }
     const size_t total = (size_t)B * D;

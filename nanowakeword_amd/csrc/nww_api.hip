@@ -882,9 +882,22 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const int ho1 = (T / 2 - 1) / 2 + 1, wo1 = (F / 2 - 1) / 2 + 1;
                 p.need(2, (size_t)32 * ho1 * wo1); p.need(3, (size_t)32 * ho1 * wo1);
                 const int max_grid = p.h->cu_count;
-                p.add(std::string("conv1_dw_mfma:init_conv + block1.depthwise (nhwc") + (act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
+                // the convolution from split operands on the bf16 matrix cores (trunk_b.hip) under the handle's arithmetic switch;
+                // NWW_BC_FRONT = 2 keeps the float32-MFMA kernel
+                void* fpack = nullptr;
+                const int fprod = p.h->conv_products;
+                if ((fprod == 6 || fprod == 9) && bc_front != 2 && bc_front_b_rows(T, F, 2) > 0 &&
+                    hipMalloc(&fpack, bc_front_b_packed_bytes()) == hipSuccess) {
+                    if (launch_bc_front_b_pack(w0, static_cast<unsigned char*>(fpack), p.h->own_stream) == hipSuccess) p.h->packed_weights.push_back(fpack);
+                    else { (void)hipFree(fpack); fpack = nullptr; }
+                }
+                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
                     a.bf16_out = act_bf16 ? 1 : 0;
+                    if (fpack) {
+                        a.wpack = static_cast<const unsigned char*>(fpack);
+                        return launch_bc_front_b(a, fprod, max_grid, r.stream);
+                    }
                     return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);
                 });
             } else if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {

@@ -75,7 +75,13 @@ struct Conv1DwArgs {
     int B, H, W, act, sh, sw;
     int Ho = 0, Wo = 0, rows_dw = 0; // filled by the launcher
     int bf16_out = 0;                // d_out / xs_out are bf16 arrays (nww_config.act_dtype = NWW_ACT_DTYPE_BF16)
+    const unsigned char* wpack = nullptr;   // launch_bc_front_b only: conv weight fragments (launch_bc_front_b_pack)
 };
+// the same stage with the convolution from split operands on the bf16 matrix cores (trunk_b.hip); products = 6 / 9
+size_t bc_front_b_packed_bytes();
+hipError_t launch_bc_front_b_pack(const float* w1, unsigned char* packed, hipStream_t s);
+int bc_front_b_rows(int H, int W, int sh);         // depthwise rows per LDS strip, 0 = does not fit
+hipError_t launch_bc_front_b(const Conv1DwArgs& a, int products, int max_grid, hipStream_t s);
 int conv1_pool_dw_rows(int H, int W, int sh);      // depthwise rows per LDS strip, 0 = does not fit
 hipError_t launch_conv1_pool_dw_nhwc(const Conv1DwArgs& a, int max_grid, hipStream_t s);
 hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hipStream_t s);

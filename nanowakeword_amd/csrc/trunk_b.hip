@@ -483,6 +483,239 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     TB_STAMP_WG(2);
 }
 
+
+// ---------------------------------------------------------------------------------------------- BcResNet front
+// Conv2d(1,32,3,p1) + BN + act + MaxPool2 fused with block 1's depthwise 3x3 (architectures.py:632-647, 653-660), the
+// convolution as the transposed split-operand product above, twice (channels 0-15 / 16-31 = two weight sets).  The
+// float32-MFMA version (trunk.hip: conv1_pool_dw_nhwc_kernel) spends 24 x 32 matrix-pipe clocks per 16 pooled pixels AND
+// blocks the SIMD's VALU while it does; here 32 pooled pixels cost 24 x 32, and the pooling of other waves runs beside them.
+// A workgroup walks clips; a clip is cut into strips of rows_dw depthwise rows: the strip's input rows (three bf16 planes,
+// a float4 per thread, in flight during the previous strip's convolution) -> conv tasks (conv row, 32 pixels, weight set:
+// a wave keeps ONE set for the whole launch) -> P [rows][W1][32] float32 in LDS -> depthwise out of P, four channels per
+// thread.  80 KB of LDS and <= 128 registers: two workgroups per CU, one's MFMAs under the other's depthwise phase.
+struct BfGeom { int Wp0, pitch0, max_conv, max_in, plane_b; };
+__host__ __device__ inline BfGeom bf_geom(int W, int sh, int rows_dw) {
+    BfGeom g;
+    g.Wp0 = (W + 3) & ~1;
+    g.pitch0 = 2 * g.Wp0;
+    g.max_conv = sh * (rows_dw - 1) + 3;
+    g.max_in = 2 * g.max_conv + 2;
+    g.plane_b = (g.max_in * g.pitch0 + 15) & ~15;
+    return g;
+}
+constexpr int BF_HEAD = 1536;                 // depthwise weights [9][32] + bias / alpha / beta [3][32], floats
+constexpr int BF_W1F = 12 * 1024;             // conv weight fragments [set][dy][term][64 lanes] x 16 bytes
+
+__global__ void __launch_bounds__(64) bc_front_pack_kernel(const float* __restrict__ w1, unsigned char* __restrict__ out) {
+    const int lane = threadIdx.x, m = lane & 31, hi = lane >> 5;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out);
+    const int cw = 8 * ((m >> 2) & 1) + 2 * (m >> 3) + ((m >> 1) & 1), dxw = m & 1;      // trunk_b_pack_kernel's row map
+    for (int set = 0; set < 2; ++set)
+        for (int dy = 0; dy < 2; ++dy) {
+            uint32_t th[8], tm[8], tl[8];
+            for (int kk = 0; kk < 8; ++kk) {
+                const int ty = 2 * hi + (kk >> 2) - dy, tx = (kk & 3) - dxw;
+                const bool in = ty >= 0 && ty < 3 && tx >= 0 && tx < 3;
+                split3(in ? w1[(16 * set + cw) * 9 + ty * 3 + tx] : 0.0f, th[kk], tm[kk], tl[kk]);
+            }
+            const int f = (set * 2 + dy) * 3;
+            o[(f + 0) * 64 + lane] = frag4(pack_hi16(th[0], th[1]), pack_hi16(th[2], th[3]), pack_hi16(th[4], th[5]), pack_hi16(th[6], th[7]));
+            o[(f + 1) * 64 + lane] = frag4(pack_hi16(tm[0], tm[1]), pack_hi16(tm[2], tm[3]), pack_hi16(tm[4], tm[5]), pack_hi16(tm[6], tm[7]));
+            o[(f + 2) * 64 + lane] = frag4(pack_hi16(tl[0], tl[1]), pack_hi16(tl[2], tl[3]), pack_hi16(tl[4], tl[5]), pack_hi16(tl[6], tl[7]));
+        }
+}
+
+template <int ACT, int PRODUCTS, bool BN>
+__global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2;
+    const int Ho = a.Ho, Wo = a.Wo, sh = a.sh, sw = a.sw;
+    const BfGeom gg = bf_geom(W, sh, a.rows_dw);
+    const int Wp0 = gg.Wp0, pitch0 = gg.pitch0, plane_b = gg.plane_b;
+    float* const Wd = reinterpret_cast<float*>(lds_raw);
+    float* const BNp = Wd + 288;
+    unsigned char* const W1F = lds_raw + BF_HEAD;
+    unsigned char* const In3 = W1F + BF_W1F;
+    float* const P = reinterpret_cast<float*>(In3 + 3 * plane_b);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+
+    for (int k = tid; k < 3 * plane_b / 4; k += NTHR) reinterpret_cast<uint32_t*>(In3)[k] = 0u;       // halo columns stay zero
+    for (int k = tid; k < 288; k += NTHR) Wd[k] = a.dw_wt[k];
+    if (tid < 32) {
+        BNp[tid] = a.bias ? a.bias[tid] : 0.0f;
+        BNp[32 + tid] = (BN && a.alpha) ? a.alpha[tid] : 1.0f;
+        BNp[64 + tid] = (BN && a.alpha) ? a.beta[tid] : 0.0f;
+    }
+    for (int k = tid; k < BF_W1F / 16; k += NTHR) reinterpret_cast<uint4*>(W1F)[k] = reinterpret_cast<const uint4*>(a.wpack)[k];
+    __syncthreads();
+    // this wave's weight set (tasks wave, wave + 8, ... all have the wave's parity) stays in registers
+    const int set = wave & 1;
+    bf16x8 wf[2][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) wf[q / 3][q % 3] = *reinterpret_cast<const bf16x8*>(W1F + (set * 6 + q) * 1024 + lane * 16);
+
+    const int nstrips = (Ho + a.rows_dw - 1) / a.rows_dw;
+    const int ngx = (W1 + 31) / 32;
+    // strip geometry: depthwise rows [oy0, oy1), conv (pooled) rows [r_lo, r_hi], input rows from y0 = 2 r_lo - 1
+    auto strip_rows = [&](int sidx, int& oy0, int& oy1, int& r_lo, int& r_hi) {
+        oy0 = sidx * a.rows_dw; oy1 = min(Ho, oy0 + a.rows_dw);
+        r_lo = max(0, sh * oy0 - 1); r_hi = min(H1 - 1, sh * (oy1 - 1) + 1);
+    };
+    constexpr int NPRE = 2;
+    const bool vec_in = (W & 3) == 0 && gg.max_in * W <= 4 * NPRE * NTHR;
+    // input rows of a strip -> registers (out-of-range rows are zeros) / -> the three planes
+    auto fetch = [&](int b, int sidx, float4 (&pre)[NPRE]) {
+        int oy0, oy1, r_lo, r_hi;
+        strip_rows(sidx, oy0, oy1, r_lo, r_hi);
+        const int y0 = 2 * r_lo - 1, n4 = (2 * (r_hi - r_lo + 1) + 2) * W / 4;
+        const float* xin = a.in + (size_t)b * H * W;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int idx4 = tid + q * NTHR;
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx4 < n4) {
+                const int lr = (4 * idx4) / W, x = 4 * idx4 - lr * W, y = y0 + lr;
+                if (y >= 0 && y < H) pre[q] = *reinterpret_cast<const float4*>(xin + (size_t)y * W + x);
+            }
+        }
+    };
+    auto put = [&](int sidx, const float4 (&pre)[NPRE]) {
+        int oy0, oy1, r_lo, r_hi;
+        strip_rows(sidx, oy0, oy1, r_lo, r_hi);
+        const int n4 = (2 * (r_hi - r_lo + 1) + 2) * W / 4;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int idx4 = tid + q * NTHR;
+            if (idx4 < n4) {
+                const int lr = (4 * idx4) / W, x = 4 * idx4 - lr * W;
+                unsigned char* d = In3 + (lr * Wp0 + x + 1) * 2;
+                uint32_t w[3][4];
+                split3(pre[q].x, w[0][0], w[1][0], w[2][0]); split3(pre[q].y, w[0][1], w[1][1], w[2][1]);
+                split3(pre[q].z, w[0][2], w[1][2], w[2][2]); split3(pre[q].w, w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    unsigned char* p = d + t * plane_b;
+                    *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
+                    *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
+                    *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+                }
+            }
+        }
+    };
+    auto stage_sync = [&](int b, int sidx) {                   // generic shapes: no prefetch
+        int oy0, oy1, r_lo, r_hi;
+        strip_rows(sidx, oy0, oy1, r_lo, r_hi);
+        const int y0 = 2 * r_lo - 1, n = (2 * (r_hi - r_lo + 1) + 2) * W;
+        const float* xin = a.in + (size_t)b * H * W;
+        for (int idx = tid; idx < n; idx += NTHR) {
+            const int lr = idx / W, x = idx - lr * W, y = y0 + lr;
+            uint32_t wh, wm, wlo;
+            split3((y >= 0 && y < H) ? xin[(size_t)y * W + x] : 0.0f, wh, wm, wlo);
+            unsigned char* d = In3 + (lr * Wp0 + x + 1) * 2;
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
+            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
+            *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+        }
+    };
+    const int cq = tid & 7, dslot = tid >> 3;                  // depthwise: four channels 4 cq .., NTHR / 8 output slots
+
+    int b = blockIdx.x, sidx = 0;
+    if (b < a.B) {
+        if (vec_in) { float4 p0[NPRE]; fetch(b, 0, p0); put(0, p0); }
+        else stage_sync(b, 0);
+    }
+    __syncthreads();
+    while (b < a.B) {
+        int nb = b, ns = sidx + 1;
+        if (ns >= nstrips) { ns = 0; nb = b + gridDim.x; }
+        const bool has_next = nb < a.B;
+        float4 pre[NPRE];
+        if (has_next && vec_in) fetch(nb, ns, pre);
+        int oy0, oy1, r_lo, r_hi;
+        strip_rows(sidx, oy0, oy1, r_lo, r_hi);
+        // ---- conv + BN + act + pool of rows r_lo .. r_hi -> P
+        const int ntask = (r_hi - r_lo + 1) * ngx * 2;
+        for (int t = wave; t < ntask; t += NW) {
+            const int g = t >> 1, Rl = g / ngx, gx = g - Rl * ngx;
+            const int xc = min(32 * gx + i, W1 - 1);
+            const unsigned char* base = In3 + (2 * Rl + 2 * hi) * pitch0 + 4 * xc;
+            bf16x8 cf[3];
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(base + tt * plane_b);
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(base + tt * plane_b + pitch0);
+                cf[tt] = frag4(p[0], p[1], q[0], q[1]);
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            x3_mfma<PRODUCTS>(wf[0], cf, acc0);
+            x3_mfma<PRODUCTS>(wf[1], cf, acc1);
+            // pool_quad reads the accumulators (VGPRs in this kernel) from inline asm, which the compiler's hazard recogniser does
+            // not see as a VALU read of an MFMA result: without these wait states the first windows read acc1 before the last
+            // MFMA has written it (tools/ubench/front_cmp.hip caught it as sporadic wrong values in the first channels)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float4* bp = reinterpret_cast<const float4*>(BNp + 16 * set + 8 * hi);
+            const float4 b0v = bp[0], b1v = bp[1], a0v = bp[8], a1v = bp[9], e0v = bp[16], e1v = bp[17];
+            const float bs[8] = {b0v.x, b0v.y, b0v.z, b0v.w, b1v.x, b1v.y, b1v.z, b1v.w};
+            const float al[8] = {a0v.x, a0v.y, a0v.z, a0v.w, a1v.x, a1v.y, a1v.z, a1v.w};
+            const float be[8] = {e0v.x, e0v.y, e0v.z, e0v.w, e1v.x, e1v.y, e1v.z, e1v.w};
+            float m[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc]);
+            const int x = 32 * gx + i;
+            if (x < W1) {
+                float* dst = P + ((size_t)Rl * W1 + x) * 32 + 16 * set + 8 * hi;
+                *reinterpret_cast<float4*>(dst) = make_float4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(m[4], m[5], m[6], m[7]);
+            }
+        }
+        __syncthreads();
+        // the planes are free: the next strip's rows land while this strip's depthwise runs
+        if (has_next) {
+            if (vec_in) put(ns, pre);
+            else stage_sync(nb, ns);
+        }
+        // ---- depthwise 3x3 of the strip's rows out of P (taps in dwconv3x3_nhwc_kernel's order and fmaf chain)
+        for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 8) {
+            const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), centre = acc;
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = oy * sh - 1 + dy;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = ox * sw - 1 + dx;
+                    const bool ok = yy >= 0 && yy < H1 && xx >= 0 && xx < W1;
+                    const float4 v = ok ? *reinterpret_cast<const float4*>(P + ((size_t)(yy - r_lo) * W1 + xx) * 32 + 4 * cq)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (dy == 1 && dx == 1) centre = v;
+                    const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cq);
+                    acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
+                    acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+                }
+            }
+            const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cq;
+            if (a.bf16_out) {                             // wave-uniform: bf16 activations (round to nearest even)
+                union { __bf16 h[4]; uint2 u; } pd, px;
+                pd.h[0] = (__bf16)acc.x; pd.h[1] = (__bf16)acc.y; pd.h[2] = (__bf16)acc.z; pd.h[3] = (__bf16)acc.w;
+                px.h[0] = (__bf16)centre.x; px.h[1] = (__bf16)centre.y; px.h[2] = (__bf16)centre.z; px.h[3] = (__bf16)centre.w;
+                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.d_out) + oi) = pd.u;
+                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.xs_out) + oi) = px.u;
+            } else {
+                *reinterpret_cast<float4*>(a.d_out + oi) = acc;
+                *reinterpret_cast<float4*>(a.xs_out + oi) = centre;
+            }
+        }
+        __syncthreads();
+        b = nb; sidx = ns;
+    }
+}
 }  // namespace
 
 size_t trunk_b_packed_bytes() { return (size_t)NFRAG * 1024; }
@@ -576,3 +809,58 @@ hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hi
     return hipGetLastError();
 }
 
+
+// ---- BcResNet front on the bf16 matrix cores
+size_t bc_front_b_packed_bytes() { return BF_W1F; }
+hipError_t launch_bc_front_b_pack(const float* w1, unsigned char* packed, hipStream_t s) {
+    hipLaunchKernelGGL(bc_front_pack_kernel, dim3(1), dim3(64), 0, s, w1, packed);
+    return hipGetLastError();
+}
+static size_t bc_front_b_lds(int W, int sh, int rows_dw) {
+    const BfGeom g = bf_geom(W, sh, rows_dw);
+    return (size_t)BF_HEAD + BF_W1F + 3 * (size_t)g.plane_b + (size_t)g.max_conv * (W / 2) * 32 * sizeof(float) + 16;
+}
+// depthwise rows per strip such that two workgroups share a CU (80 KB each); 0 = does not fit
+int bc_front_b_rows(int H, int W, int sh) {
+    if (H < 4 || W < 4) return 0;
+    const int Ho = (H / 2 - 1) / sh + 1;
+    int best = 0;
+    for (int rows = 1; rows <= Ho; ++rows)
+        if (bc_front_b_lds(W, sh, rows) <= 80 * 1024) best = rows;
+    return best;
+}
+hipError_t launch_bc_front_b(const Conv1DwArgs& a0, int products, int max_grid, hipStream_t s) {
+    if (!a0.wpack || (products != 6 && products != 9)) return hipErrorInvalidValue;
+    Conv1DwArgs a = a0;
+    a.rows_dw = bc_front_b_rows(a.H, a.W, a.sh);
+    if (a.rows_dw <= 0) return hipErrorInvalidValue;
+    const int H1 = a.H / 2, W1 = a.W / 2;
+    a.Ho = (H1 - 1) / a.sh + 1; a.Wo = (W1 - 1) / a.sw + 1;
+    // even strips: the same number of strips, the last one not shorter than the others by more than a row
+    const int nstrips = (a.Ho + a.rows_dw - 1) / a.rows_dw;
+    a.rows_dw = (a.Ho + nstrips - 1) / nstrips;
+    const size_t lds = bc_front_b_lds(a.W, a.sh, a.rows_dw);
+    int grid = a.B < max_grid * 2 ? a.B : max_grid * 2;
+    if (grid < 1) grid = 1;
+    const bool bn = a.alpha != nullptr;
+#define BF_LAUNCH(ACTV, PRODV, BNV)                                                                                    \
+    {                                                                                                                  \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(bc_front_b_kernel<ACTV, PRODV, BNV>), lds);         \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL((bc_front_b_kernel<ACTV, PRODV, BNV>), dim3(grid), dim3(NTHR), lds, s, a);                  \
+    }
+#define BF_BN(ACTV, PRODV)                                                                                             \
+    if (bn) BF_LAUNCH(ACTV, PRODV, true) else BF_LAUNCH(ACTV, PRODV, false)
+#define BF_ACT(ACTV)                                                                                                   \
+    if (products == 6) BF_BN(ACTV, 6) else BF_BN(ACTV, 9)
+    switch (a.act) {
+        case ACT_RELU: BF_ACT(ACT_RELU) break;
+        case ACT_GELU: BF_ACT(ACT_GELU) break;
+        case ACT_SILU: BF_ACT(ACT_SILU) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef BF_LAUNCH
+#undef BF_BN
+#undef BF_ACT
+    return hipGetLastError();
+}

@@ -130,7 +130,9 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
     ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),  # one-lane-per-query attention core
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM
-    ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma"], False),   # init conv and block1 depthwise apart
+    ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma", "conv1_dw_x3"], False),   # init conv and block1 depthwise apart
+    ({"NWW_BC_FRONT": "2"}, [_BC], ["conv1_dw_mfma"], ["conv1_dw_x3"], False),          # fused front kernel on the float32 MFMA
+    ({"TEST_CONV_ARITH": "bf16x9"}, [_BC], ["conv1_dw_x3"], [], False),                 # fused front kernel, all nine partial products
     ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                   # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
     ({"NWW_FE_MEL": "0"}, [], [], [], True),                                            # sparse VALU mel in the wave-private kernel

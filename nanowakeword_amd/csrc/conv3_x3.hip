@@ -85,6 +85,29 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     // so the two rows of a column are added first (row 2R, then 2R + 1) and the window test runs once per column.
     auto avg_epilogue = [&](const f32x16& acc, int R, int X, float* wsum, AvgWin aw) {
         const bool row1 = 2 * R + 1 < H;
+        if (aw.along_y) {      // (wave-uniform) windows along y: the lane's eight columns of a row are added first, then the row's windows
+            float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v0 = acc[4 * k + dx] + bias, v1 = acc[4 * k + 2 + dx] + bias;
+                    if (bn) { v0 = v0 * al + be; v1 = v1 * al + be; }
+                    v0 = trunk_act<ACT>(v0);
+                    v1 = trunk_act<ACT>(v1);
+                    const bool okx = 16 * X + 4 * k + 2 * hi + dx < W;
+                    r0 += okx ? v0 : 0.0f;
+                    r1 += okx ? v1 : 0.0f;
+                }
+            if (!row1) r1 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < aw.ow) {
+                    wsum[j] += (unsigned)(2 * R - j * aw.sw) < (unsigned)aw.kw ? r0 : 0.0f;
+                    wsum[j] += (unsigned)(2 * R + 1 - j * aw.sw) < (unsigned)aw.kw ? r1 : 0.0f;
+                }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -175,10 +198,10 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     };
     // per-lane avg-pool partials live in the 16 pad bytes of pixels 0..511 (never read by the MFMAs, never written by
     // the staging) or, for small planes, in their own region behind the weights
-    const bool part_in_pads = (H + 3) * Wp >= NTHR;
-    float* my_part = reinterpret_cast<float*>(part_in_pads ? A3 + tid * PS3 + 192 : Wt + WT_BYTES + tid * 16);
-    const int part_stride = part_in_pads ? PS3 / 4 : 4;       // in floats, between consecutive threads
-    const float* part0 = reinterpret_cast<const float*>(part_in_pads ? A3 + 192 : Wt + WT_BYTES);
+    // thread t's partial sums: the pad of pixel t while there are pixels, behind the weights after that
+    const int npix = (H + 3) * Wp;
+    auto part_ptr = [&](int t) { return reinterpret_cast<float*>(t < npix ? A3 + (size_t)t * PS3 + 192 : Wt + WT_BYTES + (size_t)(t - npix) * 16); };
+    float* my_part = part_ptr(tid);
     prefetch(b_first);
     __syncthreads();
     for (int b = b_first; b < a.B; b += b_step) {
@@ -206,7 +229,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         float* outb = seq_ch ? a.out + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho
                              : a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
         float wsum[4] = {0.f, 0.f, 0.f, 0.f};
-        const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow};
+        const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow, a.avg_y};
         int t = t_begin;
         for (; t + 1 < t_end; t += 2) tiles(t, std::true_type{}, outb, wsum, aw);
         if (t < t_end) tiles(t, std::false_type{}, outb, wsum, aw);
@@ -216,12 +239,12 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             // fixed-order reduction: one lane per (channel, window) adds its channel's 2 * NW partials in (wave, half)
             // order.  The next clip's staging may start meanwhile: it touches neither pads nor the partial region, and
             // the barrier behind it separates these reads from the next partial writes.
-            const float inv = 1.0f / (float)(H * a.avg_kw);
+            const float inv = 1.0f / (float)((a.avg_y ? W : H) * a.avg_kw);
             for (int o = tid; o < 32 * a.avg_ow; o += NTHR) {
                 const int ci = o / a.avg_ow, j = o - ci * a.avg_ow;
                 float sum = 0.0f;
                 for (int w2 = 0; w2 < NW; ++w2)
-                    for (int h2 = 0; h2 < 2; ++h2) sum += part0[(size_t)((w2 * 64) + h2 * 32 + ci) * part_stride + j];
+                    for (int h2 = 0; h2 < 2; ++h2) sum += part_ptr(w2 * 64 + h2 * 32 + ci)[j];
                 a.out[((size_t)b * a.Cout + 32 * grp + ci) * a.avg_ow + j] = sum * inv;
             }
         }
@@ -232,8 +255,8 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 static size_t conv3_x3_a3_bytes(int H, int W) { return ((size_t)(H + 3) * (W + 2) * PS3 + 15) & ~(size_t)15; }
 
 size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) {
-    const bool part_in_pads = (H + 3) * (W + 2) >= 512;       // the avg-pool partials (only that mode needs them)
-    return conv3_x3_a3_bytes(H, W) + WT_BYTES + ((avg_ow <= 0 || part_in_pads) ? 0 : 512 * 16);
+    const int npix = (H + 3) * (W + 2);                        // the avg-pool partials live in the pixels' pads; the rest behind the weights
+    return conv3_x3_a3_bytes(H, W) + WT_BYTES + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
 }
 
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {

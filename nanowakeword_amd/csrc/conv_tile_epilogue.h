@@ -19,7 +19,7 @@ __device__ __forceinline__ float trunk_act(float v) {
     return v;
 }
 
-struct AvgWin { int kw, sw, ow; };       // windows [j*sw, j*sw + kw) along x, j < ow <= 4, covering all rows (oh == 1)
+struct AvgWin { int kw, sw, ow; int along_y = 0; };   // windows [j*sw, j*sw + kw) along x (along_y: along y, conv3_x3 only), j < ow <= 4, covering all rows (columns)
 
 // acc = tile (R, X): conv rows 2R, 2R+1, columns 16X .. 16X+15; register 4k+q of lane (i, hi) is channel i, column
 // 16X + 4k + 2hi + (q & 1), row 2R + (q >> 1).

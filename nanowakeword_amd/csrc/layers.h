@@ -121,6 +121,9 @@ struct GruArgs {
     const float* xg2 = nullptr; size_t xg2_bstride = 0; const float* b_hh2 = nullptr; int col_off2 = 0;
 };
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
+// out[f][kx][ky] = w[f][ky][kx] for nfilters 3x3 filters; [B][R][C] -> [B][C][R]
+hipError_t launch_transpose3x3(const float* w, float* out, int nfilters, hipStream_t s);
+hipError_t launch_transpose_planes(const float* in, float* out, int B, int R, int C, hipStream_t s);
 // rnn_x3.hip: gates = 3 (GRU) / 4 (LSTM), H in {32, 64, 128}
 bool rnn_x3_usable(const GruArgs& a);
 bool rnn_x3_enabled(const GruArgs& a);   // ... and not switched off (NWW_GRU16 = 0)

@@ -627,6 +627,39 @@ hipError_t launch_layernorm(const float* x, float* y, const float* w, const floa
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ transposes (E2E head on the transposed plane)
+// 3x3 filters with their taps transposed: out[f][kx][ky] = w[f][ky][kx] (a convolution of the transposed plane with these
+// gives the transposed result of the original convolution)
+__global__ void __launch_bounds__(256) transpose3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int n9) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n9) return;
+    const int f = idx / 9, t = idx - f * 9, ky = t / 3, kx = t - ky * 3;
+    out[f * 9 + kx * 3 + ky] = w[idx];
+}
+hipError_t launch_transpose3x3(const float* w, float* out, int nfilters, hipStream_t s) {
+    const int n9 = nfilters * 9;
+    hipLaunchKernelGGL(transpose3x3_kernel, dim3((n9 + 255) / 256), dim3(256), 0, s, w, out, n9);
+    return hipGetLastError();
+}
+// [B][R][C] -> [B][C][R] through a 32 x 33 LDS tile
+__global__ void __launch_bounds__(256) transpose_planes_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* ib = in + (size_t)b * R * C;
+    float* ob = out + (size_t)b * R * C;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = ib[(size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) ob[(size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+hipError_t launch_transpose_planes(const float* in, float* out, int B, int R, int C, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_planes_kernel, dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, in, out, R, C);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ reductions / pools
 __global__ void __launch_bounds__(256)
 mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total, int bf16) {

@@ -40,6 +40,7 @@ struct Run {
     int B = 0;
     hipStream_t stream = nullptr;
     const float* x = nullptr;   // head input [B][in_rows*in_cols]
+    bool x_frames_major = false; // E2E head on the transposed plane: x came from the frontend as [B][frames][n_mels] already
     float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* emb = nullptr;       // [B][E]
     float* hid = nullptr;       // [B][E/2]
@@ -55,6 +56,7 @@ struct Run {
 }  // namespace
 
 struct nww_handle {
+    bool e2e_transposed = false;                   // the E2E plan runs on the (frames, n_mels) plane: the frontend writes frames-major for it
     nww_config cfg;
     FeParams fe;
     std::string err;
@@ -566,7 +568,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 // 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
-                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr) {
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0) {
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
@@ -583,11 +585,12 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
         const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
         p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name, [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
-            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out;
+            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out; a.avg_y = avg_y;
             return launch_conv3_x3(a, max_grid * per_cu, r.stream);
         });
         return true;
     }
+    if (avg_y) return false;                                   // only conv3_x3 pools along y (the caller checked e2e_transposed_ok)
     if (seq_inout) *seq_inout = false;                         // the float32-MFMA instance writes planes
     p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
         ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
@@ -595,6 +598,19 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
         return launch_conv3x3_mfma(a, Cin, max_grid, r.stream);
     });
     return true;
+}
+
+// The E2E head can run on the TRANSPOSED plane (frames, n_mels) = (101, 64) instead of (64, 101): the fused trunk's 32-pixel
+// conv1 groups and 16-column conv2 tiles waste 28 % on a 101-wide plane and nothing on a 64-wide one, conv3's 2 x 16 tiles 22 %
+// against 4 %, and the frontend's frames-major output is its fast path.  Needs the split-operand kernels (default arithmetic).
+bool e2e_transposed_ok(PlanCtx& p, int n_mels, int frames) {
+    static const int on = [] { const char* e = getenv("NWW_E2E_TRANSPOSED"); return e ? atoi(e) : 1; }();
+    static const int trunk_on = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
+    static const int mfma_on = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+    static const int c3_on = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
+    const int H = frames, W = n_mels;
+    return on && trunk_on && mfma_on && c3_on && p.h->conv_products == 6 && H >= 16 && W >= 4 && trunk_b_pick_strips(H, W) > 0 &&
+           conv_mfma_lds_bytes(32, H / 4, W / 4) <= 160 * 1024 && conv3_x3_fits(H / 4, W / 4, 64, 4, 0);
 }
 
 // nn.GRU / nn.LSTM (bidirectional; G = 3 / 4 gates) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers
@@ -787,6 +803,37 @@ extern "C" int nww_finalize(nww_handle* h) {
         case NWW_HEAD_E2E_DNN: {                  // E2E_MelSpectrogram_CNN body: architectures.py:840-865,877-889
             const int Hh = T, Ww = F;             // (n_mels, frames)
             const int ch[3] = {16, 32, 64};
+            if (e2e_transposed_ok(p, Hh, Ww)) {
+                const int Ht = Ww, Wt = Hh;       // the plane the kernels see: (frames, n_mels)
+                float* wt = nullptr;
+                const int nf[3] = {16, 32 * 16, 64 * 32};
+                if (hipMalloc(&wt, (size_t)(nf[0] + nf[1] + nf[2]) * 9 * sizeof(float)) != hipSuccess) return fail(h, NWW_ERR_HIP, "hipMalloc failed");
+                p.h->packed_weights.push_back(wt);
+                float* wts[3] = {wt, wt + (size_t)nf[0] * 9, wt + (size_t)(nf[0] + nf[1]) * 9};
+                for (int i = 0; i < 3; ++i)
+                    if (launch_transpose3x3(p.W("model.conv_block." + std::to_string(4 * i) + ".weight"), wts[i], nf[i], p.h->own_stream) != hipSuccess)
+                        return fail(h, NWW_ERR_HIP, "weight transpose failed");
+                h->e2e_transposed = true;
+                p.need(2, (size_t)Hh * Ww);
+                p.add("transpose:mel-major features -> frames-major (skipped after the frontend)", [=](Run& r) {
+                    if (r.x_frames_major) return hipSuccess;
+                    const hipError_t e = launch_transpose_planes(r.x, r.buf[2], r.B, Hh, Ww, r.stream);
+                    r.x = r.buf[2];
+                    return e;
+                });
+                if (!add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
+                               p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
+                               p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act))
+                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed trunk does not fit");
+                const int h3 = Ht / 4, w3 = Wt / 4;           // (25, 16): AdaptiveAvgPool2d((1,4))'s windows run along the FRAMES, here y
+                const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
+                if (h3 < 4 || !add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
+                                   p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1))
+                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed third conv does not fit");
+                add_gemm(p, "fc1+bn1", 0, 1, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
+                set_tail(p, "out", 1, 128, p.W("model.out.weight"), p.W("model.out.bias"));
+                break;
+            }
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
             int first = 0;
             bool fused_pool = false;
@@ -1162,8 +1209,9 @@ extern "C" int nww_reserve(nww_handle* h, int32_t B, int32_t N) {
 }
 
 static int run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s, unsigned int* done_flag = nullptr,
-                    unsigned int done_seq = 0, bool* done_armed = nullptr) {
+                    unsigned int done_seq = 0, bool* done_armed = nullptr, bool x_frames_major = false) {
     Run r;
+    r.x_frames_major = x_frames_major;
     r.done_flag = done_flag; r.done_seq = done_seq;
     r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
     r.probs = d_probs;
@@ -1230,9 +1278,10 @@ static int forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, fl
     if (rc) return rc;
     prof_begin(h);
     prof_mark(h, s, 0);
-    rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, c.mel_major_features ? 0 : 1, s, nullptr, row_stride);
+    const bool fm = !c.mel_major_features || h->e2e_transposed;
+    rc = frontend_dev(h, d_pcm, B, N, h->d_logmel, nullptr, fm ? 1 : 0, s, nullptr, row_stride);
     if (rc) return rc;
-    return run_head(h, h->d_logmel, B, d_logits, d_probs, s, done_flag, done_seq, done_armed);
+    return run_head(h, h->d_logmel, B, d_logits, d_probs, s, done_flag, done_seq, done_armed, fm && c.mel_major_features);
 }
 
 extern "C" int nww_forward_pcm_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_logits,

@@ -51,6 +51,7 @@ struct ConvMfmaArgs {
     int B, H, W, Cout, act, pool;
     // fused AvgPool2d(kernel (H, avg_kw), stride (H, avg_sw)) -> out [B][Cout][avg_ow] when avg_ow > 0 (pool must be 0)
     int avg_kw = 0, avg_sw = 0, avg_ow = 0;
+    int avg_y = 0;         // conv3_x3 only: the windows run along y and cover all columns (the same pool on a transposed plane)
     // conv3_x3 only, pooled mode: write out [B][W/2][Cout * H/2] (feature = channel * H/2 + row), the recurrent layers' input
     int seq_out = 0;
 };

@@ -132,6 +132,7 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM
     ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma", "conv1_dw_x3"], False),   # init conv and block1 depthwise apart
     ({"NWW_BC_FRONT": "2"}, [_BC], ["conv1_dw_mfma"], ["conv1_dw_x3"], False),          # fused front kernel on the float32 MFMA
+    ({"NWW_E2E_TRANSPOSED": "0"}, [_E2E], ["trunk_x3", "conv3_x3"], ["transposed"], False),   # E2E head on the (n_mels, frames) plane
     ({"TEST_CONV_ARITH": "bf16x9"}, [_BC], ["conv1_dw_x3"], [], False),                 # fused front kernel, all nine partial products
     ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                   # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM

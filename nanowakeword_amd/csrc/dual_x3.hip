@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the next weight block's LDS-DMA must have landed before the barrier behind this block: waited for here, BEFORE the
+        // stores (vmcnt counts them too - waiting after them made every block sit out the write latency of its own outputs)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
         if (!row_ok) return;
         const float* aff = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
@@ -234,12 +237,10 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     for (int blk = 0; blk < nblk; blk += 2) {
         if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
         block(blk, wb0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (blk + 1 < nblk) {
             if (blk + 2 < nblk) fetch(blk + 2, wb0);
             block(blk + 1, wb1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }

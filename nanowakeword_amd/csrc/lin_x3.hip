@@ -176,6 +176,15 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        // the residual values of this block's outputs travel during its products
+        float4 rres[4];
+        if (EPI == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * blk + 8 * g + 4 * h;
+                rres[g] = (row_ok && col < a.N) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         bf16x8 nw[PARTS][3];
 #pragma unroll
         for (int p = 0; p < PARTS; ++p)
@@ -199,6 +208,10 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
             for (int p = 0; p < PARTS; ++p) mfma6l(cw[p], xf[kb], acc[p]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The next weight block's LDS-DMA (issued before this block's products) and the residual loads must have landed before
+        // the barrier behind this block - waited for HERE, before the stores: vmcnt counts stores too, and waiting for it after
+        // them made every block sit out the write latency of its own outputs (out_proj 0.117 -> see DESIGN 7)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // lane (row n, half h), register 4g + q = output feature 32 blk + 8g + 4h + q
         if (!row_ok) return;
         const float* bp = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
                     o.w *= lin_sigmoid(acc[PARTS - 1][4 * g + 3] + b1.w);
                 }
                 if (EPI == 1) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(rrow + col);
+                    const float4 r4 = rres[g];
                     o.x = r4.x + a.rscale * o.x; o.y = r4.y + a.rscale * o.y; o.z = r4.z + a.rscale * o.z; o.w = r4.w + a.rscale * o.w;
                 }
                 if (EPI == 0 && a.qkv_T > 0) *reinterpret_cast<float4*>(orow + (size_t)qkv_which[col >> 2] * per_which + qkv_lut[col >> 2]) = o;
@@ -230,12 +243,10 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
     for (int blk = 0; blk < nblk; blk += 2) {
         if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
         block(blk, wb0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (blk + 1 < nblk) {
             if (blk + 2 < nblk) fetch(blk + 2, wb0);
             block(blk + 1, wb1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }

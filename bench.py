@@ -245,7 +245,9 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
     lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2)]
     hlog = [torch.empty(B, dtype=torch.float32).pin_memory() for _ in range(2)]
-    NCOPY = 4                                             # the upload of a batch is split over four copy streams
+    # the upload of a batch is split over TWO copy streams: 56.7 GB/s through this pipeline against 54 with one and 49 with
+    # four (tools/h2d_pipeline.py; the bare uploads reach 56-57 GB/s idle or beside the step, tools/h2d_probe.py)
+    NCOPY = 2
     copy_s, comp_s = [torch.cuda.Stream(dev) for _ in range(NCOPY)], torch.cuda.Stream(dev)
     up = [[torch.cuda.Event() for _ in range(NCOPY)] for _ in range(2)]
     done = [torch.cuda.Event() for _ in range(2)]
@@ -276,8 +278,9 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     assert np.array_equal(hlog[0].numpy(), ref_logits), "PCIe-inclusive path changed the logits"
     out["h2d_inclusive"] = {"value": round(B * k / dt, 1), "unit": "clips/s", "batches": k,
                             "pcm_gb_per_s": round(B * k * N * 2 / dt / 1e9, 2),
-                            "note": "pinned host int16 PCM, uploads double-buffered on a copy stream under the previous "
-                                    "batch's kernels, logits copied back; never the headline value"}
+                            "note": "pinned host int16 PCM, uploads double-buffered on two copy streams under the previous "
+                                    "batch's kernels, logits copied back; never the headline value (the link itself: "
+                                    "56-57 GB/s = 1.79 M clips/s, tools/h2d_probe.py)"}
     m.close()
     return out
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak test of the zero-copy small-call path (pinned staging buffer read by the kernels, completion word polled by the host):
 N random-size calls (B = 1 .. 20, so both sides of the B <= 16 completion-word rule) whose logits must equal a table computed
-once through the device-pointer entry point, bit for bit.  GPU box.  usage: python tools/stress_small_calls.py [calls=100000]"""
+once through the device-pointer entry point (B = 256: the bulk kernels), bit for bit - batch invariance of the small-batch
+instances (chain GEMM, trunk strips, folded recurrent step ...) included.  GPU box.
+usage: python tools/stress_small_calls.py [calls=100000] [head=cnn|dnn|crnn|gru|e2e_dnn|bcresnet|conformer]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +12,8 @@ from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_pcm, synth_state_dict
 
 n_calls = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-cfg = HeadConfig("cnn", (101, 64)); m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
+head = sys.argv[2] if len(sys.argv) > 2 else "cnn"
+cfg = HeadConfig(head, (64, 101) if head == "e2e_dnn" else (101, 64)); m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
 dev = torch.device("cuda", 0)
 pool = synth_pcm("noise", 256, 16000, seed=21)
 pd = torch.from_numpy(pool).to(dev); want = torch.empty(256, dtype=torch.float32, device=dev)
@@ -23,5 +26,5 @@ for i in range(n_calls):
     if not np.array_equal(lg, want[o:o + B]):
         bad += 1
         if bad < 5: print("MISMATCH at call", i, "B", B, "offset", o, lg[:4], want[o:o + 4])
-print(f"{n_calls} calls in {time.time() - t0:.1f} s, mismatches: {bad}")
+print(f"{head}: {n_calls} calls in {time.time() - t0:.1f} s, mismatches: {bad}")
 sys.exit(1 if bad else 0)

@@ -33,6 +33,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef X3_TRACE      // tools/ubench/gemm_x3_trace.hip: s_memtime stamps of workgroup 0's first k-tiles (phase boundaries per wave)
+__device__ unsigned long long x3_trace_buf[4 * 16 * 4];
+#define X3_STAMP(kt_rel, ph)                                                                                        \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (kt_rel) < 16 && (threadIdx.x & 63) == 0)        \
+        x3_trace_buf[((threadIdx.x >> 6) * 16 + (kt_rel)) * 4 + (ph)] = __builtin_readcyclecounter();
+#else
+#define X3_STAMP(kt_rel, ph)
+#endif
 namespace {
 constexpr int X3_ROW = 208;                      // bytes per LDS row: 3 terms x 32 k x bf16 + 16 pad (conflict-free b128 reads)
 constexpr int X3_BM = 128;
@@ -204,11 +212,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
             if (kt + q < kt_end) {
+                X3_STAMP(kt + q - kt_begin, 0)
                 __syncthreads();                               // everyone is done reading the previous tile
+                X3_STAMP(kt + q - kt_begin, 1)
                 lstore(0, st[q]);
                 __syncthreads();
+                X3_STAMP(kt + q - kt_begin, 2)
                 if (kt + q + NST < kt_end) gload(kt + q + NST, st[q]);
                 if (NST == 1 || has_rows) multiply();
+                X3_STAMP(kt + q - kt_begin, 3)
             }
         }
     }

@@ -25,6 +25,8 @@ def medians(path):
 
 
 shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(out, f"{rnd}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "stats_configs", "configs_kernel_stats.csv")):       # all BASELINE configs in one traced run
+    shutil.copy(os.path.join(src, "stats_configs", "configs_kernel_stats.csv"), os.path.join(out, f"{rnd}_kernel_stats_all_configs.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{rnd}_bench.json"))
 if os.path.exists(os.path.join(src, "configs.jsonl")):
     shutil.copy(os.path.join(src, "configs.jsonl"), os.path.join(out, f"{rnd}_all_configs.jsonl"))

@@ -20,4 +20,6 @@ B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --prewarm-seconds 0 --n
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B > $OUT/pmc_sq.log 2>&1
+# every BASELINE config (tools/bench_configs.py) under the kernel trace: rocprofv3's own per-kernel averages beside the tool's events
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -o configs -- python $GRAFT_REPO_ROOT/tools/bench_configs.py > $OUT/stats_configs.log 2>&1
 find $OUT -name "*.csv" | head -30

@@ -16,10 +16,17 @@ with HIP events on the launch stream inside the timed region, + "cpu_baseline": 
 of the same workload timed on the host cores; kind "port").
 """
 import argparse
+import glob
 import json
 import os
 import sys
 import time
+
+# The HIP runtime maps streams onto 4 hardware queues by default; this process creates more streams than that (one per model
+# handle, torch's, the PCIe leg's copy and compute streams), and copy streams that share a queue with the compute stream
+# serialise behind it: the PCIe-inclusive leg read 41 GB/s where the same pipeline alone does 56 (tools/h2d_pipeline.py).
+# Must be set before the runtime initialises; the headline value does not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 
@@ -241,6 +248,39 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=a.conv_arith)
     m.reserve(B, N)
     # ---- PCIe-inclusive: pinned host PCM -> (copy stream) -> device double buffer -> kernels -> host logits
+    # The staging buffers should live on the GPU's NUMA node (two-socket hosts: 53.8 vs 56.9 GB/s on this pool): probe the nodes,
+    # bind to the best one while the buffers are allocated and first touched, restore the affinity afterwards.
+    old_aff, numa_note = os.sched_getaffinity(0), "single NUMA node"
+    try:
+        nodes = {}
+        for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+            cpus = set()
+            for part in open(os.path.join(d, "cpulist")).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= old_aff
+            if cpus:
+                nodes[os.path.basename(d)] = cpus
+        if len(nodes) > 1:
+            rates = {}
+            probe_dev = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+            for name, cpus in nodes.items():
+                os.sched_setaffinity(0, cpus)
+                buf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+                buf.fill_(1)
+                probe_dev.copy_(buf, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    probe_dev.copy_(buf, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                rates[name] = 4 * (64 << 20) / (time.perf_counter() - t0) / 1e9
+                del buf
+            best = max(rates, key=rates.get)
+            os.sched_setaffinity(0, nodes[best])
+            numa_note = "staging buffers pinned on " + best + " (probe GB/s: " + ", ".join(f"{k} {v:.1f}" for k, v in rates.items()) + ")"
+    except OSError:
+        pass
     host = [torch.from_numpy(pcm_host).pin_memory(), torch.from_numpy(np.roll(pcm_host, 1, axis=0).copy()).pin_memory()]
     dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
     lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -276,7 +316,8 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     run(k)
     dt = time.perf_counter() - t0
     assert np.array_equal(hlog[0].numpy(), ref_logits), "PCIe-inclusive path changed the logits"
-    out["h2d_inclusive"] = {"value": round(B * k / dt, 1), "unit": "clips/s", "batches": k,
+    os.sched_setaffinity(0, old_aff)
+    out["h2d_inclusive"] = {"value": round(B * k / dt, 1), "unit": "clips/s", "batches": k, "numa": numa_note,
                             "pcm_gb_per_s": round(B * k * N * 2 / dt / 1e9, 2),
                             "note": "pinned host int16 PCM, uploads double-buffered on two copy streams under the previous "
                                     "batch's kernels, logits copied back; never the headline value (the link itself: "

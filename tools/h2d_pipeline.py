@@ -11,6 +11,13 @@ from nanowakeword_amd.synth import synth_pcm, synth_state_dict
 
 dev = torch.device("cuda", 0)
 B, N = 4096, 16000
+if os.environ.get("BLAS_FIRST"):          # what bench.py has done before its PCIe leg: a multi-threaded numpy / oracle pass
+    a_ = np.random.rand(3000, 3000).astype(np.float32)
+    for _ in range(5):
+        a_ = a_ @ a_ * 1e-3
+    print("numpy BLAS pass done", float(a_[0, 0]))
+if os.environ.get("SHOW_AFFINITY"):
+    print("affinity:", len(os.sched_getaffinity(0)), "cpus; running on", open("/proc/self/stat").read().split()[38])
 cfg, fe = HeadConfig("cnn", (101, 64)), FrontendConfig()
 window, fb = torchaudio_tables(fe)
 m = HipModel(cfg, fe, device=0, state_dict=synth_state_dict(cfg), window=window, mel_fb=fb)

@@ -644,7 +644,8 @@ hipError_t launch_transpose3x3(const float* w, float* out, int nfilters, hipStre
 // [B][R][C] -> [B][C][R] through a 32 x 33 LDS tile
 __global__ void __launch_bounds__(256) transpose_planes_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
     __shared__ float tile[32][33];
-    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int ct = (C + 31) / 32;                             // (clip on grid.x: no 65535 limit on the batch)
+    const int b = blockIdx.x, r0 = (blockIdx.y / ct) * 32, c0 = (blockIdx.y % ct) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* ib = in + (size_t)b * R * C;
     float* ob = out + (size_t)b * R * C;
@@ -656,7 +657,7 @@ __global__ void __launch_bounds__(256) transpose_planes_kernel(const float* __re
 }
 hipError_t launch_transpose_planes(const float* in, float* out, int B, int R, int C, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(transpose_planes_kernel, dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, in, out, R, C);
+    hipLaunchKernelGGL(transpose_planes_kernel, dim3(B, ((C + 31) / 32) * ((R + 31) / 32)), dim3(256), 0, s, in, out, R, C);
     return hipGetLastError();
 }
 

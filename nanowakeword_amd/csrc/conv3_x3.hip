@@ -2,7 +2,7 @@
 // cores by exact operand splitting: the third conv stage of the E2E mel-CNN (32 -> 64, un-pooled, avg-pool fused;
 // nanowakeword/modules/architectures.py:851-853) and of CRNN (32 -> 32, pooled; :217-225).
 //
-// Same arithmetic as conv2 of the fused trunk (trunk_x3.hip): every float32 value is hi + mid + lo, three bf16 numbers
+// Same arithmetic as conv2 of the fused trunk (trunk_b.hip): every float32 value is hi + mid + lo, three bf16 numbers
 // holding its 24 significant bits exactly; the six largest of the nine bf16 x bf16 partial products go to
 // v_mfma_f32_32x32x16_bf16 with float32 accumulation (products < 2^-23 of the result are dropped).  The float32-MFMA
 // kernel this replaces (conv3x3_mfma_kernel, trunk.hip) spends 144 x 64 = 9216 matrix-pipe clocks per 32 pixel x 32

@@ -1,6 +1,6 @@
 // frontend2.hip - wave-private fused framing / Hann / 400-point real FFT / power / mel / dB kernel for gfx950.
 //
-// Same arithmetic as frontend.hip (fe_steps.h: 400 real -> 200 complex = 8 x 25), different execution structure:
+// The arithmetic of fe_steps.h ( 400 real -> 200 complex = 8 x 25), different execution structure:
 // every WAVE owns FE2_G = 8 consecutive frames of one clip and runs all stages on them by itself, so the main loop
 // has no workgroup barrier at all - the 12 waves of a CU drift apart and cover each other's LDS / global latency.
 //   S1  lane = (frame slot 0..1, column n2 0..24): 8 sample pairs straight from global memory (4-byte loads, L1/L2

@@ -1,6 +1,6 @@
 // frontend2.hip - wave-private fused framing / Hann / 400-point real FFT / power / mel / dB kernel for gfx950.
 //
-// The arithmetic of fe_steps.h ( 400 real -> 200 complex = 8 x 25), different execution structure:
+// The arithmetic of fe_steps.h (400 real -> 200 complex = 8 x 25) in a wave-private execution structure:
 // every WAVE owns FE2_G = 8 consecutive frames of one clip and runs all stages on them by itself, so the main loop
 // has no workgroup barrier at all - the 12 waves of a CU drift apart and cover each other's LDS / global latency.
 //   S1  lane = (frame slot 0..1, column n2 0..24): 8 sample pairs straight from global memory (4-byte loads, L1/L2
@@ -51,7 +51,8 @@ __device__ __forceinline__ float fe2_db(float mel, float amin, float mult, float
 
 // MEL: how S4 contracts the powers with the filterbank
 //   2  lane = filter (n_mels <= 64, every filter <= MAXT taps): the lane's weights stay in MAXT registers for the whole
-//      launch, one LDS read + one fmaf per tap, zero-padded to MAXT - same summation order as the sparse loop.
+//      launch, one fmaf per tap and one 16-byte LDS read per four taps (the taps start at a multiple of four bins, zero weights
+//      in front), zero-padded to MAXT - same summation order as the sparse loop.
 //      The default: on gfx950 the float32 MFMA runs at the VALU rate AND blocks the SIMD's VALU while it runs
 //      (tools/ubench/mfma_valu_overlap.hip: a v_mfma_f32_16x16x4_f32 wave and a VALU wave on one SIMD take a + b,
 //      AGPR accumulators or not), so the dense 16 x 16 x K tiles with half their rows empty cost 2048 matrix-pipe

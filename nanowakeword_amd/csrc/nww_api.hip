@@ -649,7 +649,9 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                     return launch_gemm(g, r.stream);
                 });
             } else {
-                add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
+                // short-K input projections (the GRU head's 64 mel bins) on the input-stationary kernel; the rest on the general GEMM
+                if (!add_lin_x3(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, 0))
+                    add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
             }
             if (fold && dir == 0) continue;                  // the forward recurrence is launched after the reverse projection
             const int in_T = T;

@@ -503,6 +503,12 @@ __host__ __device__ inline BfGeom bf_geom(int W, int sh, int rows_dw) {
     g.plane_b = (g.max_in * g.pitch0 + 15) & ~15;
     return g;
 }
+// P [row][pixel slot][8 quads of 4 channels]: pixel x sits in slot pslot(x) (bits 0 and 1 of x swapped) and its quad q at position
+// q ^ pswz(x).  A 16-byte store of eight consecutive pixels (one quad each) and a 16-byte depthwise read of four pixels two apart
+// (four quads each) then touch every LDS bank once; with pixel x at x * 128 bytes they hit a quarter / half of the banks and 56 %
+// of the kernel's LDS cycles were conflict cycles (profiles/r03_pmc_all_configs.csv), on an LDS pipe that is busy 63 % of the time.
+__device__ __forceinline__ int bf_pslot(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
+__device__ __forceinline__ int bf_pswz(int x) { return (x & 1) | (((x >> 2) & 1) << 1); }
 constexpr int BF_HEAD = 1536;                 // depthwise weights [9][32] + bias / alpha / beta [3][32], floats
 constexpr int BF_W1F = 12 * 1024;             // conv weight fragments [set][dy][term][64 lanes] x 16 bytes
 
@@ -537,6 +543,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     unsigned char* const W1F = lds_raw + BF_HEAD;
     unsigned char* const In3 = W1F + BF_W1F;
     float* const P = reinterpret_cast<float*>(In3 + 3 * plane_b);
+    const int W1p = (W1 + 3) & ~3;                            // pixel slots per P row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hi = lane >> 5;
@@ -670,9 +677,10 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                 m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc]);
             const int x = 32 * gx + i;
             if (x < W1) {
-                float* dst = P + ((size_t)Rl * W1 + x) * 32 + 16 * set + 8 * hi;
-                *reinterpret_cast<float4*>(dst) = make_float4(m[0], m[1], m[2], m[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(m[4], m[5], m[6], m[7]);
+                float* dst = P + ((size_t)Rl * W1p + bf_pslot(x)) * 32;
+                const int q0 = 4 * set + 2 * hi, sz = bf_pswz(x);
+                *reinterpret_cast<float4*>(dst + 4 * (q0 ^ sz)) = make_float4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<float4*>(dst + 4 * ((q0 + 1) ^ sz)) = make_float4(m[4], m[5], m[6], m[7]);
             }
         }
         __syncthreads();
@@ -685,6 +693,12 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 8) {
             const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), centre = acc;
+            int xoff[3];                                      // the lane's quad of the three columns (slot and swizzle depend on x only)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = min(max(ox * sw - 1 + dx, 0), W1 - 1);
+                xoff[dx] = bf_pslot(xx) * 32 + 4 * (cq ^ bf_pswz(xx));
+            }
 #pragma unroll 1
             for (int dy = 0; dy < 3; ++dy) {
                 const int yy = oy * sh - 1 + dy;
@@ -692,7 +706,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                 for (int dx = 0; dx < 3; ++dx) {
                     const int xx = ox * sw - 1 + dx;
                     const bool ok = yy >= 0 && yy < H1 && xx >= 0 && xx < W1;
-                    const float4 v = ok ? *reinterpret_cast<const float4*>(P + ((size_t)(yy - r_lo) * W1 + xx) * 32 + 4 * cq)
+                    const float4 v = ok ? *reinterpret_cast<const float4*>(P + (size_t)(yy - r_lo) * W1p * 32 + xoff[dx])
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                     if (dy == 1 && dx == 1) centre = v;
                     const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cq);
@@ -818,7 +832,7 @@ hipError_t launch_bc_front_b_pack(const float* w1, unsigned char* packed, hipStr
 }
 static size_t bc_front_b_lds(int W, int sh, int rows_dw) {
     const BfGeom g = bf_geom(W, sh, rows_dw);
-    return (size_t)BF_HEAD + BF_W1F + 3 * (size_t)g.plane_b + (size_t)g.max_conv * (W / 2) * 32 * sizeof(float) + 16;
+    return (size_t)BF_HEAD + BF_W1F + 3 * (size_t)g.plane_b + (size_t)g.max_conv * ((W / 2 + 3) & ~3) * 32 * sizeof(float) + 16;
 }
 // depthwise rows per strip such that two workgroups share a CU (80 KB each); 0 = does not fit
 int bc_front_b_rows(int H, int W, int sh) {

@@ -279,6 +279,22 @@ def test_recurrent_kernels_every_size_and_arithmetic(HipModel):
     print("worst |dlogit| over recurrent instances:", worst)
 
 
+def test_bcresnet_front_kernel_odd_shapes(HipModel):
+    """bc_front_b_kernel away from (101, 64): widths that are not multiples of four (scalar staging path), more than 32 pooled
+    columns (two 32-pixel conv groups per row), planes smaller than one strip; six and nine partial products; against the oracle."""
+    for shape in ((33, 42), (50, 70), (21, 18), (64, 101)):
+        cfg = HeadConfig("bcresnet", shape, embedding_dim=16)
+        sd = synth_state_dict(cfg)
+        x = synth_features(5, cfg.input_shape, seed=shape[0])
+        want = oracle.model_forward(x, sd, cfg).ravel()
+        for arith in (None, "bf16x9"):
+            m = HipModel(cfg, FrontendConfig(), state_dict=sd, **({"conv_arith": arith} if arith else {}))
+            assert "conv1_dw_x3" in m.describe_plan(), m.describe_plan()
+            lg, _ = m.forward_features(x)
+            assert np.abs(lg - want).max() <= 1e-4, (shape, arith, float(np.abs(lg - want).max()))
+            m.close()
+
+
 def test_wide_recurrent_layers_are_refused_loudly(HipModel):
     """layer_dim in (256, 512] has no compiled recurrent kernel: nww_create must say so (not fail at the first launch)."""
     for mt in ("gru", "crnn"):

@@ -478,7 +478,9 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         g.Wx3 = wx3;
         g.a_blocked = a_blocked;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
-        if (wx3 && x3_mode != 2 && K >= 4096) { g.splitk = K / 800; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
+        // split-operand layers: chunks of ~16-25 k-tiles, so that a small batch's chunk is ONE round of gemm_x3_chain_kernel
+        // (32 k-tiles in flight) on a few dozen CUs - K = 12 800: 16 chunks of 25, K = 6 464: 12 of 17, K = 3 920 (C1): 7 of 18
+        if (wx3 && x3_mode != 2 && K >= 2048) { g.splitk = K >= 8192 ? K / 800 : K / 512; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
         g.splitk_ws = r.splitk_ws;
         if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
         r.deferred.active = false;

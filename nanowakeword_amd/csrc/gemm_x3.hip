@@ -436,7 +436,21 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
         X3_ACT(1, 8, grid1, lds1)
         return hipGetLastError();
     }
-    const int cb = x3_pick_cb(g.N);
+    int cb = x3_pick_cb(g.N);
+    {   // a mid-sized M leaves CUs idle with the widest tile (CRNN input projection at 1024 streams: 64 row tiles x 2 column
+        // tiles): take the widest tile of the same padded width that still gives every CU a workgroup, else the narrowest
+        const long mt = (g.M + X3_BM - 1) / X3_BM, pad = (long)((g.N + 32 * cb - 1) / (32 * cb)) * 32 * cb;
+        if (mt * ((g.N + 32 * cb - 1) / (32 * cb)) * sk < 256) {
+            int pick = cb;
+            for (int c = cb - 1; c >= 2; --c) {
+                const long tiles = (g.N + 32 * c - 1) / (32 * c);
+                if (tiles * 32 * c != pad) continue;
+                pick = c;
+                if (mt * tiles * sk >= 256) break;
+            }
+            cb = pick;
+        }
+    }
     const int bn = 32 * cb;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
     const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;

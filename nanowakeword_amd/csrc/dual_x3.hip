@@ -268,11 +268,10 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     if (a0.x && (a0.Ho <= 0 || a0.Wo <= 0 || a0.M % (a0.Ho * a0.Wo) != 0)) return hipErrorInvalidValue;
     DualArgs a = a0;
     a.nblk = (a.N + 31) / 32;
-    static const int wide = [] { const char* e = getenv("NWW_DUAL_WAVES"); return e ? atoi(e) : 8; }();
     // eight waves per workgroup where it measured faster at 8192 clips: bf16 activations at K = 32 (0.255 -> 0.211 ms) and
     // K = 128 (0.293 -> 0.229); K = 64 (0.161 -> 0.172) and every float32 shape (0.363 -> 0.395, 0.235 -> 0.248; K = 128
     // needs 284 registers) stay at four
-    const bool w8 = wide == 8 && a.M >= 256 * 256 && a.bf16 && K != 64;
+    const bool w8 = a.M >= 256 * 256 && a.bf16 && K != 64;
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define DUAL_GO(K16V, ACTV)                                                                                        \
     if (w8) {                                                                                                      \

@@ -81,6 +81,9 @@ hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
                                  int W, int sh, int sw, hipStream_t s, bool bf16 = false);
 // rows [R][D]: y = act(LayerNorm(x)*w + b), eps 1e-5, biased variance; in place allowed (y == x)
+// LayerNorm over x[row][i] = sum_z parts[z][row][i] + in_bias[i] (the split-K partials of the producing GEMM; D <= 256)
+hipError_t launch_layernorm_parts(const float* parts, int nparts, size_t part_stride, const float* in_bias, float* y, const float* w,
+                                  const float* b, int R, int D, int act, hipStream_t s);
 hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
                             hipStream_t s);
 // mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)

@@ -627,6 +627,49 @@ hipError_t launch_layernorm(const float* x, float* y, const float* w, const floa
     return hipGetLastError();
 }
 
+// The same LayerNorm on the split-K partials of the Linear that feeds it: x[row][i] = sum_z parts[z][row][i] + in_bias[i], z
+// ascending - gemm_splitk_reduce_kernel's sum, bit for bit, without its launch and its round trip (DNN layer1; D <= 256).
+__global__ void __launch_bounds__(256)
+layernorm_parts_kernel(const float* __restrict__ parts, int nparts, size_t part_stride, const float* __restrict__ in_bias,
+                       float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ b, int R, int D, int act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        float acc = 0.0f;
+        if (i < D) {
+            const float* p = parts + (size_t)row * D + i;
+            acc = p[0];
+            for (int z = 1; z < nparts; ++z) acc += p[(size_t)z * part_stride];
+            acc += in_bias ? in_bias[i] : 0.0f;
+        }
+        v[j] = acc;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[j];
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; if (lane + 64 * j < D) q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    float* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) yr[i] = act_apply((v[j] - mu) * rstd * w[i] + b[i], act);
+    }
+}
+hipError_t launch_layernorm_parts(const float* parts, int nparts, size_t part_stride, const float* in_bias, float* y, const float* w,
+                                  const float* b, int R, int D, int act, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (D > 256 || nparts < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_parts_kernel, dim3((R + 3) / 4), dim3(256), 0, s, parts, nparts, part_stride, in_bias, y, w, b, R, D, act);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ transposes (E2E head on the transposed plane)
 // 3x3 filters with their taps transposed: out[f][kx][ky] = w[f][ky][kx] (a convolution of the transposed plane with these
 // gives the transposed result of the original convolution)

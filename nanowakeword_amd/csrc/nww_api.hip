@@ -439,7 +439,7 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 // rows_per_clip: M = B*rows_per_clip
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
-              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false) {
+              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -491,6 +491,13 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
             g.defer_reduce = true;
             r.deferred.active = true; r.deferred.out_id = out_id; r.deferred.parts = g.splitk; r.deferred.stride = (size_t)g.M * N;
             r.deferred.bias = bias; r.deferred.alpha = alpha; r.deferred.beta = beta; r.deferred.act = act;
+        }
+        // a LayerNorm right behind a split-K Linear (DNN layer1) sums the partials itself, at every batch size: the reduce launch
+        // and its round trip go (the caller's LayerNorm step checks r.deferred)
+        if (feeds_ln && g.splitk > 1 && g.splitk_ws && !g.res && !alpha && act == ACT_NONE && N <= 256) {
+            g.defer_reduce = true;
+            r.deferred.active = true; r.deferred.out_id = out_id; r.deferred.parts = g.splitk; r.deferred.stride = (size_t)g.M * N;
+            r.deferred.bias = bias; r.deferred.alpha = nullptr; r.deferred.beta = nullptr; r.deferred.act = ACT_NONE;
         }
         return launch_gemm(g, r.stream);
     });
@@ -768,10 +775,17 @@ extern "C" int nww_finalize(nww_handle* h) {
     const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks, act = c.activation;
     switch (c.head_type) {
         case NWW_HEAD_DNN: {                      // Net: architectures.py:110-126
-            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE);
-            p.add("layernorm:layernorm1", [=](Run& r) {
-                return launch_layernorm(r.buf[0], r.buf[0], p.W("model.layernorm1.weight"), p.W("model.layernorm1.bias"), r.B, L, act, r.stream);
-            });
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
+            {
+                const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
+                p.add("layernorm:layernorm1", [=](Run& r) {
+                    if (r.deferred.active && r.deferred.out_id == 0) {           // layer1 left its split-K partials: sum them here
+                        r.deferred.active = false;
+                        return launch_layernorm_parts(r.splitk_ws, r.deferred.parts, r.deferred.stride, r.deferred.bias, r.buf[0], lw1, lb1, r.B, L, act, r.stream);
+                    }
+                    return launch_layernorm(r.buf[0], r.buf[0], lw1, lb1, r.B, L, act, r.stream);
+                });
+            }
             int cur = 0;
             for (int i = 0; i < nb; ++i) {
                 const std::string q = "model.blocks." + std::to_string(i);

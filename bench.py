@@ -70,16 +70,28 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, sd, window, fb, seconds):
     """The oracle (numpy/BLAS restatement of the reference path) on the host cores: PCM -> logits.
-    Timed twice: all-core BLAS (capped at 32 threads; the reference's batch path uses 0.6 x cores,
-    transform_clips.py:441) -> "value"; and 1 thread (the reference interpreter's setting,
-    nanointerpreter.py:955-959) -> "value_1thread"."""
+      value          all cores the way the reference's batch path uses them: a pool of 0.6 x nproc single-threaded workers over
+                     clip batches (transform_clips.py:441, AudioFeatures.py:195-207) - oracle/cpu_pool.py, separate processes
+      value_1thread  one process, one BLAS thread (the reference interpreter's setting, nanointerpreter.py:955-959)
+    plus BASELINE config 1 exactly (DNN head, (98,40) no-centre log-mel, batches of 32) the same two ways."""
     import oracle                                  # checker/baseline only, never on the product path
+    from oracle.cpu_pool import pool_throughput
     from threadpoolctl import threadpool_limits
     from nanowakeword_amd.synth import synth_pcm
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(32, ncpu))
+    workers = max(1, int(0.6 * ncpu))
     chunk = 64
     pcm = synth_pcm("noise", chunk, 16000, seed=123)
 
@@ -87,23 +99,20 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
         lm = oracle.frontend_logmel(pcm, window, fb).transpose(0, 2, 1)
         return oracle.model_forward(np.ascontiguousarray(lm), sd, cfg)
 
-    def timed(nthreads, budget):
+    def timed(fn, per, nthreads, budget):
         with threadpool_limits(limits=nthreads):
-            one()                                  # warm-up (BLAS threads, page-in)
+            fn()                                   # warm-up (BLAS threads, page-in)
             n, t0 = 0, time.perf_counter()
             while True:
-                one()
-                n += chunk
+                fn()
+                n += per
                 dt = time.perf_counter() - t0
                 if dt >= budget:
                     return n, dt
-    n1, dt1 = timed(1, seconds * 0.25)
-    best = (n1 / dt1, 1, n1, dt1)
-    for nt in sorted({min(8, ncpu), threads} - {1}):
-        n, dt = timed(nt, seconds * 0.2)
-        if n / dt > best[0]:
-            best = (n / dt, nt, n, dt)
-    # BASELINE config 1 exactly: DNN head on (98,40) no-centre log-mel, batches of 32, 1 thread and all cores (<= 32)
+    n1, dt1 = timed(one, chunk, 1, seconds * 0.25)
+    kw = {k: getattr(cfg, k) for k in ("layer_dim", "n_blocks", "embedding_dim", "activation") if hasattr(cfg, k)}
+    pool = pool_throughput(cfg.model_type, cfg.input_shape, 64, True, window, fb, workers, chunk=chunk, budget_s=max(2.0, seconds * 0.3), **kw)
+    # BASELINE config 1 exactly: DNN head on (98,40) no-centre log-mel, batches of 32
     from nanowakeword_amd.config import FrontendConfig, HeadConfig
     from nanowakeword_amd.session import torchaudio_tables
     from nanowakeword_amd.synth import synth_state_dict
@@ -115,21 +124,16 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
     def c1_one():
         lm = oracle.frontend_logmel(c1_pcm, c1_w, c1_fb, n_mels=40, center=False).transpose(0, 2, 1)
         return oracle.model_forward(np.ascontiguousarray(lm), c1_sd, c1_cfg)
-    c1 = {}
-    for nt in (1, threads):
-        with threadpool_limits(limits=nt):
-            c1_one()
-            n, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < seconds * 0.15:
-                c1_one()
-                n += 32
-            c1[f"clips_per_s_{nt}_threads"] = round(n / (time.perf_counter() - t0), 1)
-    return {"value": round(best[0], 1), "unit": "clips/s", "cores": int(best[1]), "kind": "port",
-            "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu),
-            "config1_dnn_98x40_batch32": c1,
-            "sample": f"{best[2]} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, "
-                      f"dense-DFT frontend + {cfg.model_type} head) in {best[3]:.1f} s on {best[1]} BLAS thread(s) "
-                      f"(best of 1/8/{threads} threads; 1 thread = the reference interpreter's setting)"}
+    c1n, c1dt = timed(c1_one, 32, 1, seconds * 0.1)
+    c1_pool = pool_throughput("dnn", (98, 40), 40, False, c1_w, c1_fb, workers, chunk=32, budget_s=max(1.5, seconds * 0.15))
+    return {"value": round(pool["rate"], 1), "unit": "clips/s", "cores": int(pool["workers"]), "kind": "port",
+            "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu), "cpu_model": _cpu_model(),
+            "config1_dnn_98x40_batch32": {"clips_per_s_1_thread": round(c1n / c1dt, 1),
+                                          f"clips_per_s_{c1_pool['workers']}_workers": round(c1_pool["rate"], 1)},
+            "sample": f"{pool['clips']} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, dense-DFT frontend + "
+                      f"{cfg.model_type} head) by {pool['workers']} single-threaded worker processes (0.6 x {ncpu} CPUs, the reference's "
+                      f"batch-path pool: transform_clips.py:441) side by side for {pool['seconds']:.1f} s each; value_1thread: {n1} clips "
+                      f"in {dt1:.1f} s in one process on one BLAS thread (the reference interpreter's setting)"}
 
 
 def sustained_leg(a, torch, dev, model, pcm, logits, B, N):
@@ -465,12 +469,11 @@ def main():
             algo["gemm:fc1"] = ("mfma", B * 2 * 32 * (T // 4) * (n_mels // 4) * 128 / 1e12, "TFLOP/s", PEAK_F32_TFLOPS)
             # fused trunk: conv1 on the 2*H1 x 2*W1 positions that survive the floor pooling + conv2 on 2*H2 x 2*W2
             algo["trunk:conv1+pool+conv2+pool"] = ("mfma", algo["conv3x3:conv1"][1] + algo["conv3x3:conv2"][1], "TFLOP/s", PEAK_F32_TFLOPS)
-            # trunk_x3: float32 products as P bf16 partial products on the bf16 MFMA.  `peak` is the algorithmic
-            # (float32-equivalent) rate of conv1/f32_peak + conv2/(bf16_peak/P) - the round-2 definition, kept.
+            # trunk_x3: BOTH convolutions run as P bf16 partial products per float32 product on v_mfma_f32_32x32x16_bf16
+            # (trunk_b.hip), so the matrix-pipe speed of light for the algorithmic (float32-equivalent) flops is bf16_peak / P.
             P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
             f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
-            peak_x3 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
-            algo["trunk_x3:conv1+pool+conv2+pool"] = ("mfma", f1 + f2, "TFLOP/s", round(peak_x3, 1))
+            algo["trunk_x3:conv1+pool+conv2+pool"] = ("mfma", f1 + f2, "TFLOP/s", round(PEAK_BF16_TFLOPS / P, 1))
         name = dom[0]
         if name in algo:
             bound, work, unit, peak = algo[name]
@@ -494,10 +497,13 @@ def main():
                                       "(tools/collect_profiles.py), not measured in this run" if traffic is not None else None,
                     "avg_launch_ms": round(dom[1], 4), "launches": dom[2]}
         if name.startswith("trunk_x3"):
-            # `peak` keeps the round-2 definition (conv1 priced at the f32 MFMA rate) so rounds stay comparable; conv1 now
-            # also runs as P bf16 products, so the matrix-pipe floor of the ISSUED mix is (f1 + f2) / (bf16_peak / P)
-            roofline["peak_definition"] = "algorithmic float32 flops / (conv1 / f32 MFMA peak + conv2 / (bf16 MFMA peak / P)) as in round 2"
-            roofline["frac_of_issued_bf16_mix"] = round(achieved / (PEAK_BF16_TFLOPS / P), 4)
+            P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
+            f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
+            roofline["peak_definition"] = (f"dense bf16 MFMA peak ({PEAK_BF16_TFLOPS:.0f} TFLOP/s) / {P} partial products per float32 product: "
+                                           "both convolutions are issued as split-operand bf16 MFMAs")
+            # rounds 2-3 priced conv1 at the f32-MFMA rate (it ran there in round 2); kept only so that rounds compare
+            peak_r2 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
+            roofline["frac_round2_definition"] = round(achieved / peak_r2, 4)
             roofline["note"] = ("peaks assume the 2.4 GHz boost clock; with all 256 CUs busy this kernel runs power-limited at "
                                 "1.9-2.0 GHz (tools/ubench/trunk_trace.hip, DESIGN.md 4.2b)")
             # back-to-back bf16 MFMAs with toggling operands on all 256 CUs sustain 5.63e10 wave-instructions per second of the
@@ -506,11 +512,24 @@ def main():
         fe_row = [r for r in per if r[0].startswith("frontend")]
         extra = {}
         if fe_row:
-            fe_gbs = B * (2 * N + 4 * n_mels * T) / 1e9 / (fe_row[0][1] * 1e-3)
+            fe_ms = fe_row[0][1]
+            fe_gbs = B * (2 * N + 4 * n_mels * T) / 1e9 / (fe_ms * 1e-3)
             extra["stft_stage"] = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(fe_gbs / PEAK_HBM_GBS, 4),
-                                   "f32_tflops": round(B * 1.27e6 / 1e12 / (fe_row[0][1] * 1e-3), 2),
-                                   "clips_per_s_stage": round(B / (fe_row[0][1] * 1e-3), 0)}
+                                   "f32_tflops": round(B * 1.27e6 / 1e12 / (fe_ms * 1e-3), 2),
+                                   "clips_per_s_stage": round(B / (fe_ms * 1e-3), 0), "avg_launch_ms": round(fe_ms, 4)}
+            # The stage's BINDING roofline is VALU issue, not HBM: SQ_INSTS_VALU wave-instructions (rocprofv3 --pmc pass of this
+            # kernel at this batch, profiles/traffic.json) x 4 clocks each / (1024 SIMDs x the live launch time x 2.4 GHz)
+            try:
+                ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("frontend:fe_stft_mel_db_kernel", {})
+                if ent.get("batch") == B and ent.get("sq_insts_valu"):
+                    n_simd, clk = 1024, 2.4e9
+                    extra["stft_stage"]["valu_issue_frac"] = round(ent["sq_insts_valu"] * 4 / (n_simd * fe_ms * 1e-3 * clk), 4)
+                    extra["stft_stage"]["valu_issue_source"] = (f"SQ_INSTS_VALU {ent['sq_insts_valu']:.4g} per launch (profiles/traffic.json, rocprofv3 --pmc) "
+                                                                "x 4 clocks / (1024 SIMDs x avg_launch_ms x 2.4 GHz)")
+                    extra["stft_stage"]["binding"] = "valu_issue"
+            except Exception:
+                pass
         out = {
             "metric": "clips/sec (1 s @16 kHz PCM->logits)", "value": round(value, 1), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),

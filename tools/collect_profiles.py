@@ -60,6 +60,8 @@ for prefix, label in plan.items():
         traffic[label] = {"batch": 4096, "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024), "fetch_size_kb": fk, "write_size_kb": wk}
         s = sq.get(k, {})
         if s:
+            traffic[label]["sq_insts_valu"] = int(big_median(s.get("SQ_INSTS_VALU", [])))      # bench.py: stft_stage.valu_issue_frac
+            traffic[label]["sq_insts_mfma"] = int(big_median(s.get("SQ_INSTS_MFMA", [])))
             busy, act = big_median(s.get("SQ_BUSY_CYCLES", [])), big_median(s.get("SQ_LDS_IDX_ACTIVE", []))
             print(f"{label}: FETCHx2 {2*fk/1024:.1f} MB WRITE {wk/1024:.1f} MB | INSTS_VALU {big_median(s.get('SQ_INSTS_VALU', [])):.3g} "
                   f"INSTS_MFMA {big_median(s.get('SQ_INSTS_MFMA', [])):.3g} MFMA_BUSY {big_median(s.get('SQ_VALU_MFMA_BUSY_CYCLES', [])):.3g} "

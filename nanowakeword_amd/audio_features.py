@@ -10,6 +10,7 @@ around them: the ``x/10 + 2`` mel transform (:124,146), 76-frame windows every 8
 conventions (:252-253,390-391).  ``mel_fn(x float32 [B,n]) -> [B,1,frames,bins]`` and
 ``embed_fn(windows float32 [W,76,bins,1]) -> [W,1,1,D]`` stand where the ONNX sessions stood; an instance plugs into
 ``HipInterpreter(sessions, preprocessor=...)`` exactly like ``AudioFeatures`` plugs into ``NanoInterpreter``.
+The host-only mirror used to check this class lives with the other checkers (``oracle/audio_features.py``).
 """
 from __future__ import annotations
 
@@ -23,128 +24,12 @@ CHUNK = 1280                # 80 ms
 MEL_CONTEXT = 160 * 3       # extra samples fed to the mel model per update (:394)
 
 
-class WindowedFeatures:
-    def __init__(self, mel_fn: Callable, embed_fn: Callable, sr: int = 16000):
-        self.mel_fn, self.embed_fn, self.sr = mel_fn, embed_fn, sr
-        self.raw_max = sr * 10
-        self.melspectrogram_max_len = 10 * 97
-        self.feature_buffer_max_len = 120
-        self.reset()
-
-    # ------------------------------------------------------------------ model calls with the reference's shaping
-    def _mel(self, x) -> np.ndarray:
-        x = np.asarray(x, dtype=np.float32)
-        if x.ndim < 2:
-            x = x[None]
-        spec = np.squeeze(self.mel_fn(x))
-        return spec / 10 + 2                                   # melspec_transform default (:124)
-
-    def _embed(self, windows: np.ndarray) -> np.ndarray:
-        return np.asarray(self.embed_fn(windows)).squeeze()    # (:103) (W,96), or (96,) for a single window
-
-    def _get_embeddings(self, x: np.ndarray) -> np.ndarray:
-        spec = self._mel(x)
-        wins = [spec[i:i + WINDOW_FRAMES] for i in range(0, spec.shape[0], WINDOW_STEP)
-                if spec[i:i + WINDOW_FRAMES].shape[0] == WINDOW_FRAMES]
-        return self._embed(np.expand_dims(np.array(wins), axis=-1).astype(np.float32))
-
-    def get_embedding_shape(self, audio_length: float, sr: int = 16000):
-        x = (np.random.uniform(-1, 1, int(audio_length * sr)) * 32767).astype(np.int16)
-        return self._get_embeddings(x).shape
-
-    # ------------------------------------------------------------------ state
-    def reset(self):
-        self._raw = np.zeros(0, np.float64)                    # last <= 10 s of samples (a deque of Python numbers in the reference)
-        self.melspectrogram_buffer = np.ones((WINDOW_FRAMES, 32))
-        self.accumulated_samples = 0
-        self.raw_data_remainder = np.empty(0)
-        # the reference warms the feature buffer with embeddings of 4 s of random noise (:112,121)
-        self.feature_buffer = self._get_embeddings(np.random.randint(-1000, 1000, 16000 * 4).astype(np.int16))
-
-    @property
-    def raw_data_buffer(self):
-        return self._raw
-
-    def _buffer_raw(self, x):
-        self._raw = np.concatenate([self._raw, np.asarray(x, np.float64)])[-self.raw_max:]
-
-    def _streaming_mel(self, n_samples: int):
-        if len(self._raw) < 400:
-            raise ValueError("The number of input frames must be at least 400 samples @ 16khz (25 ms)!")
-        new = self._mel(list(self._raw[-n_samples - MEL_CONTEXT:]))
-        self.melspectrogram_buffer = np.vstack((self.melspectrogram_buffer, new))[-self.melspectrogram_max_len:]
-
-    def _streaming_features(self, x: np.ndarray) -> int:
-        processed = 0
-        if self.raw_data_remainder.shape[0] != 0:
-            x = np.concatenate((self.raw_data_remainder, x))
-            self.raw_data_remainder = np.empty(0)
-        total = self.accumulated_samples + x.shape[0]
-        if total >= CHUNK:
-            rem = total % CHUNK
-            if rem:
-                even = x[:-rem]
-                self._buffer_raw(even)
-                self.accumulated_samples += len(even)
-                self.raw_data_remainder = x[-rem:]
-            else:
-                self._buffer_raw(x)
-                self.accumulated_samples += x.shape[0]
-        else:
-            self.accumulated_samples += x.shape[0]
-            self._buffer_raw(x)
-        if self.accumulated_samples >= CHUNK and self.accumulated_samples % CHUNK == 0:
-            self._streaming_mel(self.accumulated_samples)
-            for i in range(self.accumulated_samples // CHUNK - 1, -1, -1):     # oldest new chunk first
-                end = len(self.melspectrogram_buffer) - WINDOW_STEP * i
-                win = self.melspectrogram_buffer[end - WINDOW_FRAMES:end].astype(np.float32)[None, :, :, None]
-                if win.shape[1] == WINDOW_FRAMES:
-                    self.feature_buffer = np.vstack((self.feature_buffer, self._embed(win)))
-            processed = self.accumulated_samples
-            self.accumulated_samples = 0
-        if self.feature_buffer.shape[0] > self.feature_buffer_max_len:
-            self.feature_buffer = self.feature_buffer[-self.feature_buffer_max_len:, :]
-        return processed if processed != 0 else self.accumulated_samples
-
-    def __call__(self, x):
-        return self._streaming_features(x)
-
-    def get_features(self, n_feature_frames: int = 16, start_ndx: int = -1) -> np.ndarray:
-        if start_ndx != -1:
-            end = start_ndx + int(n_feature_frames) if start_ndx + n_feature_frames != 0 else len(self.feature_buffer)
-            return self.feature_buffer[start_ndx:end, :][None].astype(np.float32)
-        return self.feature_buffer[int(-1 * n_feature_frames):, :][None].astype(np.float32)
-
-    # ------------------------------------------------------------------ batch path (transform_clips.py:455)
-    def embed_clips(self, x: np.ndarray, batch_size: int = 128, ncpu: int = 1) -> np.ndarray:
-        """int16 [N, samples] -> float32 [N, (frames-76)//8+1, D]; mel padded to the longest clip with -80 (:221)."""
-        specs = []
-        for i in range(0, x.shape[0], batch_size):
-            specs.extend(np.squeeze(self._mel(s)) for s in x[i:i + batch_size])
-        frames = max(s.shape[0] for s in specs)
-        mel = np.full((len(specs), frames, specs[0].shape[1]), -80.0, np.float32)
-        for i, s in enumerate(specs):
-            mel[i, :s.shape[0]] = s
-        if mel.shape[1] < WINDOW_FRAMES:
-            raise ValueError("Embedding model requires the input melspectrograms to have at least 76 frames")
-        n_frames = (mel.shape[1] - WINDOW_FRAMES) // WINDOW_STEP + 1
-        out = None
-        for n in range(mel.shape[0]):
-            wins = np.stack([mel[n, i:i + WINDOW_FRAMES] for i in range(0, mel.shape[1], WINDOW_STEP)
-                             if i + WINDOW_FRAMES <= mel.shape[1]])[..., None].astype(np.float32)
-            e = np.asarray(self.embed_fn(wins)).reshape(wins.shape[0], -1)
-            if out is None:
-                out = np.empty((mel.shape[0], n_frames, e.shape[1]), np.float32)
-            out[n] = e[:n_frames]
-        return out
-
-
 class DeviceWindowedFeatures:
-    """``WindowedFeatures`` with the buffers and the windowing on the GPU (C-ABI ``nww_emb_*``, csrc/emb_stream.hip)
+    """The reference's ``AudioFeatures`` preprocessor with the buffers and the windowing on the GPU (C-ABI ``nww_emb_*``, csrc/emb_stream.hip)
     for ``n_streams`` lock-step streams: the mel ring (ones((76,32)) at reset, x/10 + 2, newest 970 frames), the
     76-frame windows of the new 80 ms chunks, the 120-row feature ring and ``get_features`` live on the device next
     to the head, whose forward reads the last T rows of every stream without a host hop (``scores()``).  The two
-    models stay pluggable host callables exactly as in ``WindowedFeatures``; the raw-audio bookkeeping in front of the
+    models stay pluggable host callables; the raw-audio bookkeeping in front of the
     mel model (remainder carry, the ``n + 480`` samples it is fed, AudioFeatures.py:394,406-424) stays on the host
     because that is where the pluggable mel model takes its input.
 
@@ -198,39 +83,32 @@ class DeviceWindowedFeatures:
         self._raw = np.concatenate([self._raw, np.asarray(x, np.float64)], axis=1)[:, -self.raw_max:]
 
     def _streaming_features(self, x: np.ndarray) -> int:
+        """AudioFeatures.py:406-449 as arithmetic on a sample counter: samples are committed to the raw buffer in whole 80 ms
+        chunks once at least one chunk is pending (the tail is carried to the next call), and every committed run of whole
+        chunks is turned into mel frames, windows and feature rows on the device."""
         x = np.asarray(x)
         if x.ndim == 1:
             x = x[None]
         if x.shape[0] != self.S:
             raise ValueError(f"expected audio for {self.S} stream(s), got {x.shape}")
-        processed = 0
-        if self.raw_data_remainder.shape[1] != 0:
+        if self.raw_data_remainder.shape[1]:
             x = np.concatenate((self.raw_data_remainder, x), axis=1)
-            self.raw_data_remainder = np.zeros((self.S, 0))
-        total = self.accumulated_samples + x.shape[1]
-        if total >= CHUNK:
-            rem = total % CHUNK
-            if rem:
-                self._buffer_raw(x[:, :-rem])
-                self.accumulated_samples += x.shape[1] - rem
-                self.raw_data_remainder = x[:, -rem:]
-            else:
-                self._buffer_raw(x)
-                self.accumulated_samples += x.shape[1]
-        else:
-            self.accumulated_samples += x.shape[1]
-            self._buffer_raw(x)
-        if self.accumulated_samples >= CHUNK and self.accumulated_samples % CHUNK == 0:
-            if self._raw.shape[1] < 400:
-                raise ValueError("The number of input frames must be at least 400 samples @ 16khz (25 ms)!")
-            n_chunks = self.accumulated_samples // CHUNK
-            self.backend.emb_push_mel(self._mel_raw(self._raw[:, -self.accumulated_samples - MEL_CONTEXT:]), raw=True)
-            wins = self.backend.emb_windows(n_chunks)                       # [S, n_valid, 76, bins], oldest chunk first
-            if wins.shape[1]:
-                self.backend.emb_push_features(self._embed(wins))
-            processed = self.accumulated_samples
-            self.accumulated_samples = 0
-        return processed if processed != 0 else self.accumulated_samples
+        pending = self.accumulated_samples + x.shape[1]
+        take = x.shape[1] - (pending % CHUNK if pending >= CHUNK else 0)
+        self._buffer_raw(x[:, :take])
+        self.raw_data_remainder = x[:, take:]
+        self.accumulated_samples += take
+        n_chunks, partial = divmod(self.accumulated_samples, CHUNK)
+        if n_chunks == 0 or partial:
+            return self.accumulated_samples
+        if self._raw.shape[1] < 400:
+            raise ValueError("The number of input frames must be at least 400 samples @ 16khz (25 ms)!")
+        self.backend.emb_push_mel(self._mel_raw(self._raw[:, -self.accumulated_samples - MEL_CONTEXT:]), raw=True)
+        wins = self.backend.emb_windows(n_chunks)                           # [S, n_valid, 76, bins], oldest chunk first
+        if wins.shape[1]:
+            self.backend.emb_push_features(self._embed(wins))
+        done, self.accumulated_samples = self.accumulated_samples, 0
+        return done
 
     def __call__(self, x):
         return self._streaming_features(x)

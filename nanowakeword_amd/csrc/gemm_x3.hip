@@ -304,6 +304,17 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if (kt_begin >= kt_end) {             // an empty split-K chunk (no split rule produces one today): its partial sums are zeros, not stale workspace
+        if (wave == 0 && bn + i < g.N) {
+            float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M) part[(size_t)m * g.N + bn + i] = 0.0f;
+            }
+        }
+        return;
+    }
     for (int round = kt_begin; round < kt_end; round += CH_NW * CH_TPW) {
         const int t0 = round + wave * CH_TPW;
         const int nt = max(0, min(CH_TPW, kt_end - t0));                      // this wave's k-tiles (wave-uniform)

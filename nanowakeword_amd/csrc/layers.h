@@ -61,6 +61,7 @@ size_t gemm_x3_weight_bytes(int N, int K);
 // wave-specialised form (gemm_x3s.hip): producer waves stage + split, consumer waves multiply; same results bit for bit
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);
 bool gemm_x3_usable(const GemmArgs& g);
+bool gemm_writes_partials(const GemmArgs& g);   // launch_gemm will take an MFMA kernel (split-K partials), not the VALU fallback
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s);
 // rows(M) x N x K -> recommended split (1 = none); workspace floats needed = split*M*N
 int gemm_recommended_splitk(long long M, int N, int K, int cu_count);

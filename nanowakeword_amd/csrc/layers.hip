@@ -192,6 +192,13 @@ __global__ void __launch_bounds__(256) gemm_valu_kernel(GemmArgs g) {
     g.C[(size_t)m * g.ldc + n] = v;
 }
 
+// true when launch_gemm will run one of the MFMA kernels (which write split-K partials for splitk > 1) and not the VALU fallback
+bool gemm_writes_partials(const GemmArgs& g) {
+    const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    return aligned || (!g.A2 && gemm_x3_usable(g));
+}
+
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const bool aligned = (g.K % 4 == 0) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&

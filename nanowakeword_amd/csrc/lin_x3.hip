@@ -276,14 +276,16 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     a.nblk = (a.N + 31) / 32;
     // eight waves per workgroup for the GLU epilogue only: its four-wave instances need 212 - 264 registers and do not reach two
     // workgroups per CU (LayerNorm + conv1 + GLU of the Conformer 0.155 -> 0.138 ms); the other epilogues measured slower with
-    // eight (in_proj 0.170 -> 0.199, out_proj / conv2 0.117 -> 0.125-0.129)
-    const bool w8 = epi == 2 && a.M >= 256 * 256;
+    // eight (in_proj 0.170 -> 0.199, out_proj / conv2 0.117 -> 0.125-0.129).  K >= 128 has no four-wave GLU instance at all (one
+    // workgroup per CU, "final occupancy 1"); the row arithmetic is the same in both shapes, so results do not depend on the choice.
+    const bool w8 = epi == 2 && (K >= 128 || a.M >= 256 * 256);
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define LIN_GO(K16V, EPIV, LNV)                                                                                    \
-    if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4)>), grid, dim3(512), 0, s, a); \
+    if constexpr (EPIV == 2 && K16V >= 8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8>), grid, dim3(512), 0, s, a); \
+    else if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4)>), grid, dim3(512), 0, s, a); \
     else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4>), grid, dim3(256), 0, s, a);
 #define LIN_EPI(K16V)                                                                                              \
-    if (epi == 0) LIN_GO(K16V, 0, false) else if (epi == 1) LIN_GO(K16V, 1, false) else if (ln) LIN_GO(K16V, 2, true) else LIN_GO(K16V, 2, false)
+    if (epi == 0) { LIN_GO(K16V, 0, false) } else if (epi == 1) { LIN_GO(K16V, 1, false) } else if (ln) { LIN_GO(K16V, 2, true) } else { LIN_GO(K16V, 2, false) }
     switch (K) {
         case 32: LIN_EPI(2) break;
         case 64: LIN_EPI(4) break;

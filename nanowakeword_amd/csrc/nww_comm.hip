@@ -1,0 +1,133 @@
+// nww_comm.hip - the path's only exchange: RCCL all-gather of the per-clip logits (nww_comm_*, nww_forward_pcm_gather_dev).
+#include "nww_internal.h"
+#define prof_mark nww_prof_mark
+#define prof_begin nww_prof_begin
+#define ensure_ws nww_ensure_ws
+#define run_head nww_run_head
+#define check_run nww_check_run
+#define frontend_dev nww_frontend_on_dev
+#define forward_pcm_dev nww_forward_pcm_on_dev
+#define h2d_small nww_h2d_small
+#define copy_out nww_copy_out
+#include <dlfcn.h>
+
+// ------------------------------------------------------------------------------------------ RCCL (multi-GPU gather)
+// The path's only exchange: an all-gather of the per-clip float32 logits (4 B per clip) over RCCL / xGMI, enqueued on
+// the SAME stream as the kernels so a step never touches the host.  RCCL is bound at run time (dlopen): a process
+// that already carries one (PyTorch's bundled librccl.so) is reused, otherwise the system librccl.so.1 is loaded; a
+// single-GPU user never loads it at all.
+struct NcclId { char internal[128]; };       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+}  // namespace
+static RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        // 1. the RCCL that sits next to the HIP runtime this process actually runs on (a PyTorch process carries its own
+        //    libamdhip64 + librccl pair; mixing one stack's RCCL with the other's HSA runtime fails at communicator
+        //    creation), 2. one that is already loaded, 3. the system library
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.find_last_of('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* name : {"librccl.so", "librccl.so.1"}) {
+                    a.lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (a.lib) break;
+                }
+            }
+        }
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            if (a.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        }
+        if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) { a.err = std::string("cannot load RCCL: ") + dlerror(); return a; }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) a.err = "RCCL library lacks the expected symbols";
+        return a;
+    }();
+    return api;
+}
+static const char* rccl_str(int rc) { return rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"; }
+
+extern "C" int nww_comm_unique_id(void* id128) {
+    if (!id128) return NWW_ERR_INVALID;
+    RcclApi& a = rccl();
+    if (!a.err.empty()) { nww_create_err() = a.err; return NWW_ERR_UNSUPPORTED; }
+    const int rc = a.GetUniqueId(id128);
+    if (rc != 0) { nww_create_err() = std::string("ncclGetUniqueId: ") + rccl_str(rc); return NWW_ERR_HIP; }
+    return NWW_OK;
+}
+
+extern "C" int nww_comm_destroy(nww_handle* h) {
+    if (!h) return NWW_ERR_INVALID;
+    if (h->comm) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_rank = 0; h->comm_world = 1;
+    return NWW_OK;
+}
+
+extern "C" int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const void* id128) {
+    if (!h) return NWW_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !id128) return fail(h, NWW_ERR_INVALID, "nww_comm_init: bad rank/world/id");
+    RcclApi& a = rccl();
+    if (!a.err.empty()) return fail(h, NWW_ERR_UNSUPPORTED, "%s", a.err.c_str());
+    nww_comm_destroy(h);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    NcclId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    const int rc = a.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_str(rc));
+    h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+    return NWW_OK;
+}
+
+static int all_gather_dev(nww_handle* h, const float* d_send, float* d_recv, int count, hipStream_t s) {
+    if (!h->comm) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    const int rc = rccl().AllGather(d_send, d_recv, (size_t)count, /* ncclFloat32 */ 7, h->comm, s);
+    if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclAllGather: %s", rccl_str(rc));
+    return NWW_OK;
+}
+
+// d_send [count] of this rank -> d_recv [world][count] on every rank, enqueued on `stream` (no synchronisation)
+extern "C" int nww_all_gather_logits(nww_handle* h, const float* d_send, float* d_recv, int32_t count, void* stream) {
+    if (!h) return NWW_ERR_INVALID;
+    if (!d_send || !d_recv || count <= 0) return fail(h, NWW_ERR_INVALID, "nww_all_gather_logits: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return all_gather_dev(h, d_send, d_recv, count, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+// One sharded step without a host hop: this rank's B clips -> its B logits (written at d_all_logits + rank * B), then
+// the all-gather into d_all_logits [world][B], both on `stream`.
+extern "C" int nww_forward_pcm_gather_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_pcm || !d_all_logits) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    if (!h->comm) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    float* mine = d_all_logits + (size_t)h->comm_rank * B;
+    rc = forward_pcm_dev(h, d_pcm, B, N, mine, nullptr, s);
+    if (rc) return rc;
+    return all_gather_dev(h, mine, d_all_logits, B, s);       // in place: send buffer = this rank's slot of the receive buffer
+}
+

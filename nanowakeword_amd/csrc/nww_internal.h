@@ -1,0 +1,136 @@
+// nww_internal.h - what the translation units of the C-ABI share: the handle, a forward's run state, error helpers and the
+// device-side entry points they call on each other.  nww_api.hip: create / load / run entry points; nww_plan.hip: state_dict spec
+// and the per-head launch plans (nww_finalize); nww_stream.hip: batched streaming (nww_stream_*); nww_comm.hip: RCCL gather;
+// nww_emb.hip: embedding-mode state (nww_emb_*).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nww.h"
+#include "fe_tables.h"
+#include "frontend.h"
+#include "layers.h"
+#include "trunk.h"
+#include "ffn_x3.h"
+#include "lin_x3.h"
+#include "dual_x3.h"
+#include "emb_stream.h"
+
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+    size_t dev_off = 0;     // float offset in the weight arena
+};
+
+struct Step {
+    std::string name;
+    std::function<hipError_t(struct Run&)> fn;
+};
+
+struct Run {
+    int B = 0;
+    hipStream_t stream = nullptr;
+    const float* x = nullptr;   // head input [B][in_rows*in_cols]
+    bool x_frames_major = false; // E2E head on the transposed plane: x came from the frontend as [B][frames][n_mels] already
+    float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* emb = nullptr;       // [B][E]
+    float* hid = nullptr;       // [B][E/2]
+    float* logits = nullptr;    // [B]
+    float* probs = nullptr;     // [B] or null; a plan step that writes it clears `need_sigmoid`
+    bool need_sigmoid = true;
+    unsigned int* done_flag = nullptr; unsigned int done_seq = 0; bool done_armed = false;   // zero-copy small calls (classifier tail's completion word)
+    float* splitk_ws = nullptr; size_t splitk_floats = 0; int cu_count = 256;
+    // a split-K GEMM that left its partials for the classifier tail to reduce (GemmArgs::defer_reduce)
+    struct { bool active = false; int out_id = 0, parts = 0; size_t stride = 0; const float *bias = nullptr, *alpha = nullptr, *beta = nullptr; int act = 0; } deferred;
+};
+
+
+struct nww_handle {
+    bool e2e_transposed = false;                   // the E2E plan runs on the (frames, n_mels) plane: the frontend writes frames-major for it
+    nww_config cfg;
+    FeParams fe;
+    std::string err;
+    std::vector<std::string> keys;                 // required state_dict keys, in order
+    std::map<std::string, HostTensor> tensors;     // required + optional + derived
+    bool finalized = false;
+    float* d_weights = nullptr;
+    FeTables* d_tables = nullptr;
+    Fe2MelPlan* d_melplan = nullptr;
+    int mel_max_taps = 0;          // longest filter support of the mel filterbank
+    hipStream_t own_stream = nullptr;
+    std::vector<Step> plan;
+    size_t buf_per_clip[6] = {0, 0, 0, 0, 0, 0};   // floats per clip of each workspace buffer
+    // workspace (grown on demand)
+    int cap_B = 0, cap_N = 0;
+    bool trunk_blocked = false;    // CNN head: the fused trunk writes fc1's A operand as [128][32] tiles (decided at plan time)
+    int cap_rows = 0;              // cap_B rounded up to 128: the blocked trunk -> fc1 buffer is written in 128-clip row blocks
+    float* d_ws = nullptr;
+    int16_t* d_pcm = nullptr;
+    float* d_logmel = nullptr;     // [B][n_mels*frames]
+    float* d_feats = nullptr;      // staging for host feature input
+    float* d_emb = nullptr;
+    float* d_hid = nullptr;
+    float* d_logits = nullptr;
+    float* d_probs = nullptr;
+    float* d_splitk = nullptr;     // split-K partials
+    // streaming rings: [S][2*W] int16, sample p of a stream lives at p and p+W
+    int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
+    EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
+    void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
+    unsigned char* pin_in = nullptr; unsigned char* pin_out = nullptr;   // pinned staging for small host-pointer calls
+    bool pin_in_busy = false;                                            // an async copy out of pin_in may still be in flight
+    unsigned int done_seq = 0;                                           // completion-word sequence of the zero-copy small calls
+    int comm_rank = 0, comm_world = 1;
+    int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
+    size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
+    std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
+    std::vector<void*> packed_weights;             // other plan-time weight packings (ffn_x3.hip)
+    int conv_products = 0;                         // fused trunk: 0 = float32 MFMA, 6 | 9 = bf16 split products
+    int cu_count = 256;
+    // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
+    bool profiling = false;
+    int prof_period = 1, prof_counter = 0;   // sampling: only every prof_period-th forward records events
+    bool prof_active = false;
+    std::vector<std::vector<hipEvent_t>> prof_runs;   // one event list per recorded forward
+    std::vector<std::vector<int>> prof_ids;           // plan-entry id of each interval
+    std::vector<hipEvent_t> event_pool;
+    std::vector<double> prof_ms;                      // size plan+2 : [0]=frontend, [1..n]=plan, [n+1]=sigmoid
+    std::vector<int> prof_cnt;
+};
+
+
+// ---- shared helpers (defined in nww_api.hip unless noted)
+int nww_fail(nww_handle* h, int code, const char* fmt, ...);
+std::string& nww_create_err();                 // nww_create / communicator errors: per thread
+void nww_prof_mark(nww_handle* h, hipStream_t s, int id_of_next);
+void nww_prof_begin(nww_handle* h);
+int nww_check_run(nww_handle* h, int B);
+int nww_ensure_ws(nww_handle* h, int B, int N);
+int nww_run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s, unsigned int* done_flag = nullptr,
+                 unsigned int done_seq = 0, bool* done_armed = nullptr, bool x_frames_major = false);
+int nww_frontend_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_db, float* d_mel, int frames_major, hipStream_t s,
+                        int* frames_out, size_t row_stride = 0);
+int nww_forward_pcm_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s,
+                           size_t row_stride = 0, unsigned int* done_flag = nullptr, unsigned int done_seq = 0, bool* done_armed = nullptr);
+int nww_h2d_small(nww_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s);
+int nww_copy_out(nww_handle* h, int B, float* logits, float* probs, float* emb, hipStream_t s);
+void nww_build_spec(nww_handle* h);            // nww_plan.hip
+
+#define fail nww_fail
+#define HIP_TRY(h, expr)                                                                             \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(h, NWW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+

@@ -1,0 +1,866 @@
+// nww_plan.hip - Model.state_dict() spec per head and the launch plans nww_finalize builds from the loaded weights.
+#include "nww_internal.h"
+#define prof_mark nww_prof_mark
+#define prof_begin nww_prof_begin
+#define ensure_ws nww_ensure_ws
+#define run_head nww_run_head
+#define check_run nww_check_run
+#define frontend_dev nww_frontend_on_dev
+#define forward_pcm_dev nww_forward_pcm_on_dev
+#define h2d_small nww_h2d_small
+#define copy_out nww_copy_out
+
+// ------------------------------------------------------------------------------------------ spec
+namespace {
+using Shape = std::vector<int64_t>;
+struct SpecBuilder {
+    std::vector<std::string>& keys;
+    std::map<std::string, HostTensor>& t;
+    void add(const std::string& k, Shape s) { keys.push_back(k); t[k].shape = std::move(s); }
+    void lin(const std::string& p, int out, int in) { add(p + ".weight", {out, in}); add(p + ".bias", {out}); }
+    void ln(const std::string& p, int d) { add(p + ".weight", {d}); add(p + ".bias", {d}); }
+    void bn(const std::string& p, int c) {
+        add(p + ".weight", {c}); add(p + ".bias", {c}); add(p + ".running_mean", {c}); add(p + ".running_var", {c});
+    }
+    void gru(const std::string& p, int in, int H, int layers, int G = 3) {   // G = 3: nn.GRU, 4: nn.LSTM
+        for (int l = 0; l < layers; ++l) {
+            const int isz = l == 0 ? in : 2 * H;
+            for (const char* sfx : {"", "_reverse"}) {
+                const std::string s = "_l" + std::to_string(l) + sfx;
+                add(p + ".weight_ih" + s, {G * H, isz}); add(p + ".weight_hh" + s, {G * H, H});
+                add(p + ".bias_ih" + s, {G * H}); add(p + ".bias_hh" + s, {G * H});
+            }
+        }
+    }
+};
+
+void crnn_out(const nww_config& c, int* C, int* H, int* W) {
+    int h = c.in_rows, w = c.in_cols;
+    for (int i = 0; i < c.n_crnn_channels; ++i) { h /= 2; w /= 2; }
+    *C = c.crnn_channels[c.n_crnn_channels - 1]; *H = h; *W = w;
+}
+
+// Mirrors nanowakeword_amd/config.py:param_spec == Model.state_dict() of the reference (model.py:67-296).
+}  // namespace
+
+void nww_build_spec(nww_handle* h) {
+    const nww_config& c = h->cfg;
+    SpecBuilder s{h->keys, h->tensors};
+    const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks;
+    switch (c.head_type) {
+        case NWW_HEAD_DNN:
+            s.lin("model.layer1", L, T * F); s.ln("model.layernorm1", L);
+            for (int i = 0; i < nb; ++i) {
+                const std::string p = "model.blocks." + std::to_string(i);
+                s.lin(p + ".fcn_layer", L, L); s.ln(p + ".layer_norm", L);
+            }
+            s.lin("model.last_layer", E, L);
+            break;
+        case NWW_HEAD_CNN:
+            s.add("model.conv1.weight", {16, 1, 3, 3}); s.add("model.conv1.bias", {16});
+            s.add("model.conv2.weight", {32, 16, 3, 3}); s.add("model.conv2.bias", {32});
+            s.lin("model.fc1", 128, 32 * (T / 4) * (F / 4)); s.lin("model.fc2", E, 128);
+            break;
+        case NWW_HEAD_CRNN: {
+            int cin = 1;
+            for (int i = 0; i < c.n_crnn_channels; ++i) {
+                const int co = c.crnn_channels[i];
+                const std::string p = "model.cnn." + std::to_string(4 * i);
+                s.add(p + ".weight", {co, cin, 3, 3}); s.add(p + ".bias", {co});
+                s.bn("model.cnn." + std::to_string(4 * i + 1), co);
+                cin = co;
+            }
+            int C, H, W; crnn_out(c, &C, &H, &W);
+            s.gru("model.rnn", C * H, L, nb, c.crnn_rnn_lstm ? 4 : 3); s.lin("model.fc", E, 2 * L);
+            break;
+        }
+        case NWW_HEAD_GRU:
+            s.gru("model.gru", F, L, nb); s.lin("model.fc", E, 2 * L);
+            break;
+        case NWW_HEAD_BCRESNET: {
+            s.add("model.init_conv.0.weight", {32, 1, 3, 3}); s.bn("model.init_conv.1", 32);
+            const int ch[4] = {32, 64, 128, 256};
+            for (int i = 1; i <= 3; ++i) {
+                const std::string p = "model.block" + std::to_string(i);
+                s.add(p + ".depthwise.weight", {ch[i - 1], 1, 3, 3});
+                s.add(p + ".pointwise.weight", {ch[i], ch[i - 1], 1, 1}); s.bn(p + ".bn1", ch[i]);
+                s.add(p + ".shortcut.0.weight", {ch[i], ch[i - 1], 1, 1}); s.bn(p + ".shortcut.1", ch[i]);
+            }
+            s.lin("model.fc", E, 256);
+            break;
+        }
+        case NWW_HEAD_CONFORMER: {
+            const int D = c.conformer_d_model;
+            s.lin("model.input_proj", D, F);
+            for (int i = 0; i < nb; ++i) {
+                const std::string p = "model.conformer_blocks." + std::to_string(i);
+                for (const char* ff : {".ff1", ".ff2"}) {
+                    s.ln(p + ff + ".layer_norm", D); s.lin(p + ff + ".linear1", 4 * D, D); s.lin(p + ff + ".linear2", D, 4 * D);
+                }
+                s.add(p + ".attention.in_proj_weight", {3 * D, D}); s.add(p + ".attention.in_proj_bias", {3 * D});
+                s.lin(p + ".attention.out_proj", D, D);
+                s.ln(p + ".conv_module.layer_norm", D);
+                s.add(p + ".conv_module.conv1.weight", {2 * D, D, 1}); s.add(p + ".conv_module.conv1.bias", {2 * D});
+                s.add(p + ".conv_module.depthwise_conv.weight", {D, 1, 31}); s.add(p + ".conv_module.depthwise_conv.bias", {D});
+                s.bn(p + ".conv_module.batch_norm", D);
+                s.add(p + ".conv_module.conv2.weight", {D, D, 1}); s.add(p + ".conv_module.conv2.bias", {D});
+                s.ln(p + ".layer_norm", D);
+            }
+            s.lin("model.output_proj", E, D);
+            break;
+        }
+        case NWW_HEAD_E2E_DNN: {
+            int cin = 1;
+            const int ch[3] = {16, 32, 64};
+            for (int i = 0; i < 3; ++i) {
+                const std::string p = "model.conv_block." + std::to_string(4 * i);
+                s.add(p + ".weight", {ch[i], cin, 3, 3}); s.add(p + ".bias", {ch[i]});
+                s.bn("model.conv_block." + std::to_string(4 * i + 1), ch[i]);
+                cin = ch[i];
+            }
+            s.lin("model.fc1", 128, 256); s.bn("model.bn1", 128); s.lin("model.out", E, 128);
+            break;
+        }
+    }
+    s.lin("classifier.0", E / 2, E);
+    s.lin("classifier.3", 1, E / 2);
+}
+
+
+// ------------------------------------------------------------------------------------------ plan helpers
+namespace {
+
+struct PlanCtx {
+    nww_handle* h;
+    const float* W(const std::string& k) const {
+        auto it = h->tensors.find(k);
+        return it == h->tensors.end() || !it->second.loaded ? nullptr : h->d_weights + it->second.dev_off;
+    }
+    void need(int buf, size_t floats_per_clip) {
+        if (h->buf_per_clip[buf] < floats_per_clip) h->buf_per_clip[buf] = floats_per_clip;
+    }
+    void add(const std::string& name, std::function<hipError_t(Run&)> fn) { h->plan.push_back({name, std::move(fn)}); }
+    void pop_last() { if (!h->plan.empty()) h->plan.pop_back(); }        // a step just planned is re-planned in another form
+    // the head's last Linear (-> embedding), deferred so that it can be fused with the classifier into one launch
+    std::string tail_name; int tail_in = 99, tail_K = 0; const float *tail_W = nullptr, *tail_b = nullptr;
+};
+
+// source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
+inline const float* src(Run& r, int id) { return id == -1 ? r.x : id == -2 ? r.emb : id == -3 ? r.hid : r.buf[id]; }
+inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid : id == -4 ? r.logits : r.buf[id]; }
+
+// rows_per_clip: M = B*rows_per_clip
+void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
+              const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
+              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false) {
+    if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
+    // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
+    // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
+    // (N,K) = (576,144) 0.32 / 0.46, (144,576) 0.41 / 0.51, (432,144) 0.26 / 0.33, (288,144) 0.18 / 0.24,
+    // (144,64) 0.05 / 0.07, (384,64) 0.23 / 0.29, (128,12800) 0.09 / 0.14 - and stay on the float32 MFMA kernel for the
+    // small square ones, (144,144) 0.23 / 0.18, whose single padded column tile wastes the wide kernel.  Long-K layers
+    // get a fine split-K.  The choice depends on (N, K) only, so batch invariance is kept.
+    // NWW_GEMM_X3 = 0: never, 2: every shape with N, K >= 32, 3: the round-1 rule (K >= 4096 only).
+    static const int x3_mode = [] { const char* e = getenv("NWW_GEMM_X3"); return e ? atoi(e) : 1; }();
+    const bool small_square = N <= 160 && K > 64 && K <= 160;
+    const bool use_x3 = p.h->conv_products != 0 &&
+                        (x3_mode == 2 ? (N >= 32 && K >= 32)
+                         : x3_mode == 3 ? (K >= 4096 && N >= 64 && N <= 256)
+                         : (x3_mode == 1 && N >= 64 && K >= 32 && !small_square));
+    const void* wx3 = nullptr;
+    if (use_x3) {
+        auto it = p.h->x3_weights.find(W);
+        if (it == p.h->x3_weights.end()) {
+            void* d = nullptr;
+            if (hipMalloc(&d, gemm_x3_weight_bytes(N, K)) == hipSuccess &&
+                launch_split_weights_x3(W, d, N, K, p.h->own_stream) == hipSuccess)
+                it = p.h->x3_weights.emplace(W, d).first;
+            else if (d) (void)hipFree(d);
+        }
+        if (it != p.h->x3_weights.end()) wx3 = it->second;
+    }
+    // the producer may write A directly as this kernel's [128][32] tiles (the fused trunk feeding fc1)
+    const int a_blocked = (a_blocked_inout && *a_blocked_inout && wx3 && K % 32 == 0 && rows_per_clip == 1) ? K / 32 : 0;
+    if (a_blocked_inout) *a_blocked_inout = a_blocked != 0;
+    if (K >= 2048 && (size_t)16 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)16 * rows_per_clip * N;
+    p.add("gemm:" + name, [=](Run& r) {
+        GemmArgs g;
+        g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;
+        g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
+        g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
+        g.Wx3 = wx3;
+        g.a_blocked = a_blocked;
+        g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
+        // split-operand layers: chunks of ~16-25 k-tiles, so that a small batch's chunk is ONE round of gemm_x3_chain_kernel
+        // (32 k-tiles in flight) on a few dozen CUs - K = 12 800: 16 chunks of 25, K = 6 464: 12 of 17, K = 3 920 (C1): 7 of 18
+        if (wx3 && x3_mode != 2 && K >= 2048) { g.splitk = K >= 8192 ? K / 800 : K / 512; if (g.splitk > 16) g.splitk = 16; if (g.splitk < 1) g.splitk = 1; }
+        g.splitk_ws = r.splitk_ws;
+        if (g.splitk > 1 && (size_t)g.splitk * g.M * N > r.splitk_floats) g.splitk = 1;
+        r.deferred.active = false;
+        // only the MFMA kernels leave split-K partials; the VALU fallback (K % 4 != 0 or an A pointer that is not 16-byte aligned)
+        // writes C itself, so nothing may be deferred to the consumer then
+        const bool partials = g.splitk > 1 && g.splitk_ws && gemm_writes_partials(g);
+        // a handful of clips (the interpreter's calls): the fused tail sums the partials itself, in the same order - one
+        // dependent launch less (B = 1: 62 -> 58 us back-to-back).  Larger batches keep the reduce launch: the tail's few
+        // workgroups read the 16 partials slower than the full-grid reduce does (B = 4096: 0.028 vs 0.019 + 0.007 ms).
+        if (feeds_tail && g.M <= 8 && partials && !g.res) {
+            g.defer_reduce = true;
+            r.deferred.active = true; r.deferred.out_id = out_id; r.deferred.parts = g.splitk; r.deferred.stride = (size_t)g.M * N;
+            r.deferred.bias = bias; r.deferred.alpha = alpha; r.deferred.beta = beta; r.deferred.act = act;
+        }
+        // a LayerNorm right behind a split-K Linear (DNN layer1) sums the partials itself, at every batch size: the reduce launch
+        // and its round trip go (the caller's LayerNorm step checks r.deferred)
+        if (feeds_ln && partials && !g.res && !alpha && act == ACT_NONE && N <= 256) {
+            g.defer_reduce = true;
+            r.deferred.active = true; r.deferred.out_id = out_id; r.deferred.parts = g.splitk; r.deferred.stride = (size_t)g.M * N;
+            r.deferred.bias = bias; r.deferred.alpha = nullptr; r.deferred.beta = nullptr; r.deferred.act = ACT_NONE;
+        }
+        return launch_gemm(g, r.stream);
+    });
+}
+
+// Short-K Linear on the input-stationary split-operand kernel (lin_x3.hip); false -> the caller plans the general GEMM.
+// epi 0: out = y + b; 1: out = res + rscale (y + b); 2: LayerNorm(ln_w, ln_b) first when given, W = [2N][K], out = a * sigmoid(b)
+bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K, const float* W,
+                const float* bias, int epi, int res_id = 99, float rscale = 1.f, const float* ln_w = nullptr,
+                const float* ln_b = nullptr, int qkv_T = 0, int qkv_dh = 0) {
+    static const int enabled = [] { const char* e = getenv("NWW_LIN_X3"); return e ? atoi(e) : 1; }();
+    if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N)) return false;
+    const int parts = epi == 2 ? 2 : 1;
+    void* packed = nullptr;
+    if (hipMalloc(&packed, lin_x3_packed_bytes(K, N, parts)) != hipSuccess) return false;
+    if (launch_lin_x3_pack(W, bias, packed, K, N, parts, N, p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+    p.h->packed_weights.push_back(packed);
+    p.need(out_id, (size_t)rows_per_clip * N);
+    p.add("lin_x3:" + name, [=](Run& r) {
+        LinArgs a;
+        a.x = src(r, in_id); a.ldx = K; a.out = dst(r, out_id); a.ldc = N;
+        a.res = res_id == 99 ? nullptr : src(r, res_id); a.ldres = N; a.rscale = rscale;
+        a.ln_w = ln_w; a.ln_b = ln_b; a.packed = static_cast<const unsigned char*>(packed);
+        a.M = r.B * rows_per_clip; a.N = N; a.qkv_T = qkv_T; a.qkv_dh = qkv_dh;
+        return launch_lin_x3(a, K, epi, ln_w != nullptr, r.stream);
+    });
+    return true;
+}
+
+void set_tail(PlanCtx& p, const std::string& name, int in_id, int K, const float* W, const float* b) {
+    p.tail_name = name; p.tail_in = in_id; p.tail_K = K; p.tail_W = W; p.tail_b = b;
+}
+
+void add_conv(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
+              const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool, int nhwc_out = 0) {
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    p.need(out_id, (size_t)Cout * Ho * Wo);
+    p.add("conv3x3:" + name, [=](Run& r) {
+        Conv3Args a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, Cin, Cout, H, W, act, pool};
+        a.nhwc_out = nhwc_out;
+        return launch_conv3x3(a, r.stream);
+    });
+}
+
+static int trunk_fits(int C1, int H, int W) { int per_cu = 0; return trunk_pick_strips(C1, H, W, &per_cu); }
+// fused conv1+pool+conv2+pool (trunk.hip) when the 1->16->32 pattern fits LDS; returns false if not applicable
+bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
+               const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
+               const float* b2, const float* al2, const float* be2, int act, const bool* out_blocked = nullptr) {
+    static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
+    if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
+    p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
+    const int max_grid = p.h->cu_count;
+    // both convolutions on the bf16 matrix cores by exact operand splitting (trunk_b.hip) or on the float32 MFMA (nww_config.conv_arith)
+    const int x3 = p.h->conv_products;
+    if ((x3 == 6 || x3 == 9) && trunk_b_pick_strips(H, W) > 0) {
+        // both convolutions' weights as the MFMA register images, split into bf16 terms once (trunk_b.hip)
+        void* packed = nullptr;
+        if (hipMalloc(&packed, trunk_b_packed_bytes()) != hipSuccess) return false;
+        if (launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+        p.h->packed_weights.push_back(packed);
+        p.add("trunk_x3:" + name, [=](Run& r) {
+            TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
+            if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
+            a.wpack = static_cast<const unsigned char*>(packed);
+            return launch_cnn_trunk_b(a, x3, max_grid, r.stream);
+        });
+        return true;
+    }
+    p.add("trunk:" + name, [=](Run& r) {
+        TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
+        return launch_cnn_trunk(a, C1, C2, max_grid, r.stream);
+    });
+    return true;
+}
+
+// 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
+bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
+                   const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0) {
+    static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+    if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
+        conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
+        return false;
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    p.need(out_id, avg_ow > 0 ? (size_t)Cout * avg_ow : (size_t)Cout * Ho * Wo);
+    const int max_grid = p.h->cu_count;
+    // split-operand bf16 instance (conv3_x3.hip) under the same arithmetic switch as the fused trunk; the 9-product
+    // mode keeps the float32-MFMA kernel (the conv3 instance implements the 6-product form only)
+    static const int x3_enabled = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
+    if (x3_enabled && p.h->conv_products == 6 && conv3_x3_fits(H, W, Cout, avg_ow, pool)) {
+        const size_t lds = conv3_x3_lds_bytes(H, W, avg_ow);
+        const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+        const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
+        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name, [=](Run& r) {
+            ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+            a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out; a.avg_y = avg_y;
+            return launch_conv3_x3(a, max_grid * per_cu, r.stream);
+        });
+        return true;
+    }
+    if (avg_y) return false;                                   // only conv3_x3 pools along y (the caller checked e2e_transposed_ok)
+    if (seq_inout) *seq_inout = false;                         // the float32-MFMA instance writes planes
+    p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
+        ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+        a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
+        return launch_conv3x3_mfma(a, Cin, max_grid, r.stream);
+    });
+    return true;
+}
+
+// The E2E head can run on the TRANSPOSED plane (frames, n_mels) = (101, 64) instead of (64, 101): the fused trunk's 32-pixel
+// conv1 groups and 16-column conv2 tiles waste 28 % on a 101-wide plane and nothing on a 64-wide one, conv3's 2 x 16 tiles 22 %
+// against 4 %, and the frontend's frames-major output is its fast path.  Needs the split-operand kernels (default arithmetic).
+bool e2e_transposed_ok(PlanCtx& p, int n_mels, int frames) {
+    static const int on = [] { const char* e = getenv("NWW_E2E_TRANSPOSED"); return e ? atoi(e) : 1; }();
+    static const int trunk_on = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
+    static const int mfma_on = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+    static const int c3_on = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
+    const int H = frames, W = n_mels;
+    return on && trunk_on && mfma_on && c3_on && p.h->conv_products == 6 && H >= 16 && W >= 4 && trunk_b_pick_strips(H, W) > 0 &&
+           conv_mfma_lds_bytes(32, H / 4, W / 4) <= 160 * 1024 && conv3_x3_fits(H / 4, W / 4, 64, 4, 0);
+}
+
+// nn.GRU / nn.LSTM (bidirectional; G = 3 / 4 gates) -> rnn_out[:, -1, :] into buffer `last_id` [B][2H]; uses buffers
+// xg_id, seqA, seqB.
+void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int I, int H, int layers, int xg_id,
+                    int seqA, int seqB, int last_id, int G = 3) {
+    p.need(xg_id, (size_t)(T + 1) * G * H);                  // + one row per clip: the reverse direction's last-frame projection
+    p.need(last_id, (size_t)2 * H);
+    const int products = p.h->conv_products;                 // the recurrent product follows the handle's arithmetic switch
+    GruArgs probe; probe.H = H; probe.products = products; probe.w_hh = nullptr;
+    const bool x3 = rnn_x3_enabled(probe);                    // (weights come from hipMalloc: 16-byte aligned)
+    int cur_in = in_id, cur_I = I;
+    for (int l = 0; l < layers; ++l) {
+        const bool last = l == layers - 1;
+        const int seq_out = (l % 2 == 0) ? seqA : seqB;
+        if (!last) p.need(seq_out, (size_t)T * 2 * H);
+        // rnn_out[:, -1] needs ONE step of the last layer's reverse direction, hence the input projection of frame T-1 only (a
+        // strided GEMM over M = B rows instead of B*T, into the row behind the forward direction's xg) - and with h = 0 that
+        // step has no recurrent product: rnn_x3 computes it in the forward direction's launch.
+        const bool fold = last && x3;
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
+            const float* wih = p.W(prefix + ".weight_ih" + sfx);
+            const float* whh = p.W(prefix + ".weight_hh" + sfx);
+            const float* bih = p.W(prefix + ".bias_ih" + sfx);
+            const float* bhh = p.W(prefix + ".bias_hh" + sfx);
+            if (last && dir) {
+                const int Iin = cur_I, in_buf = cur_in;
+                p.add("gemm:" + prefix + ".ih" + sfx + "(last frame)", [=](Run& r) {
+                    GemmArgs g;
+                    g.A = src(r, in_buf) + (size_t)(T - 1) * Iin; g.lda = T * Iin; g.W = wih;
+                    if (fold) { g.C = r.buf[xg_id] + (size_t)r.B * T * G * H; g.ldc = G * H; }      // behind the forward direction's rows
+                    else { g.C = r.buf[xg_id] + (size_t)(T - 1) * G * H; g.ldc = T * G * H; }       // in place (the forward recurrence is done)
+                    g.M = r.B; g.N = G * H; g.K = Iin; g.bias = bih; g.alpha = nullptr; g.beta = nullptr; g.act = ACT_NONE;
+                    g.res = nullptr; g.ldres = 0; g.rscale = 1.f;
+                    return launch_gemm(g, r.stream);
+                });
+            } else {
+                // short-K input projections (the GRU head's 64 mel bins) on the input-stationary kernel; the rest on the general GEMM
+                if (!add_lin_x3(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, 0))
+                    add_gemm(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, ACT_NONE);
+            }
+            if (fold && dir == 0) continue;                  // the forward recurrence is launched after the reverse projection
+            const int in_T = T;
+            const float* whh_f = fold ? p.W(prefix + ".weight_hh_l" + std::to_string(l)) : whh;
+            const float* bhh_f = fold ? p.W(prefix + ".bias_hh_l" + std::to_string(l)) : bhh;
+            const std::string nm = fold ? (G == 4 ? "lstm:" : "gru:") + prefix + "_l" + std::to_string(l) + " + first reverse step"
+                                        : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
+            p.add(nm, [=](Run& r) {
+                GruArgs a;
+                a.products = products;
+                a.xg = r.buf[xg_id]; a.w_hh = whh_f; a.b_hh = bhh_f;
+                a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
+                a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H;
+                a.B = r.B; a.T = in_T; a.H = H;
+                if (fold) {
+                    a.col_off = 0; a.reverse = 0; a.steps = in_T;
+                    a.xg2 = r.buf[xg_id] + (size_t)r.B * in_T * G * H; a.xg2_bstride = (size_t)G * H; a.b_hh2 = bhh; a.col_off2 = H;
+                } else {
+                    a.col_off = dir ? H : 0; a.reverse = dir;
+                    a.steps = (last && dir) ? 1 : in_T;      // reverse half of rnn_out[:, -1] is its first step
+                }
+                return G == 4 ? launch_lstm(a, r.stream) : launch_gru(a, r.stream);
+            });
+        }
+        cur_in = seq_out; cur_I = 2 * H;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ finalize
+extern "C" int nww_finalize(nww_handle* h) {
+    if (!h) return NWW_ERR_INVALID;
+    if (h->finalized) return NWW_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const nww_config& c = h->cfg;
+    for (const auto& k : h->keys)
+        if (!h->tensors[k].loaded) return fail(h, NWW_ERR_MISSING, "Missing key(s) in state_dict: '%s'", k.c_str());
+    // ---- fold every BatchNorm (eval): alpha = w/sqrt(var+eps), beta = b - mean*alpha (PyTorch CPU kernel form)
+    std::vector<std::string> bn_prefixes;
+    for (const auto& k : h->keys) {
+        const std::string sfx = ".running_var";
+        if (k.size() > sfx.size() && k.compare(k.size() - sfx.size(), sfx.size(), sfx) == 0)
+            bn_prefixes.push_back(k.substr(0, k.size() - sfx.size()));
+    }
+    for (const auto& p : bn_prefixes) {
+        const HostTensor &w = h->tensors[p + ".weight"], &b = h->tensors[p + ".bias"], &m = h->tensors[p + ".running_mean"],
+                         &v = h->tensors[p + ".running_var"];
+        HostTensor al, be;
+        al.shape = be.shape = w.shape;
+        al.data.resize(w.data.size()); be.data.resize(w.data.size());
+        for (size_t i = 0; i < w.data.size(); ++i) {
+            const float invstd = 1.0f / std::sqrt(v.data[i] + 1e-5f);
+            al.data[i] = w.data[i] * invstd;
+            be.data[i] = b.data[i] - m.data[i] * al.data[i];
+        }
+        al.loaded = be.loaded = true;
+        h->tensors[p + ".alpha"] = al;
+        h->tensors[p + ".beta"] = be;
+    }
+    // ---- depthwise 3x3 weights tap-major [9][C] for the channels-last kernels (BcResNet)
+    if (c.head_type == NWW_HEAD_BCRESNET)
+        for (int i = 1; i <= 3; ++i) {
+            const std::string k = "model.block" + std::to_string(i) + ".depthwise.weight";
+            const HostTensor& w = h->tensors[k];
+            const int C = (int)w.shape[0];
+            HostTensor wt;
+            wt.shape = {9, C};
+            wt.data.resize((size_t)9 * C);
+            for (int ch = 0; ch < C; ++ch)
+                for (int tap = 0; tap < 9; ++tap) wt.data[(size_t)tap * C + ch] = w.data[(size_t)ch * 9 + tap];
+            wt.loaded = true;
+            h->tensors[k + "_t"] = wt;
+        }
+    // ---- weight arena (each tensor 16-byte aligned)
+    size_t total = 0;
+    for (auto& kv : h->tensors) {
+        if (!kv.second.loaded || kv.first.rfind("frontend.", 0) == 0) continue;
+        kv.second.dev_off = total;
+        total += (kv.second.data.size() + 3) & ~(size_t)3;
+    }
+    HIP_TRY(h, hipMalloc(&h->d_weights, (total + 4) * sizeof(float)));
+    for (auto& kv : h->tensors) {
+        if (!kv.second.loaded || kv.first.rfind("frontend.", 0) == 0) continue;
+        HIP_TRY(h, hipMemcpy(h->d_weights + kv.second.dev_off, kv.second.data.data(), kv.second.data.size() * sizeof(float),
+                             hipMemcpyHostToDevice));
+    }
+    // ---- frontend tables
+    {
+        std::vector<float> win, fb;
+        auto wi = h->tensors.find("frontend.window");
+        if (wi != h->tensors.end() && wi->second.loaded) win = wi->second.data; else fe_default_window(h->fe.win_length, win);
+        auto fi = h->tensors.find("frontend.mel_fb");
+        if (fi != h->tensors.end() && fi->second.loaded) fb = fi->second.data; else fe_default_melfb(h->fe, fb);
+        FeTables tb;
+        const std::string e = fe_build_tables(h->fe, win.data(), fb.data(), &tb);
+        if (!e.empty()) return fail(h, NWW_ERR_INVALID, "frontend tables: %s", e.c_str());
+        const size_t tbytes = (sizeof(FeTables) + 15) & ~(size_t)15;
+        HIP_TRY(h, hipMalloc(&h->d_tables, tbytes));
+        HIP_TRY(h, hipMemset(h->d_tables, 0, tbytes));
+        HIP_TRY(h, hipMemcpy(h->d_tables, &tb, sizeof(FeTables), hipMemcpyHostToDevice));
+        h->mel_max_taps = 0;
+        for (int j = 0; j < h->fe.n_mels; ++j) h->mel_max_taps = tb.mel_cnt[j] > h->mel_max_taps ? tb.mel_cnt[j] : h->mel_max_taps;
+        std::vector<Fe2MelPlan> plan(1);
+        const std::string e2 = fe2_build_mel_plan(h->fe, fb.data(), plan.data());
+        if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
+        HIP_TRY(h, hipMalloc(&h->d_melplan, sizeof(Fe2MelPlan)));
+        HIP_TRY(h, hipMemcpy(h->d_melplan, plan.data(), sizeof(Fe2MelPlan), hipMemcpyHostToDevice));
+    }
+    // ---- plan
+    PlanCtx p{h};
+    const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks, act = c.activation;
+    switch (c.head_type) {
+        case NWW_HEAD_DNN: {                      // Net: architectures.py:110-126
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
+            {
+                const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
+                p.add("layernorm:layernorm1", [=](Run& r) {
+                    if (r.deferred.active && r.deferred.out_id == 0) {           // layer1 left its split-K partials: sum them here
+                        r.deferred.active = false;
+                        return launch_layernorm_parts(r.splitk_ws, r.deferred.parts, r.deferred.stride, r.deferred.bias, r.buf[0], lw1, lb1, r.B, L, act, r.stream);
+                    }
+                    return launch_layernorm(r.buf[0], r.buf[0], lw1, lb1, r.B, L, act, r.stream);
+                });
+            }
+            int cur = 0;
+            for (int i = 0; i < nb; ++i) {
+                const std::string q = "model.blocks." + std::to_string(i);
+                const int nxt = cur ^ 1;
+                add_gemm(p, q + ".fcn_layer", cur, nxt, 1, L, L, p.W(q + ".fcn_layer.weight"), p.W(q + ".fcn_layer.bias"), ACT_NONE);
+                const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
+                p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[nxt], r.buf[nxt], lw, lb, r.B, L, act, r.stream); });
+                cur = nxt;
+            }
+            set_tail(p, "last_layer", cur, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
+            break;
+        }
+        case NWW_HEAD_CNN: {                      // CNNModel: architectures.py:51-80
+            // trunk -> fc1 hand-over as the GEMM's own A tiles when both run on the split-operand path and the geometry allows
+            // 16-byte stores inside a 32-feature tile row
+            const int H2 = T / 4, W2 = F / 4;
+            h->trunk_blocked = (h->conv_products == 6 || h->conv_products == 9) && trunk_b_pick_strips(T, F) > 0 &&
+                               (W2 % 4) == 0 && ((H2 * W2) % 4) == 0 && ((32 * H2 * W2) % 32) == 0;
+            const bool fused = add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
+                                         p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked);
+            if (!fused) {
+                h->trunk_blocked = false;
+                add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
+                add_conv(p, "conv2", 0, 1, 16, 32, T / 2, F / 2, p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, 1);
+            }
+            // fc1's split-K partials are reduced by the classifier tail itself when that is the fused kernel
+            static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
+            add_gemm(p, "fc1", 1, 0, 1, 128, 32 * H2 * W2, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, nullptr, nullptr, 99, 1.f,
+                     &h->trunk_blocked, tail_on && tail_supported(128, E));
+            set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
+            break;
+        }
+        case NWW_HEAD_E2E_DNN: {                  // E2E_MelSpectrogram_CNN body: architectures.py:840-865,877-889
+            const int Hh = T, Ww = F;             // (n_mels, frames)
+            const int ch[3] = {16, 32, 64};
+            if (e2e_transposed_ok(p, Hh, Ww)) {
+                const int Ht = Ww, Wt = Hh;       // the plane the kernels see: (frames, n_mels)
+                float* wt = nullptr;
+                const int nf[3] = {16, 32 * 16, 64 * 32};
+                if (hipMalloc(&wt, (size_t)(nf[0] + nf[1] + nf[2]) * 9 * sizeof(float)) != hipSuccess) return fail(h, NWW_ERR_HIP, "hipMalloc failed");
+                p.h->packed_weights.push_back(wt);
+                float* wts[3] = {wt, wt + (size_t)nf[0] * 9, wt + (size_t)(nf[0] + nf[1]) * 9};
+                for (int i = 0; i < 3; ++i)
+                    if (launch_transpose3x3(p.W("model.conv_block." + std::to_string(4 * i) + ".weight"), wts[i], nf[i], p.h->own_stream) != hipSuccess)
+                        return fail(h, NWW_ERR_HIP, "weight transpose failed");
+                h->e2e_transposed = true;
+                p.need(2, (size_t)Hh * Ww);
+                p.add("transpose:mel-major features -> frames-major (skipped after the frontend)", [=](Run& r) {
+                    if (r.x_frames_major) return hipSuccess;
+                    const hipError_t e = launch_transpose_planes(r.x, r.buf[2], r.B, Hh, Ww, r.stream);
+                    r.x = r.buf[2];
+                    return e;
+                });
+                if (!add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
+                               p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
+                               p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act))
+                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed trunk does not fit");
+                const int h3 = Ht / 4, w3 = Wt / 4;           // (25, 16): AdaptiveAvgPool2d((1,4))'s windows run along the FRAMES, here y
+                const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
+                if (h3 < 4 || !add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
+                                   p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1))
+                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed third conv does not fit");
+                add_gemm(p, "fc1+bn1", 0, 1, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
+                set_tail(p, "out", 1, 128, p.W("model.out.weight"), p.W("model.out.bias"));
+                break;
+            }
+            int cin = 1, hh = Hh, ww = Ww, cur = -1;
+            int first = 0;
+            bool fused_pool = false;
+            if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
+                          p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
+                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act)) {
+                first = 2; cin = 32; hh = Hh / 4; ww = Ww / 4; cur = 1;
+            }
+            for (int i = first; i < 3; ++i) {
+                const std::string cw = "model.conv_block." + std::to_string(4 * i), bnp = "model.conv_block." + std::to_string(4 * i + 1);
+                const int out = (i % 2 == 0) ? 0 : 1;
+                if (i == 2 && ww >= 4) {
+                    // conv3 + AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form, fused when the MFMA kernel applies
+                    const int sw4 = ww / 4, kw4 = ww - 3 * sw4;
+                    if (add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4)) {
+                        fused_pool = true; cin = ch[i]; cur = out;
+                        continue;
+                    }
+                }
+                if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2))
+                    add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
+                if (i < 2) { hh /= 2; ww /= 2; }
+                cin = ch[i]; cur = out;
+            }
+            if (hh < 1 || ww < 4) return fail(h, NWW_ERR_INVALID, "e2e_dnn input too small for AdaptiveAvgPool2d((1,4))");
+            // AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form (_export/onnx.py:146-152)
+            const int sh = hh / 1, kh = hh, sw = ww / 4, kw = ww - 3 * sw;
+            int fc_in = cur;                                  // buffer holding [B][256] after the pool
+            if (!fused_pool) {
+                const int pin = cur, pout = cur ^ 1;
+                p.need(pout, 256);
+                p.add("avgpool:export(1,4)", [=](Run& r) { return launch_avgpool(r.buf[pin], r.buf[pout], r.B * 64, hh, ww, kh, kw, sh, sw, 1, 4, r.stream); });
+                fc_in = pout;
+            }
+            const int fc_out = fc_in ^ 1;
+            add_gemm(p, "fc1+bn1", fc_in, fc_out, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
+            set_tail(p, "out", fc_out, 128, p.W("model.out.weight"), p.W("model.out.bias"));
+            break;
+        }
+        case NWW_HEAD_CRNN: {                     // CRNNModel: architectures.py:209-287
+            int cin = 1, hh = T, ww = F, cur = -1;
+            int first = 0;
+            bool seq_written = false;
+            if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
+                add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
+                          p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
+                          p.W("model.cnn.5.beta"), act)) {
+                first = 2; cin = 32; hh = T / 4; ww = F / 4; cur = 1;
+            }
+            for (int i = first; i < c.n_crnn_channels; ++i) {
+                const std::string cw = "model.cnn." + std::to_string(4 * i), bnp = "model.cnn." + std::to_string(4 * i + 1);
+                const int out = (i % 2 == 0) ? 0 : 1;
+                // the last conv stage may write the recurrent layers' [W][C * H] sequence layout itself (conv3_x3.hip)
+                bool seq = i == c.n_crnn_channels - 1;
+                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq)) {
+                    seq = false;
+                    add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
+                }
+                seq_written = seq;
+                hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
+            }
+            if (hh < 1 || ww < 1) return fail(h, NWW_ERR_INVALID, "crnn input too small for the conv stack");
+            const int seq = seq_written ? cur : cur ^ 1, C = cin, Hc = hh, Wc = ww;
+            if (!seq_written) {
+                p.need(seq, (size_t)C * Hc * Wc);
+                p.add("crnn_seq", [=](Run& r) { return launch_crnn_seq(r.buf[cur], r.buf[seq], r.B, C, Hc, Wc, r.stream); });
+            }
+            add_bigru_last(p, "model.rnn", seq, Wc, C * Hc, L, nb, 2, seq ^ 1, 3, 4, c.crnn_rnn_lstm ? 4 : 3);      // seq ^ 1: the free one of buffers 0 / 1
+            set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
+            break;
+        }
+        case NWW_HEAD_GRU: {                      // GRUModel: architectures.py:129-145
+            add_bigru_last(p, "model.gru", -1, T, F, L, nb, 2, 0, 1, 4);
+            set_tail(p, "fc", 4, 2 * L, p.W("model.fc.weight"), p.W("model.fc.bias"));
+            break;
+        }
+        case NWW_HEAD_BCRESNET: {                 // BcResNetModel: architectures.py:620-687, channels-last on the GPU
+            // init conv (+BN+act+pool) writes [B][H1][W1][32]; each block: one depthwise kernel emits d = dw3x3(x) and
+            // xs = x at the strided centres, then two MFMA GEMMs over M = B*Ho*Wo pixels:
+            //   R = BN_s(xs . Wsc^T) ;  out = act(BN_1(d . Wpw^T)) + R      (activation BEFORE the residual add, :646-647)
+            static const int ic_mfma = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
+            // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
+            static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
+            const bool front_fused = ic_mfma && bc_front && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
+            // nww_config.act_dtype = NWW_ACT_DTYPE_BF16: every activation tensor between the kernels of this head is stored as bf16
+            // (arithmetic and accumulation stay float32); implemented on the fused front + split-operand block path only
+            const bool act_bf16 = c.act_dtype == NWW_ACT_DTYPE_BF16;
+            if (act_bf16 && !(front_fused && p.h->conv_products == 6))
+                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 needs the fused BcResNet front kernel and conv_arith bf16x6 for this input shape");
+            if (front_fused) {
+                const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
+                const float* dwt1 = p.W("model.block1.depthwise.weight_t");
+                const int ho1 = (T / 2 - 1) / 2 + 1, wo1 = (F / 2 - 1) / 2 + 1;
+                p.need(2, (size_t)32 * ho1 * wo1); p.need(3, (size_t)32 * ho1 * wo1);
+                const int max_grid = p.h->cu_count;
+                // the convolution from split operands on the bf16 matrix cores (trunk_b.hip) under the handle's arithmetic switch;
+                // NWW_BC_FRONT = 2 keeps the float32-MFMA kernel
+                void* fpack = nullptr;
+                const int fprod = p.h->conv_products;
+                if ((fprod == 6 || fprod == 9) && bc_front != 2 && bc_front_b_rows(T, F, 2) > 0 &&
+                    hipMalloc(&fpack, bc_front_b_packed_bytes()) == hipSuccess) {
+                    if (launch_bc_front_b_pack(w0, static_cast<unsigned char*>(fpack), p.h->own_stream) == hipSuccess) p.h->packed_weights.push_back(fpack);
+                    else { (void)hipFree(fpack); fpack = nullptr; }
+                }
+                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
+                    Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
+                    a.bf16_out = act_bf16 ? 1 : 0;
+                    if (fpack) {
+                        a.wpack = static_cast<const unsigned char*>(fpack);
+                        return launch_bc_front_b(a, fprod, max_grid, r.stream);
+                    }
+                    return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);
+                });
+            } else if (ic_mfma && conv1_pool_nhwc_mfma_fits(T, F)) {
+                const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
+                p.need(0, (size_t)32 * (T / 2) * (F / 2));
+                const int max_grid = p.h->cu_count;
+                p.add("conv1_mfma:init_conv(nhwc)", [=](Run& r) {
+                    Conv1NhwcArgs a{src(r, -1), w0, nullptr, a0, b0, r.buf[0], r.B, T, F, act};
+                    return launch_conv1_pool_nhwc_mfma(a, max_grid, r.stream);
+                });
+            } else {
+                add_conv(p, "init_conv(nhwc)", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1, 1);
+            }
+            int hh = T / 2, ww = F / 2, cur = 0;
+            const int ch[4] = {32, 64, 128, 256};
+            const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};
+            for (int i = 1; i <= 3; ++i) {
+                const std::string q = "model.block" + std::to_string(i);
+                const int ci = ch[i - 1], co = ch[i], sh = st[i - 1][0], sw = st[i - 1][1];
+                const int ho = (hh - 1) / sh + 1, wo = (ww - 1) / sw + 1;
+                const int dwb = 2, xsb = 3, resb = 4, outb = cur ^ 1;
+                p.need(dwb, (size_t)ci * ho * wo); p.need(xsb, (size_t)ci * ho * wo);
+                const float* dwt = p.W(q + ".depthwise.weight_t");
+                const int hin = hh, win = ww;
+                if (!(front_fused && i == 1))
+                    p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
+                // one dual GEMM per block: shortcut and pointwise products in the same workgroup, no residual round trip
+                {
+                    const float *wpw = p.W(q + ".pointwise.weight"), *a1 = p.W(q + ".bn1.alpha"), *b1 = p.W(q + ".bn1.beta");
+                    const float *wsc = p.W(q + ".shortcut.0.weight"), *as = p.W(q + ".shortcut.1.alpha"), *bs = p.W(q + ".shortcut.1.beta");
+                    const int rows = ho * wo;
+                    p.need(outb, (size_t)rows * co);
+                    // both products from split operands on the bf16 matrix cores (dual_x3.hip) under the same arithmetic switch
+                    static const int dual_x3 = [] { const char* e = getenv("NWW_BC_DUAL_X3"); return e ? atoi(e) : 1; }();
+                    void* packed = nullptr;
+                    if (dual_x3 && p.h->conv_products == 6 && dual_x3_supported(ci, co) &&
+                        hipMalloc(&packed, dual_x3_packed_bytes(ci, co)) == hipSuccess) {
+                        if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream) == hipSuccess) {
+                            p.h->packed_weights.push_back(packed);
+                            // when the block input is in HBM (every block but the one whose depthwise ran inside the fused front kernel) the
+                            // shortcut rows are gathered from it and the depthwise kernel planned just above writes no copy of them
+                            const bool gather = !(front_fused && i == 1);
+                            if (gather) {
+                                p.pop_last();
+                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act_bf16); });
+                            }
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
+                                DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
+                                if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
+                                a.bf16 = act_bf16 ? 1 : 0;
+                                return launch_dual_x3(a, ci, act, r.stream);
+                            });
+                            hh = ho; ww = wo; cur = outb;
+                            continue;
+                        }
+                        (void)hipFree(packed);
+                    }
+                    if (act_bf16) return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16: block %d has no split-operand kernel (channels %d -> %d)", i, ci, co);
+                    p.add("gemm2:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
+                        GemmArgs g;
+                        g.A = r.buf[dwb]; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;
+                        g.A2 = r.buf[xsb]; g.lda2 = ci; g.W2 = wsc; g.K2 = ci; g.alpha2 = as; g.beta2 = bs;
+                        g.C = r.buf[outb]; g.ldc = co; g.M = r.B * rows; g.N = co;
+                        g.res = nullptr; g.ldres = 0; g.rscale = 1.0f;
+                        return launch_gemm(g, r.stream);
+                    });
+                    (void)resb;
+                }
+                hh = ho; ww = wo; cur = outb;
+            }
+            const int hw = hh * ww;
+            p.need(2, 256);
+            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream, act_bf16); });
+            set_tail(p, "fc", 2, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));
+            break;
+        }
+        case NWW_HEAD_CONFORMER: {                // ConformerModel: architectures.py:441-543
+            const int D = c.conformer_d_model, NH = c.conformer_n_head;
+            const int hb = 0, t1 = 1, t3 = 2, big = 3;      // h, LN/glu/attn scratch, dwconv scratch, wide scratch
+            bool last_fused = false;
+            p.need(t1, (size_t)T * D); p.need(t3, (size_t)T * D);
+            if (!add_lin_x3(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), 0))
+                add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
+            for (int i = 0; i < nb; ++i) {
+                const std::string q = "model.conformer_blocks." + std::to_string(i);
+                auto ffn = [&](const std::string& ff) {
+                    const float *lw = p.W(q + ff + ".layer_norm.weight"), *lb = p.W(q + ff + ".layer_norm.bias");
+                    // LayerNorm + linear1 + swish + linear2 + half-step residual in one kernel (ffn_x3.hip); same arithmetic
+                    // switch as the split-operand GEMMs it replaces
+                    static const int fused = [] { const char* e = getenv("NWW_FFN_FUSED"); return e ? atoi(e) : 1; }();
+                    if (fused && p.h->conv_products == 6 && ffn_x3_supported(D)) {
+                        void* packed = nullptr;
+                        if (hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
+                            launch_ffn_x3_pack(p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"),
+                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream) == hipSuccess) {
+                            p.h->packed_weights.push_back(packed);
+                            const float* b2 = p.W(q + ff + ".linear2.bias");
+                            p.add("ffn_x3:" + q + ff + " (ln+linear1+swish+linear2+0.5res)", [=](Run& r) {
+                                FfnArgs a{r.buf[hb], lw, lb, static_cast<const unsigned char*>(packed), b2, r.B * T, 0.5f};
+                                return launch_ffn_x3(a, D, r.stream);
+                            });
+                            return;
+                        }
+                        if (packed) (void)hipFree(packed);
+                    }
+                    p.add("layernorm:" + q + ff, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                    add_gemm(p, q + ff + ".linear1+swish", t1, big, T, 4 * D, D, p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"), ACT_SILU);
+                    add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
+                };
+                ffn(".ff1");
+                // in_proj writes q, k, v head-major when the matrix-core attention consumes them: every (clip, head) block is then
+                // one contiguous run for its LDS-DMA (NWW_QKV_HEAD_MAJOR=0: nn.Linear's [B][T][3 D] rows)
+                static const int mha_mfma0 = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
+                const bool want_hm = mha_mfma0 && mha_mfma_supported(T, D, NH) && 3 * D <= 1024;
+                bool head_major = false;
+                if (add_lin_x3(p, q + (want_hm ? ".attention.in_proj(head-major)" : ".attention.in_proj"), hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), 0,
+                               99, 1.f, nullptr, nullptr, want_hm ? T : 0, want_hm ? D / NH : 0))
+                    head_major = want_hm;
+                else
+                    add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
+                static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
+                if (mha_mfma && mha_mfma_supported(T, D, NH))
+                    p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream, head_major ? 1 : 0); });
+                else
+                    p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
+                if (!add_lin_x3(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), 1, hb, 1.0f))
+                    add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                {
+                    const std::string m = q + ".conv_module";
+                    const float *lw = p.W(m + ".layer_norm.weight"), *lb = p.W(m + ".layer_norm.bias");
+                    // LayerNorm + pointwise conv1 + GLU in one launch (lin_x3.hip), else the three separate ones
+                    if (!add_lin_x3(p, m + ".layer_norm+conv1(pw)+glu", hb, t1, T, D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), 2, 99, 1.f, lw, lb)) {
+                        p.add("layernorm:" + m, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                        add_gemm(p, m + ".conv1(pw)", t1, big, T, 2 * D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), ACT_NONE);
+                        p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
+                    }
+                    const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
+                    const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
+                    p.add("dwconv1d+bn+swish:" + m, [=](Run& r) { return launch_dwconv1d_bn_swish(r.buf[t1], dw, db, ba, bb, r.buf[t3], r.B, T, D, 31, r.stream); });
+                    if (!add_lin_x3(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), 1, hb, 1.0f))
+                        add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                }
+                ffn(".ff2");
+                const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
+                // the last block's LayerNorm feeds only the mean over time: one pass for both (NWW_LN_MEAN=0: two launches)
+                if (i == nb - 1 && D <= 256) {
+                    p.add("layernorm+mean:" + q + " + time", [=](Run& r) { return launch_ln_mean(r.buf[hb], r.buf[t1], lw, lb, r.B, T, D, r.stream); });
+                    last_fused = true;
+                } else {
+                    p.add("layernorm:" + q, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[hb], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
+                }
+            }
+            if (!last_fused) p.add("mean:time", [=](Run& r) { return launch_mean_mid(r.buf[hb], r.buf[t1], r.B, T, D, r.stream); });
+            set_tail(p, "output_proj", t1, D, p.W("model.output_proj.weight"), p.W("model.output_proj.bias"));
+            break;
+        }
+    }
+    // embedding Linear + Model.classifier (model.py:291-296) (+ sigmoid) -> emb [B][E], logits [B] (, probs [B])
+    static const int tail_fused = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
+    if (tail_fused && tail_supported(p.tail_K, E)) {
+        const float *We = p.tail_W, *be = p.tail_b, *W0 = p.W("classifier.0.weight"), *b0 = p.W("classifier.0.bias"),
+                    *w3 = p.W("classifier.3.weight"), *b3 = p.W("classifier.3.bias");
+        const int tin = p.tail_in, tK = p.tail_K;
+        p.add("tail:" + p.tail_name + "+classifier", [=](Run& r) {
+            TailArgs t{src(r, tin), tK, We, be, E, W0, b0, w3, b3, r.emb, r.logits, r.probs, r.B, act};
+            if (r.deferred.active && r.deferred.out_id == tin) {
+                t.parts = r.splitk_ws; t.nparts = r.deferred.parts; t.part_stride = r.deferred.stride;
+                t.in_bias = r.deferred.bias; t.in_alpha = r.deferred.alpha; t.in_beta = r.deferred.beta; t.in_act = r.deferred.act;
+            }
+            r.deferred.active = false;
+            r.need_sigmoid = false;
+            if (r.done_flag && r.B <= 16) { t.done_flag = r.done_flag; t.done_seq = r.done_seq; r.done_armed = true; }
+            return launch_classifier_tail(t, r.stream);
+        });
+    } else {
+        add_gemm(p, p.tail_name, p.tail_in, -2, 1, E, p.tail_K, p.tail_W, p.tail_b, ACT_NONE);
+        add_gemm(p, "classifier.0", -2, -3, 1, E / 2, E, p.W("classifier.0.weight"), p.W("classifier.0.bias"), act);
+        add_gemm(p, "classifier.3", -3, -4, 1, 1, E / 2, p.W("classifier.3.weight"), p.W("classifier.3.bias"), ACT_NONE);
+    }
+    // the plan-time weight packings above were enqueued on own_stream; a forward may arrive on any caller stream
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    h->finalized = true;
+    return NWW_OK;
+}
+

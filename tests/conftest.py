@@ -80,6 +80,21 @@ def golden_heads_r02():
     return d, meta
 
 
+@pytest.fixture(scope="session")
+def golden_heads_r04():
+    """round-4 reference goldens (tools/make_goldens.py::make_round4_goldens): the distilled lite gate, DNN inputs that are not a
+    multiple of 4, recurrent widths > 256 / not a multiple of 4, Conformer head dims outside the compiled set"""
+    z = np.load(os.path.join(GOLDEN, "heads_r04.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    meta = json.loads(str(d.pop("meta_json")))
+    return d, meta
+
+
+def head_case_names_r04():
+    z = np.load(os.path.join(GOLDEN, "heads_r04.npz"), allow_pickle=False)
+    return sorted(json.loads(str(z["meta_json"])).keys())
+
+
 def head_case_names_r02():
     z = np.load(os.path.join(GOLDEN, "heads_r02.npz"), allow_pickle=False)
     return sorted(json.loads(str(z["meta_json"])).keys())

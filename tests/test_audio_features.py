@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN
 from fake_models import fake_embed, fake_mel
-from nanowakeword_amd.audio_features import WindowedFeatures
+from oracle.audio_features import WindowedFeatures
 from nanowakeword_amd.interpreter import HipInterpreter
 from nanowakeword_amd.synth import synth_pcm
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import head_case_names_r02
+from conftest import head_case_names_r02, head_case_names_r04
 from nanowakeword_amd.config import FrontendConfig, HeadConfig
 from nanowakeword_amd.synth import synth_features, synth_pcm, synth_state_dict
 from parity import logit_bounds
@@ -343,3 +343,96 @@ def test_bcresnet_bf16_activations(HipModel, golden_frontend):
     mbf.close(); m32.close()
     with pytest.raises(Exception, match="BcResNet"):
         HipModel(HeadConfig("cnn", (101, 64)), FrontendConfig(), act_dtype="bf16")
+
+
+# cases of heads_r04.npz the library still refuses at nww_create (VERDICT r03 "widen the refusals"); removed from this set
+# as their kernels land
+R04_REFUSED = {"gru_16x96_h130", "gru_16x96_h320_b2", "crnn_lstm_16x96_h512", "crnn_gru_101x64_h300", "crnn_lstm_98x40_h21",
+               "conformer_16x96_d100_h4", "conformer_101x64_d160_h2", "conformer_16x96_d66_h6"}
+
+
+@pytest.mark.parametrize("name", head_case_names_r04())
+def test_round4_heads_vs_reference(HipModel, golden_heads_r04, golden_frontend, name):
+    """The reference's distilled lite gate (distill.py:45-76: DNN 8 / 1 / 8), DNN inputs with K % 4 != 0 (the split-K / VALU seam),
+    recurrent widths and attention head dims beyond the first kernel set - against goldens made by the reference classes."""
+    d, meta = golden_heads_r04
+    g = golden_frontend
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    n_mels = 40 if cfg.input_shape == (98, 40) else 64
+    fe = FrontendConfig(n_mels=n_mels, center=n_mels == 64)
+    if name in R04_REFUSED:
+        with pytest.raises(NotImplementedError):
+            HipModel(cfg, fe, state_dict=sd, window=g["window"], mel_fb=g["fb64"] if n_mels == 64 else g["fb40"])
+        return
+    m = HipModel(cfg, fe, state_dict=sd, window=g["window"], mel_fb=g["fb64"] if n_mels == 64 else g["fb40"])
+    feats = synth_features(4, cfg.input_shape)
+    logits, probs, emb = m.forward_features(feats, return_embedding=True)
+    ref = d[f"{name}/logits_feat"].ravel()
+    assert np.abs(logits - ref).max() <= 1e-4, (name, np.abs(logits - ref).max())
+    assert np.abs(probs - oracle.sigmoid(ref)).max() <= 1e-5
+    e_ref = d[f"{name}/emb_feat"]
+    assert np.abs(emb - e_ref).max() <= 1e-4 * max(1.0, np.abs(e_ref).max())
+    for B in (1, 9, 33, 130):                               # ragged batches; B <= 8 and > 8 take different split-K reduce paths
+        fx = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(fx)
+        assert np.abs(lg - oracle.model_forward(fx, sd, cfg).ravel()).max() <= 1e-4, (name, B)
+        l1, _ = m.forward_features(fx[:1])
+        assert l1[0] == lg[0], (name, B, "batch dependence")
+    if f"{name}/logits_pcm" in d and cfg.input_shape in ((101, 64), (98, 40)):
+        lp, _ = m.forward_pcm(g["pcm"])
+        rp = d[f"{name}/logits_pcm"].ravel()
+        center = n_mels == 64
+        fb = g["fb64"] if center else g["fb40"]
+        lm32 = oracle.frontend_logmel(g["pcm"], g["window"], fb, n_mels=n_mels, center=center).transpose(0, 2, 1)
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], fb, n_mels=n_mels, center=center, dtype=np.float64).astype(np.float32).transpose(0, 2, 1)
+        bound = logit_bounds([str(n) for n in g["names"]], rp, oracle.model_forward(np.ascontiguousarray(lm32), sd, cfg).ravel(),
+                             oracle.model_forward(np.ascontiguousarray(lm64), sd, cfg).ravel())
+        assert np.all(np.abs(lp - rp) <= bound), (name, np.abs(lp - rp), bound)
+    m.close()
+
+
+def test_lite_gate_cascade(tmp_path, golden_heads_r04):
+    """`load_model(cascade=True)` finds `<name>_lite` next to the main model (nanointerpreter.py:310-325) - here the reference's
+    distilled student shape (distill.py:45-76) - evaluates it first and skips the verifier while the gate is closed."""
+    from nanowakeword_amd.interpreter import HipInterpreter
+    from nanowakeword_amd.weights import infer_head_config, save_bundle
+    d, meta = golden_heads_r04
+    main = HeadConfig("dnn", (16, 96))
+    lite = HeadConfig(**meta["lite_dnn_16x96"])
+    sd_main, sd_lite = synth_state_dict(main), synth_state_dict(lite)
+    inferred = infer_head_config(sd_lite, input_shape=(16, 96))
+    assert (inferred.layer_dim, inferred.n_blocks, inferred.embedding_dim) == (8, 1, 8)
+    save_bundle(os.path.join(tmp_path, "kw.nww.npz"), main, sd_main, mode="features")
+    save_bundle(os.path.join(tmp_path, "kw_lite.nww.npz"), inferred, sd_lite, mode="features")
+
+    class Pre:                                              # AudioFeatures protocol with scripted features
+        def __init__(self):
+            self.feature_buffer = np.zeros((0, 96), np.float32); self.n = 0; self.k = 0
+
+        def __call__(self, x):
+            self.n += len(x)
+            k, self.n = divmod(self.n, 1280)
+            for _ in range(k):
+                self.feature_buffer = np.vstack([self.feature_buffer, synth_features(1, (1, 96), seed=100 + self.k)[0]])[-120:]
+                self.k += 1
+            return k * 1280
+
+        def get_features(self, n):
+            return self.feature_buffer[-n:][None]
+
+        def reset(self):
+            self.__init__()
+
+    x = synth_pcm("noise", 1, 1280)[0]
+    for thr, closed in ((0.0, False), (1.1, True)):
+        pre = Pre()
+        it = HipInterpreter.load_model(os.path.join(tmp_path, "kw.nww.npz"), cascade=True, gate_threshold=thr, preprocessor=pre)
+        assert it.is_cascade and it.gate_name == "kw_lite" and list(it.models) == ["kw_lite", "kw"]
+        for _ in range(24):
+            r = it.predict(x)
+        feats = pre.get_features(16)
+        g_ref = float(oracle.sigmoid(oracle.model_forward(feats, sd_lite, lite))[0, 0])
+        v_ref = float(oracle.sigmoid(oracle.model_forward(feats, sd_main, main))[0, 0])
+        assert abs(r.gate_score - g_ref) <= 1e-5
+        assert (r.score == 0.0 and it.raw_scores["kw"] == 0.0) if closed else abs(r.score - v_ref) <= 1e-5

@@ -10,39 +10,52 @@ from nanowakeword_amd.config import FrontendConfig, HeadConfig
 from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_features, synth_state_dict
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-worst = 0.0
-for case in range(n_cases):
-    kind = rng.choice(["conformer", "crnn", "bcresnet", "cnn", "e2e_dnn"])
-    act = str(rng.choice(["relu", "gelu", "silu"]))
-    if kind == "conformer":
-        d, nh = [(32, 2), (32, 8), (64, 4), (96, 4), (96, 2), (128, 4), (144, 4), (144, 8), (80, 4)][rng.integers(0, 9)]
-        cfg = HeadConfig("conformer", (int(rng.integers(3, 140)), int(rng.choice([32, 40, 64]))), embedding_dim=16,
-                         conformer_d_model=d, conformer_n_head=nh, activation=act)
-    elif kind == "crnn":
-        cfg = HeadConfig("crnn", (int(rng.integers(16, 120)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
-                         crnn_rnn_type=str(rng.choice(["gru", "lstm"])), layer_dim=int(rng.choice([32, 48, 64])))
-    elif kind == "bcresnet":
-        cfg = HeadConfig("bcresnet", (int(rng.integers(16, 110)), int(rng.choice([32, 40, 64]))), embedding_dim=16, activation=act)
-    elif kind == "cnn":
-        cfg = HeadConfig("cnn", (int(rng.integers(8, 120)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act)
-    else:
-        cfg = HeadConfig("e2e_dnn", (int(rng.choice([32, 40, 64])), int(rng.integers(32, 130))), embedding_dim=16, activation=act)
-    B = int(rng.choice([1, 2, 5, 17, 33, 130]))
-    try:
-        sd = synth_state_dict(cfg)
-        m = HipModel(cfg, FrontendConfig(n_mels=cfg.input_shape[1] if kind != "e2e_dnn" else cfg.input_shape[0]), state_dict=sd)
-    except (NotImplementedError, ValueError) as e:
-        print(f"case {case}: {kind} {cfg.input_shape} refused at create: {str(e)[:80]}")
-        continue
-    x = synth_features(B, cfg.input_shape, seed=case)
-    lg, _ = m.forward_features(x)
-    ref = oracle.model_forward(x, sd, cfg).ravel()
-    err = float(np.abs(lg - ref).max())
-    worst = max(worst, err)
-    flag = "" if err <= 1e-4 else "   <-- FAIL"
-    print(f"case {case}: {kind} {cfg.input_shape} B={B} act={act} max|dlogit| {err:.2e}{flag}")
-    m.close()
-print("WORST", worst)
-sys.exit(0 if worst <= 1e-4 else 1)
+
+def run(n_cases=40, seed=0, log=print):
+    """-> (worst |dlogit|, cases that ran)"""
+    rng = np.random.default_rng(seed)
+    worst, ran = 0.0, 0
+    for case in range(n_cases):
+        kind = rng.choice(["conformer", "crnn", "bcresnet", "cnn", "e2e_dnn", "dnn", "gru"])
+        act = str(rng.choice(["relu", "gelu", "silu"]))
+        if kind == "conformer":
+            d, nh = [(32, 2), (32, 8), (64, 4), (96, 4), (96, 2), (128, 4), (144, 4), (144, 8), (80, 4)][rng.integers(0, 9)]
+            cfg = HeadConfig("conformer", (int(rng.integers(3, 140)), int(rng.choice([32, 40, 64]))), embedding_dim=16,
+                             conformer_d_model=d, conformer_n_head=nh, activation=act)
+        elif kind == "crnn":
+            cfg = HeadConfig("crnn", (int(rng.integers(16, 120)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
+                             crnn_rnn_type=str(rng.choice(["gru", "lstm"])), layer_dim=int(rng.choice([32, 48, 64])))
+        elif kind == "bcresnet":
+            cfg = HeadConfig("bcresnet", (int(rng.integers(16, 110)), int(rng.choice([32, 40, 64]))), embedding_dim=16, activation=act)
+        elif kind == "cnn":
+            cfg = HeadConfig("cnn", (int(rng.integers(8, 120)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act)
+        elif kind == "dnn":                                 # any flattened size (K % 4 != 0 included), tiny to default widths
+            cfg = HeadConfig("dnn", (int(rng.integers(4, 110)), int(rng.choice([32, 40, 41, 63, 64, 96]))), activation=act,
+                             layer_dim=int(rng.choice([8, 20, 32, 128])), n_blocks=int(rng.integers(0, 3)), embedding_dim=int(rng.choice([8, 16, 64])))
+        elif kind == "gru":
+            cfg = HeadConfig("gru", (int(rng.integers(4, 110)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
+                             layer_dim=int(rng.choice([32, 48, 64, 128])), n_blocks=int(rng.integers(1, 3)))
+        else:
+            cfg = HeadConfig("e2e_dnn", (int(rng.choice([32, 40, 64])), int(rng.integers(32, 130))), embedding_dim=16, activation=act)
+        B = int(rng.choice([1, 2, 5, 17, 33, 130]))
+        try:
+            sd = synth_state_dict(cfg)
+            m = HipModel(cfg, FrontendConfig(n_mels=min(cfg.input_shape[1], 128) if kind != "e2e_dnn" else cfg.input_shape[0]), state_dict=sd)
+        except (NotImplementedError, ValueError) as e:
+            log(f"case {case}: {kind} {cfg.input_shape} refused at create: {str(e)[:80]}")
+            continue
+        x = synth_features(B, cfg.input_shape, seed=case)
+        lg, _ = m.forward_features(x)
+        ref = oracle.model_forward(x, sd, cfg).ravel()
+        err = float(np.abs(lg - ref).max())
+        worst, ran = max(worst, err), ran + 1
+        flag = "" if err <= 1e-4 else "   <-- FAIL"
+        log(f"case {case}: {kind} {cfg.input_shape} B={B} act={act} max|dlogit| {err:.2e}{flag}")
+        m.close()
+    return worst, ran
+
+
+if __name__ == "__main__":
+    worst, ran = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("WORST", worst, "of", ran, "cases")
+    sys.exit(0 if worst <= 1e-4 else 1)

@@ -289,6 +289,7 @@ def main():
     make_audio_features_traces(os.path.join(args.out, "audio_features_trace.json"))
     make_onnx_fixtures(os.path.join(args.out, "onnx"))
     make_round2_goldens(args.out)
+    make_round4_goldens(args.out)
     print("done ->", args.out)
 
 
@@ -452,6 +453,84 @@ def make_round2_goldens(out_dir):
     np.savez_compressed(os.path.join(out_dir, "heads_r02.npz"), **heads)
 
 
+def make_round4_goldens(out_dir):
+    """Round-4 additions (own file: earlier fixtures stay byte-identical):
+      * the reference's distilled "lite" gate - the student `_build_student` builds (nanowakeword/train/distill.py:45-76: DNN,
+        layer_size 8, n_blocks 1, embedding_dim 8 -> classifier 8 -> 4 -> 1), the model `load_model(cascade=True)` looks for
+        (nanointerpreter.py:310-325); built by calling the reference function itself with a DNN teacher;
+      * a DNN whose flattened input is >= 2048 and NOT a multiple of 4 (the split-K / VALU-fallback seam);
+      * recurrent widths outside the register-resident kernels (> 256, not a multiple of 4) and Conformer head dims outside the
+        compiled set: shapes nn.GRU / nn.LSTM / nn.MultiheadAttention accept (architectures.py:132-145,238-254,499)."""
+    install_stubs()
+    torch.set_num_threads(1)
+    from nanowakeword.modules.model import Model
+    from nanowakeword_amd.config import HeadConfig, param_spec
+    from nanowakeword_amd.synth import synth_features, synth_state_dict, state_dict_checksum
+    fr = dict(np.load(os.path.join(out_dir, "frontend.npz"), allow_pickle=False))
+    db64, db40 = fr["db64"], fr["db40"]
+    for name in ("tqdm",):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                mod = types.ModuleType(name); mod.tqdm = lambda it, *a, **k: it; sys.modules[name] = mod
+    from nanowakeword.train import distill as ref_distill
+
+    def load(m, cfg, sd_np):
+        ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")}
+        assert ref_keys == dict(param_spec(cfg)), set(ref_keys) ^ set(param_spec(cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        return m.eval()
+
+    def ref_model(cfg, sd_np):
+        conf = {"activation_function": cfg.activation, "embedding_dim": cfg.embedding_dim,
+                "crnn_cnn_channels": list(cfg.crnn_cnn_channels), "crnn_rnn_type": cfg.crnn_rnn_type,
+                "conformer_d_model": cfg.conformer_d_model, "conformer_n_head": cfg.conformer_n_head}
+        m = Model(conf, "g", input_shape=cfg.input_shape, model_type=cfg.model_type, layer_dim=cfg.layer_dim, n_blocks=cfg.n_blocks)
+        return load(m, cfg, sd_np)
+
+    def lite_model(cfg, sd_np):
+        teacher = Model({"activation_function": "relu", "embedding_dim": 64}, "g", input_shape=cfg.input_shape, model_type="dnn")
+        student = ref_distill._build_student(teacher, cfg.input_shape, {})
+        assert student.model_name == "g_lite"
+        return load(student, cfg, sd_np)
+
+    lite = dict(layer_dim=8, n_blocks=1, embedding_dim=8)
+    cases = [
+        ("lite_dnn_16x96", HeadConfig("dnn", (16, 96), **lite), lite_model),
+        ("lite_dnn_101x64", HeadConfig("dnn", (101, 64), **lite), lite_model),
+        ("lite_dnn_98x40", HeadConfig("dnn", (98, 40), **lite), lite_model),
+        ("dnn_101x41", HeadConfig("dnn", (101, 41)), ref_model),                       # K = 4141: >= 2048 and K % 4 == 1
+        ("dnn_33x63_l20", HeadConfig("dnn", (33, 63), layer_dim=20, embedding_dim=10), ref_model),   # K = 2079, N = 20: nothing a multiple of 4
+        ("gru_16x96_h130", HeadConfig("gru", (16, 96), layer_dim=130), ref_model),     # not a multiple of 4
+        ("gru_16x96_h320_b2", HeadConfig("gru", (16, 96), layer_dim=320, n_blocks=2), ref_model),   # > 256
+        ("crnn_lstm_16x96_h512", HeadConfig("crnn", (16, 96), layer_dim=512, crnn_rnn_type="lstm"), ref_model),
+        ("crnn_gru_101x64_h300", HeadConfig("crnn", (101, 64), layer_dim=300), ref_model),
+        ("crnn_lstm_98x40_h21", HeadConfig("crnn", (98, 40), layer_dim=21, crnn_rnn_type="lstm"), ref_model),
+        ("conformer_16x96_d100_h4", HeadConfig("conformer", (16, 96), conformer_d_model=100, conformer_n_head=4), ref_model),   # head dim 25
+        ("conformer_101x64_d160_h2", HeadConfig("conformer", (101, 64), conformer_d_model=160, conformer_n_head=2), ref_model),  # head dim 80
+        ("conformer_16x96_d66_h6", HeadConfig("conformer", (16, 96), conformer_d_model=66, conformer_n_head=6), ref_model),      # head dim 11
+    ]
+    heads, meta = {}, {}
+    for name, cfg, build in cases:
+        sd = synth_state_dict(cfg)
+        m = build(cfg, sd)
+        feats = synth_features(4, cfg.input_shape)
+        with torch.no_grad():
+            out = {"logits_feat": m(torch.from_numpy(feats)).numpy(), "emb_feat": m.model(torch.from_numpy(feats)).numpy()}
+            if cfg.input_shape == (101, 64):
+                out["logits_pcm"] = m(torch.from_numpy(np.ascontiguousarray(db64.transpose(0, 2, 1)))).numpy()
+            if cfg.input_shape == (98, 40):
+                out["logits_pcm"] = m(torch.from_numpy(np.ascontiguousarray(db40.transpose(0, 2, 1)))).numpy()
+        out["sd_checksum"] = np.array(state_dict_checksum(sd))
+        meta[name] = cfg.to_dict()
+        for k, v in out.items():
+            heads[f"{name}/{k}"] = v
+        print("r04", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+    heads["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out_dir, "heads_r04.npz"), **heads)
+
+
 def make_wire_fixtures(path):
     """Messages produced by the reference's own encoders (remote_verifier.py:147-158) for tests/test_wire.py."""
     from nanowakeword.interpreter import remote_verifier as rv
@@ -597,6 +676,8 @@ def make_onnx_fixtures(outdir):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--onnx-only":
         make_onnx_fixtures(os.path.join(REPO, "tests", "golden", "onnx"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--r04-only":
+        make_round4_goldens(os.path.join(REPO, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--r02-only":
         make_round2_goldens(os.path.join(REPO, "tests", "golden"))
     else:

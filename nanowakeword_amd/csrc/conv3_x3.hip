@@ -189,11 +189,16 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     const int py = stager ? tid / W : 0, px = stager ? tid - py * W : 0;
     unsigned char* my_px = A3 + ((py + 1) * Wp + px + 1) * PS3;
     float pre[C1];
+    // dense planes [B][32][H][W], or (streaming hop) per-clip rings of rows written by the fused trunk: row py of the window at
+    // ring row (in_row0 + py) % in_ring_rows
+    const size_t in_clip = a.in_ring_rows ? a.in_clip_stride : (size_t)C1 * HW;
+    const size_t in_ch = a.in_ring_rows ? a.in_ch_stride : (size_t)HW;
+    const int in_px = a.in_ring_rows ? ((a.in_row0 + py) % a.in_ring_rows) * W + px : tid;
     auto prefetch = [&](int b) {
         if (stager && b < a.B) {
-            const float* xin = a.in + (size_t)b * C1 * HW + tid;
+            const float* xin = a.in + (size_t)b * in_clip + in_px;
 #pragma unroll
-            for (int c = 0; c < C1; ++c) pre[c] = xin[(size_t)c * HW];
+            for (int c = 0; c < C1; ++c) pre[c] = xin[(size_t)c * in_ch];
         }
     };
     // per-lane avg-pool partials live in the 16 pad bytes of pixels 0..511 (never read by the MFMAs, never written by

@@ -63,9 +63,11 @@ __device__ __forceinline__ float fe2_db(float mel, float amin, float mult, float
 #define FE2_PARAMS                                                                                                      \
     const int16_t *__restrict__ pcm, size_t row_stride, int B, int N, int T, int ngroups, int hop, int pad, int n_mels,    \
         float amin, float db_mult, float floor_db, const FeTables *__restrict__ gtb, const Fe2MelPlan *__restrict__ plan,  \
-        float *__restrict__ out_db, float *__restrict__ out_mel, int frames_major, int dbg, int gsz
-#define FE2_ARGS pcm, row_stride, B, N, T, ngroups, hop, pad, n_mels, amin, db_mult, floor_db, gtb, plan, out_db, out_mel, frames_major, dbg, gsz
-template <int MEL, int FAST_OUT, int MAXT>
+        float *__restrict__ out_db, float *__restrict__ out_mel, int frames_major, int dbg, int gsz, Fe2Sub sub
+#define FE2_ARGS pcm, row_stride, B, N, T, ngroups, hop, pad, n_mels, amin, db_mult, floor_db, gtb, plan, out_db, out_mel, frames_major, dbg, gsz, sub
+// RING: the streaming instances (frame subsets, ring-addressed output; Fe2Sub) - compiled apart so that the batch kernels keep their
+// register budget (three more VGPRs put the 28-tap instance into scratch)
+template <int MEL, int FAST_OUT, int MAXT, bool RING>
 __device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MFMA_MEL = MEL == 1;
@@ -124,8 +126,16 @@ __device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
     uint32_t cur[8];                                         // samples of the S1 iteration about to run (lane's column)
     auto geom = [&](int item, int& b, int& t0, int& nf) {
         b = item / ngroups;
-        t0 = (item - b * ngroups) * gsz;                     // gsz = frames per group: FE2_G, or fewer for a handful of clips
-        nf = min(gsz, T - t0);
+        const int g = item - b * ngroups;
+        if (!RING || sub.nr == 0) {
+            t0 = g * gsz;                                    // gsz = frames per group: FE2_G, or fewer for a handful of clips
+            nf = min(gsz, T - t0);
+        } else {                                             // frame subset (streaming hop): groups of range r follow those of r - 1
+            int r = 0;
+            while (r + 1 < sub.nr && g >= sub.gend[r]) ++r;
+            t0 = sub.t0[r] + (g - (r ? sub.gend[r - 1] : 0)) * gsz;
+            nf = min(gsz, sub.t1[r] - t0);
+        }
     };
     // An item is "interior" when all its frames lie inside the clip and the clip is 4-byte aligned: S1 reads its
     // samples straight from global memory, one iteration ahead (and the first iteration of the NEXT item during
@@ -357,8 +367,19 @@ __device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
         // ---- out (frames-major): the wave's nf x n_mels block is contiguous in HBM
         if (frames_major && out_db) {
             fe2_wave_sync();
-            float* dst = out_db + ((size_t)b * T + t0) * n_mels;
             const int cnt = nf * n_mels;
+            if (RING && sub.ring_rows) {
+                // streaming ring: frame t of the window sits at row x = row0 + t and again at x +- ring_rows, so that every
+                // window [row0, row0 + T) is contiguous whatever row0 is (rows of [0, 2 ring_rows) per stream)
+                float* base = out_db + (size_t)b * sub.out_clip_stride;
+                for (int i = 4 * lane; i < cnt; i += 256) {                 // n_mels % 4 == 0 (checked by the launcher)
+                    const int f = i / n_mels, j = i - f * n_mels, x = sub.row0 + t0 + f;
+                    const float4 v = *reinterpret_cast<const float4*>(slab + f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j);
+                    *reinterpret_cast<float4*>(base + (size_t)x * n_mels + j) = v;
+                    *reinterpret_cast<float4*>(base + (size_t)(x < sub.ring_rows ? x + sub.ring_rows : x - sub.ring_rows) * n_mels + j) = v;
+                }
+            } else {
+            float* dst = out_db + ((size_t)b * T + t0) * n_mels;
             if ((n_mels & 3) == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -371,13 +392,17 @@ __device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
                     dst[i] = slab[f * FE2_FRAME_DW + FE2_STAGE_OFF + FE2_PSHIFT(f) + j];
                 }
             }
+            }
         }
         fe2_wave_sync();      // the next item's S1 overwrites the stage
     }
 }
 
-template <int MEL, int FAST_OUT, int MAXT>
-__global__ void __launch_bounds__(256, 3) fe2_wave_kernel(FE2_PARAMS) { fe2_wave_body<MEL, FAST_OUT, MAXT>(FE2_ARGS); }
+template <int MEL, int FAST_OUT, int MAXT, bool RING = false>
+__global__ void __launch_bounds__(256, 3) fe2_wave_kernel(FE2_PARAMS) { fe2_wave_body<MEL, FAST_OUT, MAXT, RING>(FE2_ARGS); }
+
+// the streaming instances exist for the frames-major fast output with the mel stage on register filters or MFMA tiles
+bool fe2_subset_supported(const FeParams& p, int mel_mode) { return mel_mode != 0 && (p.n_mels & 3) == 0; }
 
 int fe2_lds_bytes(int waves, int mel_mode) {
     return waves * FE2_G * FE2_FRAME_DW * 4 + (mel_mode == 0 ? (int)sizeof(Fe2MelLds) : 0);
@@ -385,19 +410,33 @@ int fe2_lds_bytes(int waves, int mel_mode) {
 
 hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p,
                       const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
-                      int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream) {
+                      int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream, const Fe2Sub* subset) {
     if (block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
     const int nwv = block / 64;
-    int ngroups = (T + FE2_G - 1) / FE2_G;
+    Fe2Sub sub = subset ? *subset : Fe2Sub{};
+    if (sub.nr < 0 || sub.nr > 4) return hipErrorInvalidValue;
+    if ((sub.nr || sub.ring_rows) && !(frames_major && d_db && !d_mel && (p.n_mels & 3) == 0)) return hipErrorInvalidValue;
+    if (sub.ring_rows && (sub.ring_rows < T || sub.row0 < 0 || sub.row0 >= sub.ring_rows)) return hipErrorInvalidValue;
+    auto count_groups = [&](int g) {
+        if (sub.nr == 0) return (T + g - 1) / g;
+        int n = 0;
+        for (int r = 0; r < sub.nr; ++r) { n += (sub.t1[r] - sub.t0[r] + g - 1) / g; sub.gend[r] = n; }
+        return n;
+    };
+    for (int r = 0; r < sub.nr; ++r)
+        if (sub.t0[r] < 0 || sub.t1[r] <= sub.t0[r] || sub.t1[r] > T) return hipErrorInvalidValue;
+    int ngroups = count_groups(FE2_G);
     // mel_mode: 2 = register-resident filters (falls back to the MFMA tiles when the filterbank does not fit), 1, 0
     int mode = mel_mode;
     if (mode == 2 && (p.n_mels > 64 || max_taps > 25)) mode = 1;      // (up to three more taps than the longest filter: the 16-byte alignment)
     const int lds = fe2_lds_bytes(nwv, mode);
     const int fast = (frames_major && d_db && !d_mel) ? 1 : 0;
+    const bool ring = sub.nr > 0 || sub.ring_rows > 0;
+    if (ring && (mode == 0 || !fast)) return hipErrorInvalidValue;
     auto kern = mode == 0 ? fe2_wave_kernel<0, 0, 1>
-              : mode == 1 ? (fast ? fe2_wave_kernel<1, 1, 1> : fe2_wave_kernel<1, 0, 1>)
-              : max_taps <= 17 ? (fast ? fe2_wave_kernel<2, 1, 20> : fe2_wave_kernel<2, 0, 20>)
-                               : (fast ? fe2_wave_kernel<2, 1, 28> : fe2_wave_kernel<2, 0, 28>);
+              : mode == 1 ? (ring ? fe2_wave_kernel<1, 1, 1, true> : fast ? fe2_wave_kernel<1, 1, 1> : fe2_wave_kernel<1, 0, 1>)
+              : max_taps <= 17 ? (ring ? fe2_wave_kernel<2, 1, 20, true> : fast ? fe2_wave_kernel<2, 1, 20> : fe2_wave_kernel<2, 0, 20>)
+                               : (ring ? fe2_wave_kernel<2, 1, 28, true> : fast ? fe2_wave_kernel<2, 1, 28> : fe2_wave_kernel<2, 0, 28>);
     const void* fn = reinterpret_cast<const void*>(kern);
     {
         hipError_t e = nww_allow_lds(fn, (size_t)lds);
@@ -414,7 +453,7 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
     int gsz = FE2_G;
     if (mode == 2 && small_g >= 2 && small_g < FE2_G && (small_g % 2) == 0 && (long long)B * ngroups * 4 <= (long long)max_grid * nwv) {
         gsz = small_g;
-        ngroups = (T + gsz - 1) / gsz;
+        ngroups = count_groups(gsz);
     }
     const long long total = (long long)B * ngroups;
     long long need = (total + nwv - 1) / nwv;
@@ -422,6 +461,6 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
     if (grid < 1) grid = 1;
     const int pad = p.center ? FE_NFFT / 2 : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, d_pcm, row_stride, B, N, T, ngroups, p.hop, pad, p.n_mels,
-                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, gsz);
+                       p.amin, p.db_mult, p.db_mult * log10f(p.amin), d_tables, d_plan, d_db, d_mel, frames_major, dbg, gsz, sub);
     return hipGetLastError();
 }

@@ -284,6 +284,22 @@ int nww_run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float*
     r.B = B; r.stream = s; r.x = d_x; r.emb = h->d_emb; r.hid = h->d_hid; r.logits = d_logits ? d_logits : h->d_logits;
     r.probs = d_probs;
     r.splitk_ws = h->d_splitk; r.splitk_floats = h->splitk_per_clip * (size_t)h->cap_B; r.cu_count = h->cu_count;
+    if (h->sr.on) {                                    // a streaming hop (nww_stream.hip) configured this forward
+        h->sr.on = false;
+        r.x_stride = h->sr.x_stride;
+        r.stream_mode = h->sr.mode;
+        if (r.stream_mode) {
+            const int W2 = h->stream_W / 4;
+            r.a2_ring = h->d_a2_ring; r.a2_rows = h->a2_rows; r.a2_row0 = h->a2_pos;
+            r.a2_ch_stride = (size_t)h->a2_rows * W2; r.a2_clip_stride = 32 * r.a2_ch_stride;
+            if (r.stream_mode == 2) {
+                const int H2 = h->stream_H / 4;
+                r.a2_nsub = 0;
+                if (h->a2_lo > 0) { r.a2_sub_a[r.a2_nsub] = 0; r.a2_sub_b[r.a2_nsub] = h->a2_lo; ++r.a2_nsub; }
+                if (h->a2_hi + 1 < H2) { r.a2_sub_a[r.a2_nsub] = h->a2_hi + 1; r.a2_sub_b[r.a2_nsub] = H2; ++r.a2_nsub; }
+            }
+        }
+    }
     size_t off = 0;
     for (int i = 0; i < 6; ++i) {
         r.buf[i] = h->d_ws + off;
@@ -313,13 +329,13 @@ int nww_check_run(nww_handle* h, int B) {
 }
 
 int nww_frontend_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_db, float* d_mel, int frames_major,
-                        hipStream_t s, int* frames_out, size_t row_stride) {
+                        hipStream_t s, int* frames_out, size_t row_stride, const Fe2Sub* sub) {
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
     if (frames_out) *frames_out = T;
     static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();    // 2: register filters, 1: MFMA tiles, 0: sparse LDS loop
     // three 4-wave workgroups per CU (frontend2.hip)
-    hipError_t e = fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * 3, s);
+    hipError_t e = fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * 3, s, sub);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;
 }

@@ -42,6 +42,12 @@ struct Run {
     int B = 0;
     hipStream_t stream = nullptr;
     const float* x = nullptr;   // head input [B][in_rows*in_cols]
+    size_t x_stride = 0;        // floats between consecutive clips of x; 0 = dense (only first steps that say so at plan time take a stride)
+    // streaming hop (nww_stream.hip; set only for plans with nww_handle::stream_conv): 1 = the fused trunk writes its pooled rows
+    // into per-stream rings and the third conv reads them there, 2 = and only the rows a hop invalidates are computed
+    int stream_mode = 0;
+    float* a2_ring = nullptr; int a2_rows = 0, a2_row0 = 0; size_t a2_ch_stride = 0, a2_clip_stride = 0;
+    int a2_nsub = 0, a2_sub_a[2] = {0, 0}, a2_sub_b[2] = {0, 0};
     bool x_frames_major = false; // E2E head on the transposed plane: x came from the frontend as [B][frames][n_mels] already
     float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* emb = nullptr;       // [B][E]
@@ -86,6 +92,15 @@ struct nww_handle {
     float* d_splitk = nullptr;     // split-K partials
     // streaming rings: [S][2*W] int16, sample p of a stream lives at p and p+W
     int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
+    // incremental hops (nww_stream.hip): log-mel ring [S][2 * lm_rows][n_mels] (frame t of the current window at row lm_pos + t and
+    // lm_rows away), pooled conv rows [S][32][a2_rows][W / 4] (row R at (a2_pos + R) % a2_rows); a hop shifts them by lm_shift / a2_shift
+    bool x_stride_ok = false;      // plan time: the first step takes Run::x_stride (fused split-operand trunk, DNN layer1)
+    bool stream_conv = false;      // plan time: fused trunk -> conv3_x3 pair that takes Run::stream_mode (CRNN)
+    int stream_H = 0, stream_W = 0;   // the plane that pair works on
+    bool inc_fe = false, inc_conv = false, primed = false;
+    float* d_lm_ring = nullptr; int lm_rows = 0, lm_pos = 0, lm_shift = 0, fe_edge_l = 0, fe_edge_r = 0;
+    float* d_a2_ring = nullptr; int a2_rows = 0, a2_pos = 0, a2_shift = 0, a2_lo = 0, a2_hi = 0;
+    struct { bool on = false; size_t x_stride = 0; int mode = 0; } sr;    // what the next nww_run_head hands to its Run
     EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
     void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)
     unsigned char* pin_in = nullptr; unsigned char* pin_out = nullptr;   // pinned staging for small host-pointer calls
@@ -120,7 +135,7 @@ int nww_ensure_ws(nww_handle* h, int B, int N);
 int nww_run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float* d_probs, hipStream_t s, unsigned int* done_flag = nullptr,
                  unsigned int done_seq = 0, bool* done_armed = nullptr, bool x_frames_major = false);
 int nww_frontend_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_db, float* d_mel, int frames_major, hipStream_t s,
-                        int* frames_out, size_t row_stride = 0);
+                        int* frames_out, size_t row_stride = 0, const Fe2Sub* sub = nullptr);
 int nww_forward_pcm_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float* d_logits, float* d_probs, hipStream_t s,
                            size_t row_stride = 0, unsigned int* done_flag = nullptr, unsigned int done_seq = 0, bool* done_armed = nullptr);
 int nww_h2d_small(nww_handle* h, void* dst, const void* src, size_t bytes, hipStream_t s);

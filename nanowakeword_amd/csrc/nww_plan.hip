@@ -275,10 +275,18 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
         if (hipMalloc(&packed, trunk_b_packed_bytes()) != hipSuccess) return false;
         if (launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
         p.h->packed_weights.push_back(packed);
+        if (in_id == -1 && !p.h->e2e_transposed) p.h->x_stride_ok = true;                   // this step reads the head input with any clip stride
         p.add("trunk_x3:" + name, [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
             a.wpack = static_cast<const unsigned char*>(packed);
+            if (in_id == -1) a.in_clip_stride = r.x_stride;
+            if (r.stream_mode) {                        // streaming hop: pooled rows into the per-stream rings, all of them or the invalidated ones
+                a.out = r.a2_ring; a.out_ring_rows = r.a2_rows; a.out_row0 = r.a2_row0;
+                a.out_ch_stride = r.a2_ch_stride; a.out_clip_stride = r.a2_clip_stride;
+                a.n_sub = r.stream_mode == 2 ? r.a2_nsub : 0;
+                for (int q = 0; q < a.n_sub; ++q) { a.sub_a[q] = r.a2_sub_a[q]; a.sub_b[q] = r.a2_sub_b[q]; }
+            }
             return launch_cnn_trunk_b(a, x3, max_grid, r.stream);
         });
         return true;
@@ -293,7 +301,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 // 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
-                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0) {
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0, bool* ring_in = nullptr) {
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
@@ -308,15 +316,21 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
         const size_t lds = conv3_x3_lds_bytes(H, W, avg_ow);
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
         const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
+        const bool ring_ok = ring_in && *ring_in;                                             // ... and may hand the input over in rings
         p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name, [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
             a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out; a.avg_y = avg_y;
+            if (ring_ok && r.stream_mode) {             // streaming hop: the fused trunk's pooled rows are read from their rings
+                a.in = r.a2_ring; a.in_ring_rows = r.a2_rows; a.in_row0 = r.a2_row0;
+                a.in_ch_stride = r.a2_ch_stride; a.in_clip_stride = r.a2_clip_stride;
+            }
             return launch_conv3_x3(a, max_grid * per_cu, r.stream);
         });
         return true;
     }
     if (avg_y) return false;                                   // only conv3_x3 pools along y (the caller checked e2e_transposed_ok)
     if (seq_inout) *seq_inout = false;                         // the float32-MFMA instance writes planes
+    if (ring_in) *ring_in = false;                             // ... and reads dense planes
     p.add(std::string(avg_ow > 0 ? "conv3x3_mfma+avgpool:" : "conv3x3_mfma:") + name, [=](Run& r) {
         ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
         a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow;
@@ -611,6 +625,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             int cin = 1, hh = T, ww = F, cur = -1;
             int first = 0;
             bool seq_written = false;
+            const size_t steps_before = h->plan.size();
             if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
                 add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
                           p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
@@ -622,10 +637,14 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const int out = (i % 2 == 0) ? 0 : 1;
                 // the last conv stage may write the recurrent layers' [W][C * H] sequence layout itself (conv3_x3.hip)
                 bool seq = i == c.n_crnn_channels - 1;
-                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq)) {
+                // the stage right behind a fused split-operand trunk may take its input from the streaming rings (nww_stream.hip)
+                bool ring = i == 2 && first == 2 && h->plan.size() == steps_before + 1 && h->plan.back().name.rfind("trunk_x3:", 0) == 0 && ((F / 4) % 4) == 0;
+                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring)) {
+                    ring = false;
                     seq = false;
                     add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
                 }
+                if (ring) { h->stream_conv = true; h->stream_H = T; h->stream_W = F; }
                 seq_written = seq;
                 hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
             }

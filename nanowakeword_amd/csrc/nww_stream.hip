@@ -24,12 +24,64 @@ stream_push_kernel(int16_t* __restrict__ ring, const int16_t* __restrict__ chunk
     r[p + W] = v;
 }
 
+// dense [B][n] <- the first n floats of every clip's slot (stride floats apart): the window of a log-mel ring for heads whose first
+// kernel wants dense clips
+__global__ void __launch_bounds__(256) stream_gather_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int B, int n4, size_t stride4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * n4) return;
+    const int b = (int)(idx / n4), i = (int)(idx - (size_t)b * n4);
+    dst[idx] = src[(size_t)b * stride4 + i];
+}
+
+static void free_inc(nww_handle* h) {
+    if (h->d_lm_ring) (void)hipFree(h->d_lm_ring);
+    if (h->d_a2_ring) (void)hipFree(h->d_a2_ring);
+    h->d_lm_ring = nullptr; h->d_a2_ring = nullptr;
+    h->inc_fe = h->inc_conv = h->primed = false;
+    h->lm_rows = h->lm_pos = h->lm_shift = h->a2_rows = h->a2_pos = h->a2_shift = 0;
+}
+
 extern "C" int nww_stream_close(nww_handle* h) {
     if (!h) return NWW_ERR_INVALID;
     (void)hipSetDevice(h->cfg.device);
     if (h->d_ring) (void)hipFree(h->d_ring);
     if (h->d_chunk) (void)hipFree(h->d_chunk);
+    free_inc(h);
     h->d_ring = nullptr; h->d_chunk = nullptr; h->ring_S = h->ring_W = h->ring_hop = h->ring_pos = 0; h->ring_filled = 0;
+    return NWW_OK;
+}
+
+// What a hop invalidates.  A hop of k = hop / hop_length frames turns frame t of the old window into frame t - k of the new one, bit
+// for bit, unless the frame touches the reflect padding of either window (the first fe_edge_l and last fe_edge_r frames of a centred
+// window): per hop only frames [0, fe_edge_l) and [T - fe_edge_r - k, T) are computed, into a ring of log-mel rows per stream.
+// Likewise pooled row j of the fused trunk (input rows 4j - 3 .. 4j + 6) equals row j + k / 4 of the previous window when those
+// rows are shifted interior frames in both windows: rows [a2_lo, a2_hi] are reused, the rest recomputed from the log-mel ring.
+// NWW_STREAM_INC = 0: every hop re-scores the whole window (rounds 1-3), 1: frontend only, 2 (default): frontend + conv rows.
+static int plan_incremental(nww_handle* h, int S, int W, int hop) {
+    static const int mode = [] { const char* e = getenv("NWW_STREAM_INC"); return e ? atoi(e) : 2; }();
+    const nww_config& c = h->cfg;
+    const int T = fe_num_frames(h->fe, W), hl = h->fe.hop;
+    const bool frames_major = !c.mel_major_features || h->e2e_transposed;
+    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();
+    if (mode <= 0 || !frames_major || !fe2_subset_supported(h->fe, mel_env) || hop % hl != 0) return NWW_OK;
+    const int k = hop / hl, pad = h->fe.center ? h->fe.n_fft / 2 : 0;
+    int el = 0, er = 0;
+    while (el < T && el * hl - pad < 0) ++el;
+    while (er < T && (T - 1 - er) * hl - pad + h->fe.n_fft > W) ++er;
+    if (T - er - k <= el) return NWW_OK;                      // a hop replaces (nearly) the whole window: nothing to keep
+    h->fe_edge_l = el; h->fe_edge_r = er; h->lm_shift = k;
+    h->lm_rows = (T + k - 1) / k * k;
+    HIP_TRY(h, hipMalloc(&h->d_lm_ring, (size_t)S * 2 * h->lm_rows * c.n_mels * sizeof(float) + 16));
+    h->inc_fe = true;
+    if (mode >= 2 && h->stream_conv && h->stream_H == T && (k % 4) == 0) {
+        const int H2 = T / 4, W2 = h->stream_W / 4;
+        const int lo = (el + 3 + 3) / 4, hi = (T - 1 - er - k - 6) >= 0 ? (T - 1 - er - k - 6) / 4 : -1;
+        if (hi >= lo && hi < H2) {
+            h->a2_lo = lo; h->a2_hi = hi; h->a2_shift = k / 4; h->a2_rows = H2;
+            HIP_TRY(h, hipMalloc(&h->d_a2_ring, (size_t)S * 32 * H2 * W2 * sizeof(float) + 16));
+            h->inc_conv = true;
+        }
+    }
     return NWW_OK;
 }
 
@@ -49,6 +101,8 @@ extern "C" int nww_stream_open(nww_handle* h, int32_t S, int32_t W, int32_t hop)
     HIP_TRY(h, hipMemset(h->d_ring, 0, (size_t)S * 2 * W * sizeof(int16_t)));
     HIP_TRY(h, hipMalloc(&h->d_chunk, (size_t)S * hop * sizeof(int16_t) + 16));
     h->ring_S = S; h->ring_W = W; h->ring_hop = hop; h->ring_pos = 0; h->ring_filled = 0;
+    rc = plan_incremental(h, S, W, hop);
+    if (rc) return rc;
     return ensure_ws(h, S, W);
 }
 
@@ -58,10 +112,49 @@ extern "C" int nww_stream_reset(nww_handle* h) {
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemset(h->d_ring, 0, (size_t)h->ring_S * 2 * h->ring_W * sizeof(int16_t)));
     h->ring_pos = 0; h->ring_filled = 0;
+    h->primed = false; h->lm_pos = 0; h->a2_pos = 0;          // the next full window is computed whole
     return NWW_OK;
 }
 
 extern "C" int64_t nww_stream_filled(const nww_handle* h) { return h ? h->ring_filled : 0; }
+
+// One hop on the incremental path: the invalidated frames (all of them for the first full window) -> log-mel ring -> head.
+static int stream_hop_incremental(nww_handle* h, float* d_logits, float* d_probs, hipStream_t s) {
+    const nww_config& c = h->cfg;
+    const int S = h->ring_S, W = h->ring_W, T = fe_num_frames(h->fe, W), k = h->lm_shift;
+    int rc = ensure_ws(h, S, W);
+    if (rc) return rc;
+    prof_begin(h);
+    prof_mark(h, s, 0);
+    Fe2Sub sub;
+    sub.ring_rows = h->lm_rows; sub.row0 = h->lm_pos; sub.out_clip_stride = (size_t)2 * h->lm_rows * c.n_mels;
+    if (h->primed) {
+        if (h->fe_edge_l > 0) { sub.t0[sub.nr] = 0; sub.t1[sub.nr] = h->fe_edge_l; ++sub.nr; }
+        // the new interior frames, then the trailing edge frames as a group of their own (groups of up to eight frames)
+        sub.t0[sub.nr] = T - h->fe_edge_r - k; sub.t1[sub.nr] = T - h->fe_edge_r; ++sub.nr;
+        if (h->fe_edge_r > 0) { sub.t0[sub.nr] = T - h->fe_edge_r; sub.t1[sub.nr] = T; ++sub.nr; }
+    }
+    rc = frontend_dev(h, h->d_ring + h->ring_pos, S, W, h->d_lm_ring, nullptr, 1, s, nullptr, (size_t)2 * W, &sub);
+    if (rc) return rc;
+    const float* win = h->d_lm_ring + (size_t)h->lm_pos * c.n_mels;          // rows [lm_pos, lm_pos + T) of every stream's ring: its window
+    const bool conv_inc = h->inc_conv && h->x_stride_ok;
+    if (h->x_stride_ok) {
+        h->sr.on = true; h->sr.x_stride = sub.out_clip_stride; h->sr.mode = conv_inc ? (h->primed ? 2 : 1) : 0;
+        rc = run_head(h, win, S, d_logits, d_probs, s, nullptr, 0, nullptr, false);
+    } else {
+        const int n4 = T * c.n_mels / 4;
+        const size_t total = (size_t)S * n4;
+        hipLaunchKernelGGL(stream_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(win),
+                           reinterpret_cast<float4*>(h->d_logmel), S, n4, sub.out_clip_stride / 4);
+        HIP_TRY(h, hipGetLastError());
+        rc = run_head(h, h->d_logmel, S, d_logits, d_probs, s, nullptr, 0, nullptr, c.mel_major_features != 0);
+    }
+    if (rc) return rc;
+    h->lm_pos = (h->lm_pos + k) % h->lm_rows;
+    if (h->inc_conv) h->a2_pos = (h->a2_pos + h->a2_shift) % h->a2_rows;
+    h->primed = true;
+    return NWW_OK;
+}
 
 static int stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, hipStream_t s) {
     const int S = h->ring_S, W = h->ring_W, hop = h->ring_hop;
@@ -76,9 +169,9 @@ static int stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logit
         if (d_probs) HIP_TRY(h, hipMemsetAsync(d_probs, 0, (size_t)S * sizeof(float), s));
         return NWW_OK;
     }
+    if (h->inc_fe) return stream_hop_incremental(h, d_logits, d_probs, s);
     return forward_pcm_dev(h, h->d_ring + h->ring_pos, S, W, d_logits, d_probs, s, (size_t)2 * W);
 }
-
 extern "C" int nww_stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, void* stream) {
     if (!h || !h->d_ring) return fail(h, NWW_ERR_STATE, "no open stream batch (nww_stream_open)");
     if (!d_chunk) return fail(h, NWW_ERR_INVALID, "null chunk pointer");

@@ -19,15 +19,24 @@ struct TrunkArgs {
     // strip s for life (wg_end[0] == 0: strip = blockIdx % strips instead)
     const unsigned char* wpack = nullptr;
     int wg_end[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // trunk_b, streaming hop (nww_stream.hip): `in` is a window inside a per-clip ring (in_clip_stride floats between clips, 0 = H * W);
+    // only the pooled output rows [sub_a[s], sub_b[s]) of n_sub explicit strips are computed (n_sub = 0: all rows, `strips` strips);
+    // with out_ring_rows > 0 output row R of channel c goes to out + b * out_clip_stride + c * out_ch_stride + ((out_row0 + R) %
+    // out_ring_rows) * (W / 4) - a ring of pooled rows per clip and channel, read back by conv3_x3 with the same row map
+    size_t in_clip_stride = 0, out_clip_stride = 0, out_ch_stride = 0;
+    int out_ring_rows = 0, out_row0 = 0;
+    int n_sub = 0, sub_a[4] = {0, 0, 0, 0}, sub_b[4] = {0, 0, 0, 0};
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
 };
-__host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
-    const int H1 = H / 2, H2 = H1 / 2;
+// the strip that produces pooled output rows [R2a, R2b): the A1 / input rows it needs (seam rows are recomputed by every strip
+// that needs them, with the same arithmetic: results do not depend on how a clip is cut)
+__host__ __device__ inline TrunkStrip trunk_strip_rows(int H, int R2a, int R2b) {
+    const int H1 = H / 2;
     TrunkStrip g;
-    g.R2a = (s * H2 + S - 1) / S;
-    g.R2b = ((s + 1) * H2 + S - 1) / S;
+    g.R2a = R2a;
+    g.R2b = R2b;
     g.a1_base = 2 * g.R2a - 1;                                  // A1 row kept at local row 0
     g.a1_lo = g.a1_base < 0 ? 0 : g.a1_base;
     g.a1_hi = 2 * g.R2b < H1 - 1 ? 2 * g.R2b : H1 - 1;
@@ -39,6 +48,10 @@ __host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
     g.y_hi = iy1 < H - 1 ? iy1 : H - 1;
     return g;
 }
+__host__ __device__ inline TrunkStrip trunk_strip(int H, int S, int s) {
+    const int H2 = H / 4;
+    return trunk_strip_rows(H, (s * H2 + S - 1) / S, ((s + 1) * H2 + S - 1) / S);
+}
 size_t trunk_lds_bytes(int C1, int H, int W, int strips);
 // strips needed for a workgroup to fit in LDS (0 = does not fit at all); *wgs_per_cu = 2 when two workgroups share a CU
 int trunk_pick_strips(int C1, int H, int W, int* wgs_per_cu);
@@ -49,6 +62,10 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
 struct ConvMfmaArgs {
     const float* in; const float* w; const float *bias, *alpha, *beta; float* out;
     int B, H, W, Cout, act, pool;
+    // conv3_x3 only, streaming hop: the input planes live in per-clip rings of pooled rows (TrunkArgs::out_ring_rows): row y of
+    // channel c of clip b at in + b * in_clip_stride + c * in_ch_stride + ((in_row0 + y) % in_ring_rows) * W
+    size_t in_clip_stride = 0, in_ch_stride = 0;
+    int in_ring_rows = 0, in_row0 = 0;
     // fused AvgPool2d(kernel (H, avg_kw), stride (H, avg_sw)) -> out [B][Cout][avg_ow] when avg_ow > 0 (pool must be 0)
     int avg_kw = 0, avg_sw = 0, avg_ow = 0;
     int avg_y = 0;         // conv3_x3 only: the windows run along y and cover all columns (the same pool on a transposed plane)

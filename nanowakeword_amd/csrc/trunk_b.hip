@@ -257,7 +257,11 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     {
         // strip of this workgroup (kept for life) and the clips it walks
         int sidx;
-        if (a.wg_end[0] > 0) {
+        if (a.n_sub > 0) {                                  // explicit strips (streaming hop): equal shares of the grid
+            sidx = (int)blockIdx.x % a.n_sub;
+            b0 = (int)blockIdx.x / a.n_sub;
+            bstep = (int)gridDim.x / a.n_sub;
+        } else if (a.wg_end[0] > 0) {
             sidx = 0;
             while (sidx + 1 < S && (int)blockIdx.x >= a.wg_end[sidx]) ++sidx;
             const int first = sidx ? a.wg_end[sidx - 1] : 0;
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
             b0 = (int)blockIdx.x / S;
             bstep = (int)gridDim.x / S;
         }
-        const TrunkStrip sg = trunk_strip(H, S, sidx);
+        const TrunkStrip sg = a.n_sub > 0 ? trunk_strip_rows(H, a.sub_a[sidx], a.sub_b[sidx]) : trunk_strip(H, S, sidx);
         const TbGeom gg = tb_geom(W, sg);
         Wp0 = gg.Wp0; rowB = gg.rowB; plane_b = gg.plane_b; a1_b = gg.a1_b;
         n_a1 = sg.a1_hi - sg.a1_lo + 1;
@@ -279,6 +283,9 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         in_off = (size_t)sg.y_lo * W;
         out_off = (size_t)sg.R2a * W2;
     }
+    const size_t in_clip = a.in_clip_stride ? a.in_clip_stride : (size_t)H * W;
+    const int ring = a.out_ring_rows;
+    const int ring_r0 = ring ? (a.out_row0 + (int)(out_off / W2)) % ring : 0;      // ring row of the strip's first pooled row
     const int pitch0 = 2 * Wp0;
     unsigned char* const In3 = lds_raw;
     unsigned char* const A1 = lds_raw + 3 * plane_b;
@@ -325,7 +332,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     const int a1_lane = dyi * rowB + xi * PS + 16 * hi;
     // output: lane = (channel i, pooled columns 8 X + 4 hi .. + 3)
     const int blk_kt = a.out_blocked;
-    const int out_lane = i * H2 * W2 + 4 * hi;
+    const int out_lane = ring ? i * (int)a.out_ch_stride + 4 * hi : i * H2 * W2 + 4 * hi;
 
     // input rows -> the three bf16 planes (zero halo): value (y, x) at column x + 1 of local row y + row_shift
     auto store4 = [&](unsigned char* planes, int idx, float4 v) {
@@ -354,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         }
     };
     constexpr int NPRE = 2;                                     // float4 registers per thread for the rows of the next item
-    const bool vec_in = (W & 3) == 0 && n_in <= 4 * NPRE * NTHR;
+    const bool vec_in = (W & 3) == 0 && (in_clip & 3) == 0 && n_in <= 4 * NPRE * NTHR;
 
     [[maybe_unused]] int item_no = -1;                          // trace builds only
     // conv1 groups: 32 consecutive pooled pixels of one A1 row; group g = (row g / ngx, block g % ngx)
@@ -424,6 +431,11 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         if ((TB_ABL & 8) || cnt <= 0) return;
         int R = t0 / nX, X = t0 - R * nX;
         auto tile_dst = [&](int Rr, int Xx) -> float* {
+            if (ring) {                                                        // (wave-uniform) pooled row Rr of the strip -> its ring row
+                int row = ring_r0 + Rr;
+                if (row >= ring) row -= ring;
+                return outb + row * W2 + 8 * Xx + out_lane;
+            }
             const int rel = Rr * W2 + 8 * Xx;                                  // wave-uniform
             if (!blk_kt) return outb + rel + out_lane;
             const int k = out_lane + (int)out_off + rel;                       // feature index of (channel, row, column)
@@ -440,7 +452,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     };
 
     __syncthreads();
-    if (b0 < a.B) load_plane_sync(In3, a.in + (size_t)b0 * H * W + in_off);
+    if (b0 < a.B) load_plane_sync(In3, a.in + (size_t)b0 * in_clip + in_off);
     __syncthreads();
     // ---- two phases per item, all eight waves in each: conv1 -> A1 | conv2 (the next item's rows in flight) -> planes
     TB_STAMP_WG(1);
@@ -453,11 +465,12 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         conv1_groups(In3, A1, wave, NW);
         TB_STAMP(1);
         __syncthreads();
-        float* outb = blk_kt ? a.out + ((size_t)(b >> 7) * blk_kt * 128 + (b & 127)) * 32
+        float* outb = ring ? a.out + (size_t)b * a.out_clip_stride
+                    : blk_kt ? a.out + ((size_t)(b >> 7) * blk_kt * 128 + (b & 127)) * 32
                              : a.out + (size_t)b * C2 * H2 * W2 + out_off;
         float4 pre[NPRE];
         if (has1 && vec_in && !(TB_ABL & 64)) {
-            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)b1 * H * W + in_off);
+            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)b1 * in_clip + in_off);
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 const int idx4 = tid + q * NTHR;
@@ -474,7 +487,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
                     if (idx4 < n_in / 4) store4(In3, idx4 * 4, pre[q]);
                 }
             } else {
-                load_plane_sync(In3, a.in + (size_t)b1 * H * W + in_off);
+                load_plane_sync(In3, a.in + (size_t)b1 * in_clip + in_off);
             }
         }
         __syncthreads();
@@ -753,10 +766,68 @@ int trunk_b_pick_strips(int H, int W) {
     return 0;
 }
 
+#define TB_DISPATCH(aa, grid, lds)                                                                                      \
+    {                                                                                                                  \
+        const bool bn_ = (aa).al1 != nullptr || (aa).al2 != nullptr;                                                   \
+        hipError_t e_ = hipErrorInvalidValue;                                                                          \
+        const int key_ = ((aa).act == ACT_RELU ? 0 : (aa).act == ACT_GELU ? 1 : (aa).act == ACT_SILU ? 2 : 3) * 4 + (products == 6 ? 0 : 2) + (bn_ ? 1 : 0); \
+        switch (key_) {                                                                                                \
+            TB_CASE(0, ACT_RELU, 6, false) TB_CASE(1, ACT_RELU, 6, true) TB_CASE(2, ACT_RELU, 9, false) TB_CASE(3, ACT_RELU, 9, true)   \
+            TB_CASE(4, ACT_GELU, 6, false) TB_CASE(5, ACT_GELU, 6, true) TB_CASE(6, ACT_GELU, 9, false) TB_CASE(7, ACT_GELU, 9, true)   \
+            TB_CASE(8, ACT_SILU, 6, false) TB_CASE(9, ACT_SILU, 6, true) TB_CASE(10, ACT_SILU, 9, false) TB_CASE(11, ACT_SILU, 9, true) \
+            default: return hipErrorInvalidValue;                                                                      \
+        }                                                                                                              \
+        if (e_ != hipSuccess) return e_;                                                                               \
+    }
+#define TB_CASE(K, ACTV, PRODV, BNV)                                                                                   \
+    case K:                                                                                                            \
+        e_ = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_b_kernel<ACTV, PRODV, BNV>), lds);                  \
+        if (e_ == hipSuccess) hipLaunchKernelGGL((cnn_trunk_b_kernel<ACTV, PRODV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa); \
+        break;
+
+// Streaming hop: explicit strips of pooled rows and / or ring-addressed output (TrunkArgs::n_sub, out_ring_rows).  Explicit strips get
+// equal shares of the grid; without them the clip is cut as usual.
+static hipError_t launch_cnn_trunk_b_stream(TrunkArgs aa, int products, int max_grid, hipStream_t s) {
+    const int H2 = aa.H / 4, W2 = aa.W / 4;
+    if (aa.out_blocked || aa.n_sub < 0 || aa.n_sub > 4) return hipErrorInvalidValue;
+    if (aa.out_ring_rows > 0 && (aa.out_ring_rows < H2 || aa.out_row0 < 0 || aa.out_row0 >= aa.out_ring_rows || aa.out_ch_stride < (size_t)aa.out_ring_rows * W2 ||
+                                 aa.out_clip_stride < C2 * aa.out_ch_stride || (aa.out_ch_stride & 3) || (W2 & 3)))
+        return hipErrorInvalidValue;
+    for (int q = 0; q < 8; ++q) aa.wg_end[q] = 0;
+    size_t lds = 0;
+    int S;
+    if (aa.n_sub > 0) {
+        S = aa.n_sub;
+        for (int q = 0; q < S; ++q) {
+            if (aa.sub_a[q] < 0 || aa.sub_b[q] <= aa.sub_a[q] || aa.sub_b[q] > H2) return hipErrorInvalidValue;
+            const TbGeom gg = tb_geom(aa.W, trunk_strip_rows(aa.H, aa.sub_a[q], aa.sub_b[q]));
+            const size_t b = 3 * (size_t)gg.plane_b + (size_t)gg.a1_b + 6 * 1024 + NWL * 1024;
+            if (b > lds) lds = b;
+        }
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+    } else {
+        S = trunk_b_pick_strips(aa.H, aa.W);
+        if (S < 1) return hipErrorInvalidValue;
+        for (int small_strips : {8, 6, 4})
+            if (small_strips > S && (long)aa.B * small_strips * 4 <= max_grid && small_strips <= aa.H / 4) { S = small_strips; break; }
+        lds = trunk_b_lds_bytes(aa.H, aa.W, S);
+    }
+    aa.strips = S;
+    const int per_cu = 1;                                        // eight waves x ~220 registers: one workgroup per CU whatever its LDS
+    long want = (long)aa.B * S;
+    long cap = (long)max_grid * per_cu;
+    int grid = (int)(want < cap ? want : cap);
+    grid -= grid % S;
+    if (grid < S) grid = S;
+    TB_DISPATCH(aa, grid, lds)
+    return hipGetLastError();
+}
+
 hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s) {
     if (!a.wpack) return hipErrorInvalidValue;
     TrunkArgs aa = a;
     static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    if (a.n_sub > 0 || a.out_ring_rows > 0) return launch_cnn_trunk_b_stream(aa, products, max_grid, s);
     int S = trunk_b_pick_strips(a.H, a.W);
     if (S < 1) return hipErrorInvalidValue;
     if (force_strips > S && force_strips <= a.H / 4) S = force_strips;
@@ -798,26 +869,7 @@ hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hi
         grid -= grid % S;
         if (grid < S) grid = S;
     }
-    const bool bn = a.al1 != nullptr || a.al2 != nullptr;
-#define TB_LAUNCH(ACTV, PRODV, BNV)                                                                                    \
-    {                                                                                                                  \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_b_kernel<ACTV, PRODV, BNV>), lds);        \
-        if (e != hipSuccess) return e;                                                                                 \
-        hipLaunchKernelGGL((cnn_trunk_b_kernel<ACTV, PRODV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa);                \
-    }
-#define TB_BN(ACTV, PRODV)                                                                                             \
-    if (bn) TB_LAUNCH(ACTV, PRODV, true) else TB_LAUNCH(ACTV, PRODV, false)
-#define TB_ACT(ACTV)                                                                                                   \
-    if (products == 6) TB_BN(ACTV, 6) else TB_BN(ACTV, 9)
-    switch (a.act) {
-        case ACT_RELU: TB_ACT(ACT_RELU) break;
-        case ACT_GELU: TB_ACT(ACT_GELU) break;
-        case ACT_SILU: TB_ACT(ACT_SILU) break;
-        default: return hipErrorInvalidValue;
-    }
-#undef TB_LAUNCH
-#undef TB_BN
-#undef TB_ACT
+    TB_DISPATCH(aa, grid, lds)
     return hipGetLastError();
 }
 

@@ -79,3 +79,59 @@ def test_streambatch_on_device_rings(golden_frontend):
     sb.reset()
     assert m.stream_filled() == 0
     sb.close(); m.close(); m2.close()
+
+
+# (head kwargs, frontend (n_mels, center), window samples, hop samples): what a hop keeps differs per row -
+#   hop 1280 = 8 frames: log-mel ring + (CRNN) pooled conv-row rings; 640 = 4 frames: one pooled row per hop; 2560: two hops of rows;
+#   800 = 5 frames: frontend ring only (conv rows do not line up); 1000: not a whole number of frames -> every hop re-scores the window
+_INC_CASES = [
+    (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="crnn", input_shape=(101, 64), crnn_rnn_type="lstm"), (64, True), 16000, 640),
+    (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 2560),
+    (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 800),
+    (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 1000),
+    (dict(model_type="crnn", input_shape=(98, 40)), (40, False), 16000, 1280),
+    (dict(model_type="crnn", input_shape=(151, 64), layer_dim=64), (64, True), 24000, 1280),
+    (dict(model_type="cnn", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="dnn", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="dnn", input_shape=(98, 40)), (40, False), 16000, 1280),
+    (dict(model_type="bcresnet", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="conformer", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="gru", input_shape=(101, 64)), (64, True), 16000, 1280),
+    (dict(model_type="e2e_dnn", input_shape=(64, 101)), (64, True), 16000, 1280),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(_INC_CASES)))
+def test_incremental_hops_equal_window_rescoring(golden_frontend, case):
+    """The streaming path keeps per-stream rings of log-mel frames (and, for the CRNN stem, pooled conv rows) and computes per hop only
+    what the hop invalidates.  Contract: every hop's logits are BIT-IDENTICAL to scoring that stream's last window from scratch
+    (`forward_pcm`) - through ring wrap-arounds, after a reset, and for hops where only part (or none) of the state can be kept."""
+    from nanowakeword_amd.config import FrontendConfig, HeadConfig
+    from nanowakeword_amd.session import HipModel
+    from nanowakeword_amd.synth import synth_state_dict
+    g = golden_frontend
+    kw, (n_mels, center), W, hop = _INC_CASES[case]
+    cfg = HeadConfig(**kw)
+    fe = FrontendConfig(n_mels=n_mels, center=center)
+    m = HipModel(cfg, fe, state_dict=synth_state_dict(cfg), window=g["window"], mel_fb=g["fb64"] if n_mels == 64 else g["fb40"])
+    S = 5
+    n_hops = (W + hop - 1) // hop + 34                        # more than two trips round the log-mel ring (13 hops of 8 frames)
+    streams = np.stack([synth_pcm("speechlike" if s % 2 else "noise", 1, hop * n_hops, seed=300 + 7 * s + case)[0] for s in range(S)])
+    streams[4, hop * 20:hop * 30] = 0                         # a stretch of digital silence (-100 dB floor rows travel through the rings)
+    m.stream_open(S, W, hop)
+    for rnd in range(2):                                      # second round: after nww_stream_reset the state is rebuilt from the first full window
+        hist = np.zeros((S, 0), np.int16)
+        for i in range(n_hops if rnd == 0 else (W + hop - 1) // hop + 3):
+            chunk = np.ascontiguousarray(streams[:, i * hop:(i + 1) * hop] if rnd == 0 else streams[:, ::-1][:, i * hop:(i + 1) * hop])
+            hist = np.concatenate([hist, chunk], axis=1)[:, -W:]
+            lg, pr = m.stream_push(chunk)
+            if hist.shape[1] < W or m.stream_filled() < W:
+                assert not lg.any() and not pr.any()
+                continue
+            want, wantp = m.forward_pcm(np.ascontiguousarray(hist))
+            assert np.array_equal(lg, want), (case, rnd, i, np.abs(lg - want).max())
+            assert np.array_equal(pr, wantp)
+        m.stream_reset()
+    m.stream_close(); m.close()

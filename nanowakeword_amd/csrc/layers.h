@@ -123,7 +123,10 @@ struct GruArgs {
     // rnn_x3 only: the FIRST step of the opposite direction (all that rnn_out[:, -1] needs of it; h = 0, so no recurrent product)
     // computed in the same launch from its gate pre-activations xg2 [B][xg2_bstride] and recurrent bias -> last_out[:, col_off2 + j]
     const float* xg2 = nullptr; size_t xg2_bstride = 0; const float* b_hh2 = nullptr; int col_off2 = 0;
+    int ldw = 0;           // > 0: w_hh is the zero-padded [gates H][ldw] copy of launch_rnn_pad_weights -> the any-width kernel (H <= 512)
 };
+size_t rnn_wide_weight_bytes(int gates, int H);
+hipError_t launch_rnn_pad_weights(const float* w_hh, float* out, int gates, int H, hipStream_t s);
 hipError_t launch_gru(const GruArgs& a, hipStream_t s);
 // out[f][kx][ky] = w[f][ky][kx] for nfilters 3x3 filters; [B][R][C] -> [B][C][R]
 hipError_t launch_transpose3x3(const float* w, float* out, int nfilters, hipStream_t s);

@@ -1012,9 +1012,11 @@ hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int
 // ------------------------------------------------------------------------------------------ attention core
 // One workgroup per (clip, head).  K and V of the head live in LDS; lane t owns query row t and walks the
 // keys with an online softmax (running max / sum), every lane reading the same K/V element (LDS broadcast).
+// DH = the compiled width, dh <= DH the head's real width: the columns beyond dh are zeros (q . k gains + 0 terms, the sums are
+// unchanged bit for bit), so any head dim runs on the next compiled instance
 template <int DH>
 __global__ void __launch_bounds__(128)
-mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int D, float scale) {
+mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int D, int dh, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Ks = reinterpret_cast<float*>(smem_raw);
     float* Vs = Ks + (size_t)T * DH;
@@ -1022,14 +1024,14 @@ mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, i
     const float* base = qkv + (size_t)b * T * 3 * D;
     for (int i = threadIdx.x; i < T * DH; i += blockDim.x) {
         const int t = i / DH, c = i - t * DH;
-        Ks[i] = base[(size_t)t * 3 * D + D + head * DH + c];
-        Vs[i] = base[(size_t)t * 3 * D + 2 * D + head * DH + c];
+        Ks[i] = c < dh ? base[(size_t)t * 3 * D + D + head * dh + c] : 0.0f;
+        Vs[i] = c < dh ? base[(size_t)t * 3 * D + 2 * D + head * dh + c] : 0.0f;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         float q[DH], o[DH];
 #pragma unroll
-        for (int c = 0; c < DH; ++c) { q[c] = base[(size_t)t * 3 * D + head * DH + c] * scale; o[c] = 0.0f; }
+        for (int c = 0; c < DH; ++c) { q[c] = c < dh ? base[(size_t)t * 3 * D + head * dh + c] * scale : 0.0f; o[c] = 0.0f; }
         float mx = -INFINITY, den = 0.0f;
         for (int j = 0; j < T; ++j) {
             const float* kj = Ks + (size_t)j * DH;
@@ -1045,44 +1047,45 @@ mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, i
             mx = nm;
         }
         const float inv = 1.0f / den;
-        float* op = out + ((size_t)b * T + t) * D + head * DH;
+        float* op = out + ((size_t)b * T + t) * D + head * dh;
 #pragma unroll
-        for (int c = 0; c < DH; ++c) op[c] = o[c] * inv;
+        for (int c = 0; c < DH; ++c)
+            if (c < dh) op[c] = o[c] * inv;
     }
 }
 
-// head dims with a compiled instance (q and the output row live in registers, so DH is a template parameter):
-// every multiple of 4 up to 72, plus 18 and 36-style odd splits of the reference's default d_model = 144.
+// compiled widths (q and the output row live in registers, so the width is a template parameter): every multiple of 4 up to 72,
+// 18 (the reference's default d_model = 144 over 8 heads), then 80 / 96 / 112 / 128; a head dim in between runs zero-padded on the
+// next one (nn.MultiheadAttention takes any embed_dim divisible by num_heads, architectures.py:499)
 #define NWW_MHA_HEAD_DIMS(X) X(4) X(8) X(12) X(16) X(18) X(20) X(24) X(28) X(32) X(36) X(40) X(44) X(48) X(52) X(56) \
-    X(60) X(64) X(68) X(72)
+    X(60) X(64) X(68) X(72) X(80) X(96) X(112) X(128)
+static int mha_compiled_width(int dh) {
+    static const int widths[] = {4, 8, 12, 16, 18, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 80, 96, 112, 128};
+    for (int w : widths)
+        if (w >= dh) return w;
+    return 0;
+}
 hipError_t launch_mha_core(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s) {
-    const int dh = D / n_head;
-    const size_t lds = (size_t)2 * T * dh * sizeof(float);
-    if (lds > 150 * 1024 || dh * n_head != D) return hipErrorInvalidValue;
+    const int dh = D / n_head, dhw = mha_compiled_width(dh);
+    const size_t lds = (size_t)2 * T * dhw * sizeof(float);
+    if (dhw == 0 || lds > 150 * 1024 || dh * n_head != D) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(n_head, B);
 #define MHA_CASE(DHV)                                                                                              \
     case DHV: {                                                                                                    \
         hipError_t ea = nww_allow_lds(reinterpret_cast<const void*>(mha_core_kernel<DHV>), lds);                   \
         if (ea != hipSuccess) return ea;                                                                           \
-        hipLaunchKernelGGL((mha_core_kernel<DHV>), grid, dim3(128), lds, s, qkv, out, T, D, scale);                \
+        hipLaunchKernelGGL((mha_core_kernel<DHV>), grid, dim3(128), lds, s, qkv, out, T, D, dh, scale);            \
         break;                                                                                                     \
     }
-    switch (dh) {
+    switch (dhw) {
         NWW_MHA_HEAD_DIMS(MHA_CASE)
         default: return hipErrorInvalidValue;
     }
 #undef MHA_CASE
     return hipGetLastError();
 }
-bool mha_head_dim_supported(int dh) {
-#define MHA_OK(DHV) case DHV: return true;
-    switch (dh) {
-        NWW_MHA_HEAD_DIMS(MHA_OK)
-        default: return false;
-    }
-#undef MHA_OK
-}
+bool mha_head_dim_supported(int dh) { return dh >= 1 && mha_compiled_width(dh) > 0; }
 
 // ------------------------------------------------------------------------------------------ GRU recurrence
 // Gate functions of the register-resident recurrences on the hardware exp2 and reciprocal (1 ulp each): absolute error
@@ -1467,13 +1470,137 @@ __global__ void __launch_bounds__(64 * (H / 16), 1) lstm16_kernel(GruArgs a) {
 }
 
 // the split-operand recurrence serves this layer (plan time: the plan folds the reverse direction's single step into it)
+// ------------------------------------------------------------------------------------------ any-width recurrence
+// nn.GRU / nn.LSTM take any hidden_size (architectures.py:132-145,238-254); the kernels above want H % 4 == 0 (16-byte weight rows)
+// and H <= 256 (a wave per 32 hidden units).  This one takes any H <= 512: W_hh re-laid at plan time as [G H][ldw] rows padded with
+// zeros to ldw = H rounded up to 8 (rnn_pad_rows_kernel), a wave walks tiles wave, wave + 8 (32 hidden units each) one after the
+// other within a step, and h lives in TWO LDS buffers (read step t, write step t + 1: one barrier per step).  Gate arithmetic as in
+// gru_kernel / lstm_kernel (expf / tanhf).  G = 3: GRU, 4: LSTM.
+__global__ void __launch_bounds__(256) rnn_pad_rows_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int H, int ldw) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows * ldw) return;
+    const int r = (int)(idx / ldw), k = (int)(idx - (size_t)r * ldw);
+    out[idx] = k < H ? w[(size_t)r * H + k] : 0.0f;
+}
+size_t rnn_wide_weight_bytes(int gates, int H) { return (size_t)gates * H * ((H + 7) & ~7) * sizeof(float); }
+hipError_t launch_rnn_pad_weights(const float* w_hh, float* out, int gates, int H, hipStream_t s) {
+    const int ldw = (H + 7) & ~7;
+    const size_t total = (size_t)gates * H * ldw;
+    hipLaunchKernelGGL(rnn_pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_hh, out, gates * H, H, ldw);
+    return hipGetLastError();
+}
+
+template <int G>
+__global__ void __launch_bounds__(512) rnn_wide_kernel(GruArgs a) {
+    constexpr int TP = 2;                                     // tiles per wave: 8 waves x 2 x 32 = 512 hidden units
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int H = a.H, ldw = a.ldw, ldh = ldw + 4;
+    float* hbuf[2] = {reinterpret_cast<float*>(smem_raw), reinterpret_cast<float*>(smem_raw) + (size_t)32 * ldh};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b0 = blockIdx.x * 32;
+    const int ntile = (H + 31) / 32;
+    for (int idx = threadIdx.x; idx < 2 * 32 * ldh; idx += blockDim.x) hbuf[0][idx] = 0.0f;
+    float hprev[TP][16], cprev[TP][16];
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hprev[tp][r] = 0.0f; cprev[tp][r] = 0.0f; }
+    __syncthreads();
+    for (int step = 0; step < a.steps; ++step) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        const float* cur = hbuf[step & 1];
+        float* nxt = hbuf[(step & 1) ^ 1];
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+            const int tile = wave + 8 * tp;
+            if (tile >= ntile) continue;                      // (wave-uniform)
+            const int j = tile * 32 + i;
+            const bool jok = j < H;
+            const int jc = jok ? j : H - 1;
+            f32x16 acc[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+            if (step > 0) {
+                const float* arow = cur + (size_t)i * ldh + 4 * hh;
+                const float* wq[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) wq[q] = a.w_hh + (size_t)(q * H + jc) * ldw + 4 * hh;
+                for (int k = 0; k < ldw; k += 8) {
+                    const float4 av = *reinterpret_cast<const float4*>(arow + k);
+                    float4 bw[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) bw[q] = *reinterpret_cast<const float4*>(wq[q] + k);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw[q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw[q].w, acc[q], 0, 0, 0);
+                }
+            }
+            float bh[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) bh[q] = a.b_hh[q * H + jc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int b = b0 + c;
+                float hn = 0.0f, cn = 0.0f;
+                if (b < a.B && jok) {
+                    const float* xg = a.xg + ((size_t)b * a.T + t) * G * H + j;
+                    if (G == 3) {
+                        const float rg = 1.0f / (1.0f + expf(-(xg[0] + acc[0][r] + bh[0])));
+                        const float zg = 1.0f / (1.0f + expf(-(xg[H] + acc[1][r] + bh[1])));
+                        const float ng = tanhf(xg[2 * H] + rg * (acc[2][r] + bh[2]));
+                        hn = (1.0f - zg) * ng + zg * hprev[tp][r];
+                    } else {
+                        const float ig = 1.0f / (1.0f + expf(-(xg[0] + acc[0][r] + bh[0])));
+                        const float fg = 1.0f / (1.0f + expf(-(xg[H] + acc[1][r] + bh[1])));
+                        const float gg = tanhf(xg[2 * H] + acc[2][r] + bh[2]);
+                        const float og = 1.0f / (1.0f + expf(-(xg[3 * H] + acc[G - 1][r] + bh[G - 1])));
+                        cn = fg * cprev[tp][r] + ig * gg;
+                        hn = og * tanhf(cn);
+                    }
+                    if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
+                    if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
+                }
+                hprev[tp][r] = hn; cprev[tp][r] = cn;
+                if (jok) nxt[(size_t)c * ldh + j] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static hipError_t launch_rnn_wide(const GruArgs& a, int gates, hipStream_t s) {
+    if (a.H < 1 || a.H > 512 || a.ldw != ((a.H + 7) & ~7) || a.xg2) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * 32 * (a.ldw + 4) * sizeof(float);
+    const dim3 grid((a.B + 31) / 32);
+    if (gates == 3) {
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(rnn_wide_kernel<3>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rnn_wide_kernel<3>, grid, dim3(512), lds, s, a);
+    } else {
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(rnn_wide_kernel<4>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rnn_wide_kernel<4>, grid, dim3(512), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
 bool rnn_x3_enabled(const GruArgs& a) {
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
     return use16 && rnn_x3_usable(a);
 }
 
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
-    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
+    if (a.ldw) return launch_rnn_wide(a, 4, s);                      // padded weights: the any-width kernel (planned for H % 4 != 0 or H > 256)
+    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
     if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 4, s);
     if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step
@@ -1498,7 +1625,8 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
-    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads (nww_create refuses wider layers)
+    if (a.ldw) return launch_rnn_wide(a, 3, s);
+    if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
     if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 3, s);
     if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step

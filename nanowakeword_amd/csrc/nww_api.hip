@@ -83,15 +83,15 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     if (c.n_mels <= 0 || c.n_mels > FE_MAX_MELS) return fail(nullptr, NWW_ERR_INVALID, "n_mels must be in 1..%d", FE_MAX_MELS);
     if (c.head_type == NWW_HEAD_CRNN && (c.n_crnn_channels < 1 || c.n_crnn_channels > 4))
         return fail(nullptr, NWW_ERR_INVALID, "crnn_cnn_channels must have 1..4 stages");
-    if ((c.head_type == NWW_HEAD_CRNN || c.head_type == NWW_HEAD_GRU) && (c.layer_dim % 4 != 0 || c.layer_dim > 256))
-        return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be a multiple of 4 and <= 256", c.layer_dim);
+    if ((c.head_type == NWW_HEAD_CRNN || c.head_type == NWW_HEAD_GRU) && c.layer_dim > 512)
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be <= 512", c.layer_dim);
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
     if (c.act_dtype != NWW_ACT_DTYPE_F32 && c.act_dtype != NWW_ACT_DTYPE_BF16) return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_DTYPE_F32 or NWW_ACT_DTYPE_BF16");
     if (c.act_dtype == NWW_ACT_DTYPE_BF16 && c.head_type != NWW_HEAD_BCRESNET)
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 is implemented for the BcResNet head only (BASELINE config 3)");
     if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
-        return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d has no compiled kernel (multiples of 4 up to 72, or 18)",
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d is wider than the widest compiled kernel (128)",
                     c.conformer_d_model / c.conformer_n_head);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

@@ -395,6 +395,15 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
             if (fold && dir == 0) continue;                  // the forward recurrence is launched after the reverse projection
             const int in_T = T;
             const float* whh_f = fold ? p.W(prefix + ".weight_hh_l" + std::to_string(l)) : whh;
+            // widths the register-resident / 32-units-per-wave kernels do not take: zero-padded weight rows for the any-width kernel
+            int ldw = 0;
+            if (H % 4 != 0 || H > 256) {
+                float* padded = nullptr;
+                if (hipMalloc(&padded, rnn_wide_weight_bytes(G, H)) == hipSuccess && launch_rnn_pad_weights(whh_f, padded, G, H, p.h->own_stream) == hipSuccess) {
+                    p.h->packed_weights.push_back(padded);
+                    whh_f = padded; ldw = (H + 7) & ~7;
+                } else if (padded) (void)hipFree(padded);
+            }
             const float* bhh_f = fold ? p.W(prefix + ".bias_hh_l" + std::to_string(l)) : bhh;
             const std::string nm = fold ? (G == 4 ? "lstm:" : "gru:") + prefix + "_l" + std::to_string(l) + " + first reverse step"
                                         : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
@@ -404,7 +413,7 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                 a.xg = r.buf[xg_id]; a.w_hh = whh_f; a.b_hh = bhh_f;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
                 a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H;
-                a.B = r.B; a.T = in_T; a.H = H;
+                a.B = r.B; a.T = in_T; a.H = H; a.ldw = ldw;
                 if (fold) {
                     a.col_off = 0; a.reverse = 0; a.steps = in_T;
                     a.xg2 = r.buf[xg_id] + (size_t)r.B * in_T * G * H; a.xg2_bstride = (size_t)G * H; a.b_hh2 = bhh; a.col_off2 = H;

@@ -225,10 +225,10 @@ def test_batch_invariance_full_size(hip, golden_frontend):
     m.close()
 
 
-@pytest.mark.parametrize("d_model,n_head", [(32, 8), (80, 4), (144, 8), (96, 2), (144, 2)])
+@pytest.mark.parametrize("d_model,n_head", [(32, 8), (80, 4), (144, 8), (96, 2), (144, 2), (66, 2), (50, 2), (90, 6), (250, 2), (186, 2)])
 def test_conformer_attention_head_dims(hip, d_model, n_head):
-    """Every compiled attention head_dim (4, 20, 18, 48, 72 here) against the oracle; an uncompiled one is refused
-    when the model is created, not at the first batch."""
+    """Compiled attention head dims (4, 20, 18, 48, 72) and ones in between / above (33, 25, 15, 125, 93: zero-padded onto the
+    next compiled width; d_model itself need not be a multiple of 4) against the oracle."""
     HipModel, _ = hip
     cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=d_model, conformer_n_head=n_head)
     sd = synth_state_dict(cfg)
@@ -260,9 +260,10 @@ def test_conformer_fused_kernels_every_width(hip, d_model, n_head, shape, B):
 
 
 def test_conformer_unsupported_head_dim_is_refused_at_create(hip):
+    """a head wider than the widest compiled attention kernel (128) is refused when the model is created, not at the first batch"""
     HipModel, _ = hip
-    cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=66, conformer_n_head=2)
-    with pytest.raises(NotImplementedError, match="head_dim 33"):
+    cfg = HeadConfig("conformer", (16, 24), embedding_dim=16, conformer_d_model=260, conformer_n_head=2)
+    with pytest.raises(NotImplementedError, match="head_dim 130"):
         HipModel(cfg, FrontendConfig())
 
 

@@ -296,10 +296,26 @@ def test_bcresnet_front_kernel_odd_shapes(HipModel):
 
 
 def test_wide_recurrent_layers_are_refused_loudly(HipModel):
-    """layer_dim in (256, 512] has no compiled recurrent kernel: nww_create must say so (not fail at the first launch)."""
+    """layer_dim > 512 has no recurrent kernel: nww_create must say so (not fail at the first launch)."""
     for mt in ("gru", "crnn"):
-        with pytest.raises(Exception, match="256"):
-            HipModel(HeadConfig(mt, (16, 96), layer_dim=384), FrontendConfig())
+        with pytest.raises(Exception, match="512"):
+            HipModel(HeadConfig(mt, (16, 96), layer_dim=520), FrontendConfig())
+
+
+@pytest.mark.parametrize("mt,rnn,H,nb,shape", [("gru", "gru", 384, 1, (16, 96)), ("gru", "gru", 37, 2, (20, 40)), ("crnn", "lstm", 260, 1, (32, 64)),
+                                               ("crnn", "gru", 512, 1, (16, 96)), ("crnn", "lstm", 6, 2, (16, 96)), ("crnn", "lstm", 512, 1, (16, 32))])
+def test_any_recurrent_width(HipModel, mt, rnn, H, nb, shape):
+    """nn.GRU / nn.LSTM take any hidden_size (architectures.py:132-145,238-254): widths that are not a multiple of 4 or exceed 256
+    run on the any-width kernel (zero-padded W_hh rows, two hidden-unit tiles per wave) - against the oracle, ragged batches."""
+    cfg = HeadConfig(mt, shape, layer_dim=H, n_blocks=nb, crnn_rnn_type=rnn, embedding_dim=16)
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(n_mels=min(shape[1], 64)), state_dict=sd)
+    for B in (1, 5, 33, 70):
+        x = synth_features(B, cfg.input_shape, seed=H + B)
+        lg, _ = m.forward_features(x)
+        want = oracle.model_forward(x, sd, cfg).ravel()
+        assert np.abs(lg - want).max() <= 1e-4, (mt, rnn, H, B, float(np.abs(lg - want).max()))
+    m.close()
 
 
 def test_bcresnet_bf16_activations(HipModel, golden_frontend):
@@ -345,10 +361,7 @@ def test_bcresnet_bf16_activations(HipModel, golden_frontend):
         HipModel(HeadConfig("cnn", (101, 64)), FrontendConfig(), act_dtype="bf16")
 
 
-# cases of heads_r04.npz the library still refuses at nww_create (VERDICT r03 "widen the refusals"); removed from this set
-# as their kernels land
-R04_REFUSED = {"gru_16x96_h130", "gru_16x96_h320_b2", "crnn_lstm_16x96_h512", "crnn_gru_101x64_h300", "crnn_lstm_98x40_h21",
-               "conformer_16x96_d100_h4", "conformer_101x64_d160_h2", "conformer_16x96_d66_h6"}
+R04_REFUSED = set()          # every shape of heads_r04.npz runs (round 4: any recurrent width <= 512, any attention head dim <= 128)
 
 
 @pytest.mark.parametrize("name", head_case_names_r04())

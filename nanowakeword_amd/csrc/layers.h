@@ -155,6 +155,13 @@ struct TailArgs {
     // *done_flag = done_seq (system scope, after the logits / probabilities) - the host polls it instead of paying the
     // runtime's stream synchronisation
     unsigned int* done_flag = nullptr; unsigned int done_seq = 0;
+    // DNN head (Net, architectures.py:102-126) behind its first Linear, in the same launch: x <- act(LayerNorm(x; ln0_w, ln0_b)), then
+    // n_mid times x <- act(LayerNorm(x mid_W[i]^T + mid_b[i]; mid_lnw[i], mid_lnb[i])) with [Kin][Kin] weights, then the tail above.
+    // Used at EVERY batch size (a clip's logit must not depend on the batch it travels in); Kin <= 256, n_mid <= 4.
+    const float *ln0_w = nullptr, *ln0_b = nullptr;
+    int n_mid = 0;
+    const float *mid_W[4] = {nullptr, nullptr, nullptr, nullptr}, *mid_b[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float *mid_lnw[4] = {nullptr, nullptr, nullptr, nullptr}, *mid_lnb[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 bool tail_supported(int Kin, int E);
 hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s);

@@ -1678,19 +1678,44 @@ __device__ __forceinline__ void tail_dot4(const float* __restrict__ xr, const fl
     }
 }
 
-template <int ACT>
+// CT clips per workgroup pass (16, or 4 for small batches: four times the threads per clip), NG = 256 / CT output groups; a thread
+// computes outputs g, g + NG, g + 2 NG, g + 3 NG at a time, each ONE fmaf chain in ascending k whatever CT is - a clip's results
+// do not depend on the tile shape (batch invariance).
+template <int ACT, int CT>
 __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
+    constexpr int NG = 256 / CT;
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     const int Kin = a.Kin, E = a.E, Hd = E / 2;
     const int ldx = ((Kin + 3) & ~3) + 4, lde = ((E + 3) & ~3) + 4, ldh = Hd + 1;      // 16-byte aligned rows, +4: conflict-free
-    float* xs = tsm;                      // [16][ldx]
-    float* es = xs + 16 * ldx;            // [16][lde]
-    float* hs = es + 16 * lde;            // [16][ldh]
-    const int tid = threadIdx.x, c = tid & 15, g = tid >> 4;                          // clip slot, output group (16 groups)
+    float* xs = tsm;                      // [CT][ldx]
+    float* es = xs + CT * ldx;            // [CT][lde]
+    float* hs = es + CT * lde;            // [CT][ldh]
+    float* ys = hs + CT * ldh;            // [16][ldx]: the DNN body's second tile (a.ln0_w only)
+    // LayerNorm + activation of the 16 tile rows, in place or into another tile: a wave per row (four rows each), the row in four
+    // registers per lane - layernorm_kernel's arithmetic (Kin <= 256)
+    auto tile_ln = [&](const float* src, float* dst, const float* w, const float* b) {
+        const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+        for (int r = (CT / 4) * wv; r < (CT / 4) * (wv + 1); ++r) {
+            float v[4], sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = lane + 64 * j; v[j] = i < Kin ? src[r * ldx + i] : 0.0f; sum += v[j]; }
+            const float mu = wave_sum(sum) / (float)Kin;
+            float q = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[j] - mu; if (lane + 64 * j < Kin) q = fmaf(d, d, q); }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)Kin + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;
+                if (i < Kin) dst[r * ldx + i] = act_ct<ACT>((v[j] - mu) * rstd * w[i] + b[i]);
+            }
+        }
+    };
+    const int tid = threadIdx.x, c = tid % CT, g = tid / CT;                          // clip slot, output group
     const bool vx = (Kin & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.We) & 15) == 0);
     const bool ve = (E & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.W0) & 15) == 0);
-    for (int b0 = blockIdx.x * 16; b0 < a.B; b0 += gridDim.x * 16) {
-        for (int idx = tid; idx < 16 * Kin; idx += 256) {
+    for (int b0 = blockIdx.x * CT; b0 < a.B; b0 += gridDim.x * CT) {
+        for (int idx = tid; idx < CT * Kin; idx += 256) {
             const int cc = idx / Kin, k = idx - cc * Kin;
             float v = 0.0f;
             if (b0 + cc < a.B) {
@@ -1716,12 +1741,32 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
             xs[cc * ldx + k] = v;
         }
         __syncthreads();
+        if (a.ln0_w) {                                         // the DNN body (wave-uniform)
+            tile_ln(xs, xs, a.ln0_w, a.ln0_b);
+            __syncthreads();
+            for (int m = 0; m < a.n_mid; ++m) {
+                const float* Wm = a.mid_W[m];
+                const bool vm = (Kin & 3) == 0 && ((reinterpret_cast<uintptr_t>(Wm) & 15) == 0);
+                for (int e0 = g; e0 < Kin; e0 += 4 * NG) {
+                    const int e1 = min(e0 + NG, Kin - 1), e2 = min(e0 + 2 * NG, Kin - 1), e3 = min(e0 + 3 * NG, Kin - 1);
+                    float acc[4];
+                    tail_dot4(xs + c * ldx, Wm + (size_t)e0 * Kin, Wm + (size_t)e1 * Kin, Wm + (size_t)e2 * Kin, Wm + (size_t)e3 * Kin, Kin, vm, acc);
+                    const int eo[4] = {e0, e0 + NG, e0 + 2 * NG, e0 + 3 * NG};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (eo[r] < Kin) ys[c * ldx + eo[r]] = acc[r] + a.mid_b[m][eo[r]];
+                }
+                __syncthreads();
+                tile_ln(ys, xs, a.mid_lnw[m], a.mid_lnb[m]);
+                __syncthreads();
+            }
+        }
         // embedding: outputs e = g, g+16, ...; four at a time
-        for (int e0 = g; e0 < E; e0 += 64) {
-            const int e1 = min(e0 + 16, E - 1), e2 = min(e0 + 32, E - 1), e3 = min(e0 + 48, E - 1);
+        for (int e0 = g; e0 < E; e0 += 4 * NG) {
+            const int e1 = min(e0 + NG, E - 1), e2 = min(e0 + 2 * NG, E - 1), e3 = min(e0 + 3 * NG, E - 1);
             float acc[4];
             tail_dot4(xs + c * ldx, a.We + (size_t)e0 * Kin, a.We + (size_t)e1 * Kin, a.We + (size_t)e2 * Kin, a.We + (size_t)e3 * Kin, Kin, vx, acc);
-            const int es_[4] = {e0, e0 + 16, e0 + 32, e0 + 48};
+            const int es_[4] = {e0, e0 + NG, e0 + 2 * NG, e0 + 3 * NG};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (es_[r] < E) {
@@ -1731,17 +1776,17 @@ __global__ void __launch_bounds__(256) classifier_tail_kernel(TailArgs a) {
                 }
         }
         __syncthreads();
-        for (int j0 = g; j0 < Hd; j0 += 64) {
-            const int j1 = min(j0 + 16, Hd - 1), j2 = min(j0 + 32, Hd - 1), j3 = min(j0 + 48, Hd - 1);
+        for (int j0 = g; j0 < Hd; j0 += 4 * NG) {
+            const int j1 = min(j0 + NG, Hd - 1), j2 = min(j0 + 2 * NG, Hd - 1), j3 = min(j0 + 3 * NG, Hd - 1);
             float acc[4];
             tail_dot4(es + c * lde, a.W0 + (size_t)j0 * E, a.W0 + (size_t)j1 * E, a.W0 + (size_t)j2 * E, a.W0 + (size_t)j3 * E, E, ve, acc);
-            const int js[4] = {j0, j0 + 16, j0 + 32, j0 + 48};
+            const int js[4] = {j0, j0 + NG, j0 + 2 * NG, j0 + 3 * NG};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (js[r] < Hd) hs[c * ldh + js[r]] = act_ct<ACT>(acc[r] + a.b0[js[r]]);
         }
         __syncthreads();
-        if (tid < 16 && b0 + tid < a.B) {                      // (tid 0 is among them when B >= 1: its stores precede the flag)
+        if (tid < CT && b0 + tid < a.B) {                      // (tid 0 is among them when B >= 1: its stores precede the flag)
             const float* hr = hs + tid * ldh;
             float acc = 0.0f;
             for (int j = 0; j < Hd; ++j) acc = fmaf(hr[j], a.w3[j], acc);
@@ -1762,12 +1807,25 @@ bool tail_supported(int Kin, int E) { return Kin >= 1 && Kin <= 512 && E >= 2 &&
 
 hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s) {
     if (!tail_supported(a.Kin, a.E)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)16 * ((((a.Kin + 3) & ~3) + 4) + (((a.E + 3) & ~3) + 4) + (a.E / 2 + 1)) * sizeof(float);
-    int grid = (a.B + 15) / 16;
+    if (a.ln0_w && (a.Kin > 256 || a.n_mid < 0 || a.n_mid > 4)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)16 * ((a.ln0_w ? 2 : 1) * (((a.Kin + 3) & ~3) + 4) + (((a.E + 3) & ~3) + 4) + (a.E / 2 + 1)) * sizeof(float);
+    // small batches: four clips per workgroup (64 threads per clip instead of 16; measured at B = 32 / 1024 / 4096: DNN body + tail
+    // 0.035 -> 0.021 ms, CRNN tail 0.0255 -> 0.022, CNN tail 0.020 -> 0.029).  B = 5 .. 16 keep ONE 16-clip workgroup: the
+    // completion word of the interpreter's zero-copy calls is written by a launch of a single workgroup only
+    static const int ct4_max = [] { const char* e = getenv("NWW_TAIL_CT4_MAX"); return e ? atoi(e) : 1024; }();
+    const bool small = a.B <= 4 || (a.B > 16 && a.B <= ct4_max);
+    const int ct = small ? 4 : 16;
+    int grid = (a.B + ct - 1) / ct;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
-#define TAIL_CALL(A) hipLaunchKernelGGL((classifier_tail_kernel<A>), dim3(grid), dim3(256), lds, s, a)
-    NWW_DISPATCH_ACT(a.act, TAIL_CALL)
+    if (small) {
+#define TAIL_CALL(A) hipLaunchKernelGGL((classifier_tail_kernel<A, 4>), dim3(grid), dim3(256), lds, s, a)
+        NWW_DISPATCH_ACT(a.act, TAIL_CALL)
 #undef TAIL_CALL
+    } else {
+#define TAIL_CALL(A) hipLaunchKernelGGL((classifier_tail_kernel<A, 16>), dim3(grid), dim3(256), lds, s, a)
+        NWW_DISPATCH_ACT(a.act, TAIL_CALL)
+#undef TAIL_CALL
+    }
     return hipGetLastError();
 }

@@ -143,6 +143,8 @@ struct PlanCtx {
     void pop_last() { if (!h->plan.empty()) h->plan.pop_back(); }        // a step just planned is re-planned in another form
     // the head's last Linear (-> embedding), deferred so that it can be fused with the classifier into one launch
     std::string tail_name; int tail_in = 99, tail_K = 0; const float *tail_W = nullptr, *tail_b = nullptr;
+    // DNN: LayerNorm1 + blocks run inside the tail's launch (TailArgs::ln0_w)
+    bool dnn_body = false; const float *dnn_ln0_w = nullptr, *dnn_ln0_b = nullptr; int dnn_n_mid = 0; const float* dnn_mid[4][4] = {};
 };
 
 // source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
@@ -514,6 +516,23 @@ extern "C" int nww_finalize(nww_handle* h) {
     const int T = c.in_rows, F = c.in_cols, L = c.layer_dim, E = c.embedding_dim, nb = c.n_blocks, act = c.activation;
     switch (c.head_type) {
         case NWW_HEAD_DNN: {                      // Net: architectures.py:110-126
+            // Everything behind layer1 runs inside the tail's launch (layers.hip: TailArgs::ln0_w) when the widths allow: LayerNorm1 on
+            // layer1's split-K partials, the blocks' Linear + LayerNorm, last_layer, classifier - two launches per forward instead of six
+            static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
+            static const int body_on = [] { const char* e = getenv("NWW_DNN_BODY"); return e ? atoi(e) : 1; }();
+            if (tail_on && body_on && L <= 256 && nb <= 4 && tail_supported(L, E)) {
+                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
+                p.dnn_body = true;
+                p.dnn_ln0_w = p.W("model.layernorm1.weight"); p.dnn_ln0_b = p.W("model.layernorm1.bias");
+                p.dnn_n_mid = nb;
+                for (int i = 0; i < nb; ++i) {
+                    const std::string q = "model.blocks." + std::to_string(i);
+                    p.dnn_mid[i][0] = p.W(q + ".fcn_layer.weight"); p.dnn_mid[i][1] = p.W(q + ".fcn_layer.bias");
+                    p.dnn_mid[i][2] = p.W(q + ".layer_norm.weight"); p.dnn_mid[i][3] = p.W(q + ".layer_norm.bias");
+                }
+                set_tail(p, "layernorm1+blocks+last_layer", 0, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
+                break;
+            }
             add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
             {
                 const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
@@ -870,8 +889,13 @@ extern "C" int nww_finalize(nww_handle* h) {
         const float *We = p.tail_W, *be = p.tail_b, *W0 = p.W("classifier.0.weight"), *b0 = p.W("classifier.0.bias"),
                     *w3 = p.W("classifier.3.weight"), *b3 = p.W("classifier.3.bias");
         const int tin = p.tail_in, tK = p.tail_K;
+        const PlanCtx pc = p;                                   // (the DNN body's pointers, by value)
         p.add("tail:" + p.tail_name + "+classifier", [=](Run& r) {
             TailArgs t{src(r, tin), tK, We, be, E, W0, b0, w3, b3, r.emb, r.logits, r.probs, r.B, act};
+            if (pc.dnn_body) {
+                t.ln0_w = pc.dnn_ln0_w; t.ln0_b = pc.dnn_ln0_b; t.n_mid = pc.dnn_n_mid;
+                for (int i = 0; i < pc.dnn_n_mid; ++i) { t.mid_W[i] = pc.dnn_mid[i][0]; t.mid_b[i] = pc.dnn_mid[i][1]; t.mid_lnw[i] = pc.dnn_mid[i][2]; t.mid_lnb[i] = pc.dnn_mid[i][3]; }
+            }
             if (r.deferred.active && r.deferred.out_id == tin) {
                 t.parts = r.splitk_ws; t.nparts = r.deferred.parts; t.part_stride = r.deferred.stride;
                 t.in_bias = r.deferred.bias; t.in_alpha = r.deferred.alpha; t.in_beta = r.deferred.beta; t.in_act = r.deferred.act;

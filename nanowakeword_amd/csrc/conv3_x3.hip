@@ -74,7 +74,15 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     const float bias = a.bias ? a.bias[cout] : 0.0f;
     const float al = a.alpha ? a.alpha[cout] : 1.0f, be = a.alpha ? a.beta[cout] : 0.0f;
     const bool bn = a.alpha != nullptr;
-    const int nRp = POOL ? H / 2 : (H + 1) / 2, nX = (W + 15) / 16, nT = nRp * nX;
+    const int nRp = POOL ? H / 2 : (H + 1) / 2, nX = (W + 15) / 16;
+    // streaming hop: pooled rows [keep_lo, keep_hi] come from the previous hop's sequence buffer, the tile rows outside are computed
+    const bool carry = POOL && a.seq_out && a.seq_prev != nullptr && a.keep_hi >= a.keep_lo;
+    const int n_keep = carry ? a.keep_hi - a.keep_lo + 1 : 0;
+    const int nT = (nRp - n_keep) * nX;
+    auto tile_of = [&](int u) {                                 // u-th computed tile -> tile index R * nX + X
+        const int Ru = u / nX, Xu = u - Ru * nX;
+        return (carry && Ru >= a.keep_lo ? Ru + n_keep : Ru) * nX + Xu;
+    };
     const int t_base = nT / NW, t_rem = nT - t_base * NW;
     const int t_begin = wave * t_base + min(wave, t_rem), t_end = t_begin + t_base + (wave < t_rem ? 1 : 0);
     const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
@@ -125,10 +133,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     };
 
     // conv for tile t (and t + 1 when TWO): 9 taps x 2 sixteen-channel blocks x 6 products
-    auto tiles = [&](int t, auto two_c, float* outb, float* wsum, AvgWin aw) {
+    auto tiles = [&](int u, auto two_c, float* outb, float* wsum, AvgWin aw) {
         constexpr bool TWO = decltype(two_c)::value;
+        const int t = tile_of(u);
         const int R0 = t / nX, X0 = t - R0 * nX;
-        const int t1 = TWO ? t + 1 : t;
+        const int t1 = TWO ? tile_of(u + 1) : t;
         const int R1 = t1 / nX, X1 = t1 - R1 * nX;
         const unsigned char* pa = A3 + lane_off + (2 * R0) * rowB + 16 * X0 * PS3;
         const unsigned char* pb = A3 + lane_off + (2 * R1) * rowB + 16 * X1 * PS3;
@@ -238,6 +247,13 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         int t = t_begin;
         for (; t + 1 < t_end; t += 2) tiles(t, std::true_type{}, outb, wsum, aw);
         if (t < t_end) tiles(t, std::false_type{}, outb, wsum, aw);
+        if (carry) {                                           // kept rows: the previous hop's values, keep_shift rows further down
+            const float* prev = a.seq_prev + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho;
+            for (int idx = tid; idx < Wo * 32 * n_keep; idx += NTHR) {
+                const int x = idx / (32 * n_keep), r2 = idx - x * (32 * n_keep), c = r2 / n_keep, j = a.keep_lo + (r2 - c * n_keep);
+                outb[(size_t)x * seq_ch + c * Ho + j] = prev[(size_t)x * seq_ch + c * Ho + j + a.keep_shift];
+            }
+        }
         if (AVG) *reinterpret_cast<float4*>(my_part) = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
         __syncthreads();                                       // every wave is done reading A3; partials visible
         if (AVG) {

@@ -292,6 +292,10 @@ int nww_run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float*
             const int W2 = h->stream_W / 4;
             r.a2_ring = h->d_a2_ring; r.a2_rows = h->a2_rows; r.a2_row0 = h->a2_pos;
             r.a2_ch_stride = (size_t)h->a2_rows * W2; r.a2_clip_stride = 32 * r.a2_ch_stride;
+            if (h->d_seq[0]) {
+                r.seq_new = h->d_seq[h->seq_cur];
+                if (r.stream_mode == 2) { r.seq_prev = h->d_seq[h->seq_cur ^ 1]; r.a3_lo = h->a3_lo; r.a3_hi = h->a3_hi; r.a3_shift = h->a3_shift; }
+            }
             if (r.stream_mode == 2) {
                 const int H2 = h->stream_H / 4;
                 r.a2_nsub = 0;

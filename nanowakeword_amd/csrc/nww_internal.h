@@ -48,6 +48,9 @@ struct Run {
     int stream_mode = 0;
     float* a2_ring = nullptr; int a2_rows = 0, a2_row0 = 0; size_t a2_ch_stride = 0, a2_clip_stride = 0;
     int a2_nsub = 0, a2_sub_a[2] = {0, 0}, a2_sub_b[2] = {0, 0};
+    // the third conv's sequence output lives in two per-stream buffers that alternate from hop to hop: rows [a3_lo, a3_hi] of the new
+    // one are rows + a3_shift of the previous one, the others are computed (stream_mode 2); null: the plan's workspace buffer
+    float* seq_new = nullptr; const float* seq_prev = nullptr; int a3_lo = 0, a3_hi = -1, a3_shift = 0;
     bool x_frames_major = false; // E2E head on the transposed plane: x came from the frontend as [B][frames][n_mels] already
     float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* emb = nullptr;       // [B][E]
@@ -100,6 +103,9 @@ struct nww_handle {
     bool inc_fe = false, inc_conv = false, primed = false;
     float* d_lm_ring = nullptr; int lm_rows = 0, lm_pos = 0, lm_shift = 0, fe_edge_l = 0, fe_edge_r = 0;
     float* d_a2_ring = nullptr; int a2_rows = 0, a2_pos = 0, a2_shift = 0, a2_lo = 0, a2_hi = 0;
+    bool stream_seq = false;       // plan time: that third conv writes the recurrent layers' sequence layout (its rows can be carried over)
+    size_t seq_floats = 0;         // ... floats per clip of it
+    float* d_seq[2] = {nullptr, nullptr}; int seq_cur = 0, a3_lo = 0, a3_hi = -1, a3_shift = 0;
     struct { bool on = false; size_t x_stride = 0; int mode = 0; } sr;    // what the next nww_run_head hands to its Run
     EmbState* emb = nullptr;       // embedding-mode preprocessor state (nww_emb_*)
     void* comm = nullptr;          // ncclComm_t of this rank (nww_comm_init)

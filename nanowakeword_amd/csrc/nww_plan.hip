@@ -325,6 +325,11 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
             if (ring_ok && r.stream_mode) {             // streaming hop: the fused trunk's pooled rows are read from their rings
                 a.in = r.a2_ring; a.in_ring_rows = r.a2_rows; a.in_row0 = r.a2_row0;
                 a.in_ch_stride = r.a2_ch_stride; a.in_clip_stride = r.a2_clip_stride;
+                if (seq_out && r.seq_new) {             // ... and the sequence rows a hop does not invalidate are carried over from the previous hop's buffer
+                    r.buf[out_id] = r.seq_new;          // (the recurrent layers planned behind this step read r.buf[out_id])
+                    a.out = r.seq_new;
+                    a.seq_prev = r.seq_prev; a.keep_lo = r.a3_lo; a.keep_hi = r.a3_hi; a.keep_shift = r.a3_shift;
+                }
             }
             return launch_conv3_x3(a, max_grid * per_cu, r.stream);
         });
@@ -672,7 +677,11 @@ extern "C" int nww_finalize(nww_handle* h) {
                     seq = false;
                     add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);
                 }
-                if (ring) { h->stream_conv = true; h->stream_H = T; h->stream_W = F; }
+                if (ring) {
+                    h->stream_conv = true; h->stream_H = T; h->stream_W = F;
+                    h->stream_seq = seq && i == c.n_crnn_channels - 1;
+                    h->seq_floats = (size_t)c.crnn_channels[i] * (hh / 2) * (ww / 2);
+                }
                 seq_written = seq;
                 hh /= 2; ww /= 2; cin = c.crnn_channels[i]; cur = out;
             }

@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(256) stream_gather_kernel(const float4* __rest
 static void free_inc(nww_handle* h) {
     if (h->d_lm_ring) (void)hipFree(h->d_lm_ring);
     if (h->d_a2_ring) (void)hipFree(h->d_a2_ring);
+    for (int q = 0; q < 2; ++q) { if (h->d_seq[q]) (void)hipFree(h->d_seq[q]); h->d_seq[q] = nullptr; }
+    h->seq_cur = 0; h->a3_hi = -1;
     h->d_lm_ring = nullptr; h->d_a2_ring = nullptr;
     h->inc_fe = h->inc_conv = h->primed = false;
     h->lm_rows = h->lm_pos = h->lm_shift = h->a2_rows = h->a2_pos = h->a2_shift = 0;
@@ -56,9 +58,12 @@ extern "C" int nww_stream_close(nww_handle* h) {
 // window): per hop only frames [0, fe_edge_l) and [T - fe_edge_r - k, T) are computed, into a ring of log-mel rows per stream.
 // Likewise pooled row j of the fused trunk (input rows 4j - 3 .. 4j + 6) equals row j + k / 4 of the previous window when those
 // rows are shifted interior frames in both windows: rows [a2_lo, a2_hi] are reused, the rest recomputed from the log-mel ring.
-// NWW_STREAM_INC = 0: every hop re-scores the whole window (rounds 1-3), 1: frontend only, 2 (default): frontend + conv rows.
+// And pooled row j of the third conv (input rows 8j - 7 .. 8j + 14) equals row j + k / 8 of the previous hop: its sequence output
+// alternates between two per-stream buffers, rows [a3_lo, a3_hi] copied over, the others computed.
+// NWW_STREAM_INC = 0: every hop re-scores the whole window (rounds 1-3), 1: frontend only, 2: + the fused trunk's rows, 3 (default):
+// + the third conv's rows.
 static int plan_incremental(nww_handle* h, int S, int W, int hop) {
-    static const int mode = [] { const char* e = getenv("NWW_STREAM_INC"); return e ? atoi(e) : 2; }();
+    static const int mode = [] { const char* e = getenv("NWW_STREAM_INC"); return e ? atoi(e) : 3; }();
     const nww_config& c = h->cfg;
     const int T = fe_num_frames(h->fe, W), hl = h->fe.hop;
     const bool frames_major = !c.mel_major_features || h->e2e_transposed;
@@ -80,6 +85,12 @@ static int plan_incremental(nww_handle* h, int S, int W, int hop) {
             h->a2_lo = lo; h->a2_hi = hi; h->a2_shift = k / 4; h->a2_rows = H2;
             HIP_TRY(h, hipMalloc(&h->d_a2_ring, (size_t)S * 32 * H2 * W2 * sizeof(float) + 16));
             h->inc_conv = true;
+            // pooled rows of the third conv (row j: input rows 8j - 7 .. 8j + 14) carried from hop to hop in its sequence layout
+            const int H3 = H2 / 2, lo3 = (el + 7 + 7) / 8, hi3 = (T - 1 - er - k - 14) >= 0 ? (T - 1 - er - k - 14) / 8 : -1;
+            if (mode >= 3 && h->stream_seq && (k % 8) == 0 && hi3 >= lo3 && hi3 < H3) {
+                for (int q = 0; q < 2; ++q) HIP_TRY(h, hipMalloc(&h->d_seq[q], (size_t)S * h->seq_floats * sizeof(float) + 16));
+                h->a3_lo = lo3; h->a3_hi = hi3; h->a3_shift = k / 8;
+            }
         }
     }
     return NWW_OK;
@@ -112,7 +123,7 @@ extern "C" int nww_stream_reset(nww_handle* h) {
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemset(h->d_ring, 0, (size_t)h->ring_S * 2 * h->ring_W * sizeof(int16_t)));
     h->ring_pos = 0; h->ring_filled = 0;
-    h->primed = false; h->lm_pos = 0; h->a2_pos = 0;          // the next full window is computed whole
+    h->primed = false; h->lm_pos = 0; h->a2_pos = 0; h->seq_cur = 0;      // the next full window is computed whole
     return NWW_OK;
 }
 
@@ -152,6 +163,7 @@ static int stream_hop_incremental(nww_handle* h, float* d_logits, float* d_probs
     if (rc) return rc;
     h->lm_pos = (h->lm_pos + k) % h->lm_rows;
     if (h->inc_conv) h->a2_pos = (h->a2_pos + h->a2_shift) % h->a2_rows;
+    if (h->d_seq[0]) h->seq_cur ^= 1;
     h->primed = true;
     return NWW_OK;
 }

@@ -111,7 +111,12 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
                     return n, dt
     n1, dt1 = timed(one, chunk, 1, seconds * 0.25)
     kw = {k: getattr(cfg, k) for k in ("layer_dim", "n_blocks", "embedding_dim", "activation") if hasattr(cfg, k)}
-    pool = pool_throughput(cfg.model_type, cfg.input_shape, 64, True, window, fb, workers, chunk=chunk, budget_s=max(2.0, seconds * 0.3), **kw)
+    # the pool at 0.6 x nproc workers (the reference's rule) and at a smaller count: container CPU quotas and the host's memory
+    # bandwidth decide which is faster; batches of 8 clips per task (the reference maps single clips)
+    pools = {}
+    for wk in sorted({max(1, min(16, ncpu)), workers}):
+        pools[wk] = pool_throughput(cfg.model_type, cfg.input_shape, 64, True, window, fb, wk, chunk=8, budget_s=max(2.0, seconds * 0.2), **kw)
+    pool = max(pools.values(), key=lambda r: r["rate"])
     # BASELINE config 1 exactly: DNN head on (98,40) no-centre log-mel, batches of 32
     from nanowakeword_amd.config import FrontendConfig, HeadConfig
     from nanowakeword_amd.session import torchaudio_tables
@@ -125,14 +130,15 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
         lm = oracle.frontend_logmel(c1_pcm, c1_w, c1_fb, n_mels=40, center=False).transpose(0, 2, 1)
         return oracle.model_forward(np.ascontiguousarray(lm), c1_sd, c1_cfg)
     c1n, c1dt = timed(c1_one, 32, 1, seconds * 0.1)
-    c1_pool = pool_throughput("dnn", (98, 40), 40, False, c1_w, c1_fb, workers, chunk=32, budget_s=max(1.5, seconds * 0.15))
+    c1_pool = pool_throughput("dnn", (98, 40), 40, False, c1_w, c1_fb, pool["workers"], chunk=32, budget_s=max(1.5, seconds * 0.15))
     return {"value": round(pool["rate"], 1), "unit": "clips/s", "cores": int(pool["workers"]), "kind": "port",
             "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu), "cpu_model": _cpu_model(),
+            "pool_clips_per_s_by_workers": {str(k): round(v["rate"], 1) for k, v in pools.items()},
             "config1_dnn_98x40_batch32": {"clips_per_s_1_thread": round(c1n / c1dt, 1),
                                           f"clips_per_s_{c1_pool['workers']}_workers": round(c1_pool["rate"], 1)},
-            "sample": f"{pool['clips']} synthetic 1 s clips in batches of {chunk} through oracle/ (numpy float32, dense-DFT frontend + "
-                      f"{cfg.model_type} head) by {pool['workers']} single-threaded worker processes (0.6 x {ncpu} CPUs, the reference's "
-                      f"batch-path pool: transform_clips.py:441) side by side for {pool['seconds']:.1f} s each; value_1thread: {n1} clips "
+            "sample": f"{pool['clips']} synthetic 1 s clips in batches of 8 through oracle/ (numpy float32, dense-DFT frontend + "
+                      f"{cfg.model_type} head) by {pool['workers']} single-threaded worker processes side by side for {pool['seconds']:.1f} s each "
+                      f"(best of 16 and 0.6 x {ncpu} = {workers} workers, the reference's batch-path pool size: transform_clips.py:441); value_1thread: {n1} clips "
                       f"in {dt1:.1f} s in one process on one BLAS thread (the reference interpreter's setting)"}
 
 

@@ -183,6 +183,28 @@ def test_c4_streaming_full_size(HipModel, golden_frontend):
     sb.close(); m.close()
 
 
+def test_bcresnet_bf16_batch_invariance_at_baseline_size(HipModel, golden_frontend):
+    """BASELINE config 3 as written (bf16 activations) at its per-GPU batch of 8192: a clip's logit does not depend on the batch it
+    travels in or on its slot (bit-exact), and stays within the mode's tolerance of the float32 path on broadband clips."""
+    g = golden_frontend
+    cfg = HeadConfig("bcresnet", (101, 64))
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"], act_dtype="bf16")
+    B = 8192
+    x = synth_pcm("noise", B, 16000, seed=7)
+    lg, _ = m.forward_pcm(x)
+    assert np.isfinite(lg).all()
+    l16, _ = m.forward_pcm(x[:16])
+    assert np.array_equal(lg[:16], l16)
+    perm = np.random.default_rng(0).permutation(B)
+    lp, _ = m.forward_pcm(np.ascontiguousarray(x[perm]))
+    assert np.array_equal(lp, lg[perm])
+    m32 = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    l32, _ = m32.forward_pcm(x[:64])
+    assert np.abs(lg[:64] - l32).max() <= 2e-2, float(np.abs(lg[:64] - l32).max())
+    m.close(); m32.close()
+
+
 @pytest.mark.parametrize("head,B", [("bcresnet", 8192), ("conformer", 2048)])
 def test_batch_invariance_at_baseline_sizes(HipModel, golden_frontend, head, B):
     """BASELINE configs 3 (BcResNet, 65 536 / 8 GPUs) and 5 (Conformer, 16 384 / 8 GPUs) at their per-GPU batch:

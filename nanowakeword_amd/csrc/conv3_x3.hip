@@ -35,6 +35,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 constexpr int PS3 = 208;                 // bytes per A3 pixel
 constexpr int WT_BYTES = 9 * 2 * 3 * 1024;
+// A3 row pitch.  A 16-lane group of a fragment read covers 2 rows x 8 pixels; with 208-byte pixels the 8 pixels of a row take the
+// 16-byte slots {0, 13, 10, 7, 4, 1, 14, 11} of the 256-byte bank row, so the second row must sit 8 slots (128 bytes mod 256) away to
+// take the other eight.  (W + 2) * 208 is 160 mod 256 for the 16-wide planes of the E2E / CRNN heads: both rows on the same slots,
+// 36-44 % of the kernel's LDS cycles were conflict cycles (profiles/r03_pmc_all_configs.csv).  The pitch is padded - or, by up to
+// 32 bytes, SHORTENED: the tail of the right halo pixel then overlaps the head of the next row's left halo pixel, both zero for ever.
+// Planes that would no longer fit the CU's LDS with the padding keep the dense pitch.
+static int conv3_row_pitch(int H, int W, int avg_ow) {
+    const int dense = (W + 2) * PS3;
+    static const int padded = [] { const char* e = getenv("NWW_CONV3_PITCH"); return e ? atoi(e) : 1; }();      // 0: dense rows (round 3), for A/B runs
+    if (!padded) return dense;
+    int pad = (128 - dense % 256 + 256) % 256;               // multiple of 16
+    if (pad > 128 && pad - 256 >= -32) pad -= 256;
+    const int npix = (H + 3) * (W + 1);
+    const long extra = (avg_ow <= 0 || npix >= 512) ? 0 : (long)(512 - npix) * 16;
+    if ((long)(H + 3) * (dense + pad) + 48 + WT_BYTES + extra > 160 * 1024) return dense;
+    return dense + pad;
+}
 
 __device__ __forceinline__ void split3c(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     hi = __float_as_uint(x) & 0xffff0000u;
@@ -49,8 +66,8 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     const int H = a.H, W = a.W, Wp = W + 2;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
-    const int rowB = Wp * PS3;
-    const int a3_bytes = (H + 3) * rowB;
+    const int rowB = a.row_pitch;
+    const int a3_bytes = (H + 3) * rowB + 32;                   // (+ 32: the last row's right halo pixel when the pitch is shortened)
     unsigned char* A3 = lds3;
     unsigned char* Wt = lds3 + ((a3_bytes + 15) & ~15);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,7 +103,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     const int t_base = nT / NW, t_rem = nT - t_base * NW;
     const int t_begin = wave * t_base + min(wave, t_rem), t_end = t_begin + t_base + (wave < t_rem ? 1 : 0);
     const int dyi = (i >> 1) & 1, xi = 2 * (i >> 2) + (i & 1);
-    const int lane_off = (dyi * Wp + xi) * PS3 + 16 * hi;      // the lane's pixel inside a tile, its 8 channels of a k-block
+    const int lane_off = dyi * rowB + xi * PS3 + 16 * hi;      // the lane's pixel inside a tile, its 8 channels of a k-block
     const unsigned char* wlane = Wt + lane * 16;
 
     // Fused export-form AvgPool (full-height windows along x, _export/onnx.py:146-152).  A lane's registers 4k+q hold column 16X + 4k + 2hi + (q & 1) of rows 2R + (q >> 1),
@@ -196,7 +213,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     const int HW = H * W;
     const bool stager = tid < HW;
     const int py = stager ? tid / W : 0, px = stager ? tid - py * W : 0;
-    unsigned char* my_px = A3 + ((py + 1) * Wp + px + 1) * PS3;
+    unsigned char* my_px = A3 + (py + 1) * rowB + (px + 1) * PS3;
     float pre[C1];
     // dense planes [B][32][H][W], or (streaming hop) per-clip rings of rows written by the fused trunk: row py of the window at
     // ring row (in_row0 + py) % in_ring_rows
@@ -213,8 +230,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     // per-lane avg-pool partials live in the 16 pad bytes of pixels 0..511 (never read by the MFMAs, never written by
     // the staging) or, for small planes, in their own region behind the weights
     // thread t's partial sums: the pad of pixel t while there are pixels, behind the weights after that
-    const int npix = (H + 3) * Wp;
-    auto part_ptr = [&](int t) { return reinterpret_cast<float*>(t < npix ? A3 + (size_t)t * PS3 + 192 : Wt + WT_BYTES + (size_t)(t - npix) * 16); };
+    // (the right halo column is left out: with a shortened pitch its pad overlaps the next row's left halo pixel)
+    const int npix = (H + 3) * (Wp - 1);
+    auto part_ptr = [&](int t) {
+        return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + 192 : Wt + WT_BYTES + (size_t)(t - npix) * 16);
+    };
     float* my_part = part_ptr(tid);
     prefetch(b_first);
     __syncthreads();
@@ -273,11 +293,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 }
 }  // namespace
 
-static size_t conv3_x3_a3_bytes(int H, int W) { return ((size_t)(H + 3) * (W + 2) * PS3 + 15) & ~(size_t)15; }
+static size_t conv3_x3_a3_bytes(int H, int W, int avg_ow) { return ((size_t)(H + 3) * conv3_row_pitch(H, W, avg_ow) + 32 + 15) & ~(size_t)15; }
 
 size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) {
-    const int npix = (H + 3) * (W + 2);                        // the avg-pool partials live in the pixels' pads; the rest behind the weights
-    return conv3_x3_a3_bytes(H, W) + WT_BYTES + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
+    const int npix = (H + 3) * (W + 1);                        // the avg-pool partials live in the pixels' pads; the rest behind the weights
+    return conv3_x3_a3_bytes(H, W, avg_ow) + WT_BYTES + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
 }
 
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
@@ -289,6 +309,8 @@ bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     if (!conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
     const size_t lds = conv3_x3_lds_bytes(a.H, a.W, a.avg_ow);
+    ConvMfmaArgs aa = a;
+    aa.row_pitch = conv3_row_pitch(a.H, a.W, a.avg_ow);
     const int ngroups = a.Cout / 32;
     long want = (long)a.B * ngroups;
     int grid = (int)(want < max_grid ? want : max_grid);
@@ -298,7 +320,7 @@ hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     {                                                                                                              \
         hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, POOLV, AVGV>), lds);      \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, AVGV>), dim3(grid), dim3(512), lds, s, a);                \
+        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, AVGV>), dim3(grid), dim3(512), lds, s, aa);                \
     }
 #define C3_ACT(ACTV)                                                                                               \
     if (a.avg_ow > 0) C3_LAUNCH(ACTV, false, true) else if (a.pool) C3_LAUNCH(ACTV, true, false) else C3_LAUNCH(ACTV, false, false)

@@ -69,6 +69,7 @@ struct ConvMfmaArgs {
     // ... and (pooled + seq_out mode) only the pooled output rows outside [keep_lo, keep_hi] are computed; row j of that range is
     // row j + keep_shift of the previous hop's sequence buffer seq_prev (same layout as out), copied over
     const float* seq_prev = nullptr; int keep_lo = 0, keep_hi = -1, keep_shift = 0;
+    int row_pitch = 0;     // conv3_x3: bytes between the rows of the LDS plane (filled by the launcher)
     // fused AvgPool2d(kernel (H, avg_kw), stride (H, avg_sw)) -> out [B][Cout][avg_ow] when avg_ow > 0 (pool must be 0)
     int avg_kw = 0, avg_sw = 0, avg_ow = 0;
     int avg_y = 0;         // conv3_x3 only: the windows run along y and cover all columns (the same pool on a transposed plane)

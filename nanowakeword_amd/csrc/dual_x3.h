@@ -16,7 +16,12 @@ struct DualArgs {
     // bf16 activations (nww_config.act_dtype): d, xs / x and out are bf16 arrays; an activation is then ONE bf16 term, so a
     // float32 weight needs three products (hi, mid, lo) instead of six
     int bf16 = 0;
+    // mean_out != nullptr (the last block): out is NOT written; the block's output is averaged over the mean_P = Ho * Wo pixels of
+    // every clip instead -> mean_out [M / mean_P][N] float32 (BcResNetModel's global average pool, architectures.py:677-678).  The
+    // pixel tiling is then clip-aligned (a wave = 32 pixels of ONE clip), so a clip's sums do not depend on its slot in the batch.
+    float* mean_out = nullptr; int mean_P = 0;
 };
+bool dual_x3_mean_supported(int pixels_per_clip);
 
 // one packed 32-output block: 2 x K/16 x 3 fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps
 __host__ __device__ inline size_t dual_x3_block_bytes(int K) { return ((size_t)2 * (K / 16) * 3072 + 512 + 4095) & ~(size_t)4095; }

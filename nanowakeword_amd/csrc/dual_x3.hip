@@ -114,17 +114,35 @@ __device__ __forceinline__ uint32_t pk_bf16d(float a, float b) {      // round t
 // BF: bf16 activations in and out (DualArgs::bf16).  NWV waves per workgroup (32 pixels each) share every weight block: a
 // workgroup streams ALL packed weights (K = 128: 8 x 52 KB) through LDS once per 32 NWV pixels, which at four waves was the
 // kernel's bound for the wide blocks (1.4 GB of L2 -> LDS traffic for block 3 at 8192 clips) - eight waves halve it.
-template <int K16, int ACT, bool BF, int NWV>
+// MEAN: the global average pool fused behind the last block (DualArgs::mean_out): waves are (clip, 32-pixel group) pairs, the
+// activated outputs of a wave go through a [32 pixels][32 channels] LDS tile (rows 144 bytes apart: conflict-free 16-byte stores) to
+// be summed per channel in pixel order, the groups of a clip are added in group order by the clip's first wave.
+template <int K16, int ACT, bool BF, int NWV, bool MEAN = false>
 __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
     constexpr int FRAG_BYTES = 2 * K16 * 3072, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
     __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
+    constexpr int MT_LD = 36;                                            // floats per pixel row of the mean tile
+    __shared__ __attribute__((aligned(16))) float mtile[MEAN ? NWV * 32 * MT_LD : 4];
+    __shared__ float mpart[MEAN ? 2 * NWV * 32 : 4];                     // per block parity: the waves' channel sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int row = (int)blockIdx.x * (32 * NWV) + wave * 32 + n;
-    const bool row_ok = row < a.M;
+    int row;
+    bool row_ok;
+    int gpc = 1, clip = 0, grp = 0;                                      // MEAN: groups per clip, this wave's clip and group
+    if constexpr (MEAN) {
+        gpc = (a.mean_P + 31) / 32;
+        const int wg = (int)blockIdx.x * NWV + wave;
+        clip = wg / gpc; grp = wg - clip * gpc;
+        const int pix = 32 * grp + n;
+        row = clip * a.mean_P + pix;
+        row_ok = pix < a.mean_P && row < a.M;
+    } else {
+        row = (int)blockIdx.x * (32 * NWV) + wave * 32 + n;
+        row_ok = row < a.M;
+    }
     const size_t rr = (size_t)(row_ok ? row : a.M - 1);
 
     auto fetch = [&](int blk, unsigned char* buf) {
@@ -213,12 +231,12 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
         // stores (vmcnt counts them too - waiting after them made every block sit out the write latency of its own outputs)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
-        if (!row_ok) return;
+        if (!MEAN && !row_ok) return;
         const float* aff = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = 32 * blk + 8 * g + 4 * h;
-            if (col < a.N) {                                   // N % 4 == 0: the four channels are in or out together
+            if (MEAN || col < a.N) {                           // N % 4 == 0: the four channels are in or out together
                 const float4 a1 = *reinterpret_cast<const float4*>(aff + 8 * g), b1 = *reinterpret_cast<const float4*>(aff + 32 + 8 * g);
                 const float4 as = *reinterpret_cast<const float4*>(aff + 64 + 8 * g), bs = *reinterpret_cast<const float4*>(aff + 96 + 8 * g);
                 float4 o;
@@ -226,22 +244,51 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
                 o.y = (acc[1][4 * g + 1] * as.y + bs.y) + dual_act<ACT>(acc[0][4 * g + 1] * a1.y + b1.y);
                 o.z = (acc[1][4 * g + 2] * as.z + bs.z) + dual_act<ACT>(acc[0][4 * g + 2] * a1.z + b1.z);
                 o.w = (acc[1][4 * g + 3] * as.w + bs.w) + dual_act<ACT>(acc[0][4 * g + 3] * a1.w + b1.w);
-                if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) = make_uint2(pk_bf16d(o.x, o.y), pk_bf16d(o.z, o.w));
+                if constexpr (MEAN) {
+                    if (!row_ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(mtile + (wave * 32 + n) * MT_LD + 8 * g + 4 * h) = o;
+                } else if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) = make_uint2(pk_bf16d(o.x, o.y), pk_bf16d(o.z, o.w));
                 else *reinterpret_cast<float4*>(orow + col) = o;
             }
+        }
+        if constexpr (MEAN) {
+            // the wave's own tile (LDS operations of a wave execute in order): lane (channel n, half h) adds pixels 16 h .. 16 h + 15
+            // in pixel order, then the two halves - the same order for every clip and slot
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float* tp = mtile + (wave * 32 + 16 * h) * MT_LD + n;
+            float sum = tp[0];
+#pragma unroll
+            for (int px = 1; px < 16; ++px) sum += tp[px * MT_LD];
+            const float other = __shfl_xor(sum, 32, 64);
+            if (h == 0) mpart[((blk & 1) * NWV + wave) * 32 + n] = sum + other;
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int nblk = a.nblk;
+    // MEAN: behind the barrier that ends block blk, the first wave of every clip adds the groups' sums (group order) and stores the
+    // clip's 32 channel means; mpart alternates with the block parity, so the next block's sums do not disturb the reads
+    auto finish_mean = [&](int blk) {
+        if constexpr (MEAN) {
+            if (grp == 0 && h == 0 && (size_t)clip * a.mean_P < (size_t)a.M && 32 * blk + n < a.N) {
+                float sum = mpart[((blk & 1) * NWV + wave) * 32 + n];
+                for (int j = 1; j < gpc; ++j) sum += mpart[((blk & 1) * NWV + wave + j) * 32 + n];
+                a.mean_out[(size_t)clip * a.N + 32 * blk + n] = sum * (1.0f / (float)a.mean_P);
+            }
+        }
+    };
     for (int blk = 0; blk < nblk; blk += 2) {
         if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
         block(blk, wb0);
         __syncthreads();
+        finish_mean(blk);
         if (blk + 1 < nblk) {
             if (blk + 2 < nblk) fetch(blk + 2, wb0);
             block(blk + 1, wb1);
             __syncthreads();
+            finish_mean(blk + 1);
         }
     }
 }
@@ -249,6 +296,8 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
 }  // namespace
 
 bool dual_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 128) && N % 4 == 0 && N >= 4; }
+// the fused mean needs every clip's 32-pixel groups inside one four-wave workgroup
+bool dual_x3_mean_supported(int pixels_per_clip) { return pixels_per_clip >= 1 && pixels_per_clip <= 128 && 4 % ((pixels_per_clip + 31) / 32) == 0; }
 
 size_t dual_x3_packed_bytes(int K, int N) { return (size_t)((N + 31) / 32) * dual_x3_block_bytes(K); }
 
@@ -268,6 +317,25 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     if (a0.x && (a0.Ho <= 0 || a0.Wo <= 0 || a0.M % (a0.Ho * a0.Wo) != 0)) return hipErrorInvalidValue;
     DualArgs a = a0;
     a.nblk = (a.N + 31) / 32;
+    if (a.mean_out) {
+        if (!dual_x3_mean_supported(a.mean_P) || a.M % a.mean_P != 0 || K != 128) return hipErrorInvalidValue;      // (the last block: K = 128)
+        const int gpc = (a.mean_P + 31) / 32, clips = a.M / a.mean_P;
+        // bf16 activations: eight waves per workgroup as in the unfused launch (half the weight traffic through LDS; 8 % gpc == 0 too)
+        const bool w8m = a.bf16 && a.M >= 256 * 256;
+        const dim3 gridm((unsigned)(((size_t)clips * gpc + (w8m ? 7 : 3)) / (w8m ? 8 : 4)));
+#define DUAL_MEAN(ACTV)                                                                                            \
+        if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, true, 8, true>), gridm, dim3(512), 0, s, a);          \
+        else if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, true, 4, true>), gridm, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, false, 4, true>), gridm, dim3(256), 0, s, a);
+        switch (act) {
+            case ACT_RELU: DUAL_MEAN(ACT_RELU) break;
+            case ACT_GELU: DUAL_MEAN(ACT_GELU) break;
+            case ACT_SILU: DUAL_MEAN(ACT_SILU) break;
+            default: return hipErrorInvalidValue;
+        }
+#undef DUAL_MEAN
+        return hipGetLastError();
+    }
     // eight waves per workgroup where it measured faster at 8192 clips: bf16 activations at K = 32 (0.255 -> 0.211 ms) and
     // K = 128 (0.293 -> 0.229); K = 64 (0.161 -> 0.172) and every float32 shape (0.363 -> 0.395, 0.235 -> 0.248; K = 128
     // needs 284 registers) stay at four

@@ -749,6 +749,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 add_conv(p, "init_conv(nhwc)", -1, 0, 1, 32, T, F, p.W("model.init_conv.0.weight"), nullptr, p.W("model.init_conv.1.alpha"), p.W("model.init_conv.1.beta"), act, 1, 1);
             }
             int hh = T / 2, ww = F / 2, cur = 0;
+            bool mean_fused = false;
             const int ch[4] = {32, 64, 128, 256};
             const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};
             for (int i = 1; i <= 3; ++i) {
@@ -781,10 +782,15 @@ extern "C" int nww_finalize(nww_handle* h) {
                                 p.pop_last();
                                 p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act_bf16); });
                             }
-                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
+                            // the last block feeds only the global average pool: averaged in the same launch, its output never reaches HBM
+                            static const int mean_fused_on = [] { const char* e = getenv("NWW_BC_MEAN_FUSED"); return e ? atoi(e) : 1; }();
+                            const bool fuse_mean = mean_fused_on && i == 3 && ci == 128 && dual_x3_mean_supported(rows);
+                            if (fuse_mean) { mean_fused = true; p.need(5, 256); }
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
                                 if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
                                 a.bf16 = act_bf16 ? 1 : 0;
+                                if (fuse_mean) { a.mean_out = r.buf[5]; a.mean_P = rows; }
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });
                             hh = ho; ww = wo; cur = outb;
@@ -806,6 +812,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                 hh = ho; ww = wo; cur = outb;
             }
             const int hw = hh * ww;
+            if (mean_fused) {
+                set_tail(p, "fc", 5, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));
+                break;
+            }
             p.need(2, 256);
             p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream, act_bf16); });
             set_tail(p, "fc", 2, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));

@@ -30,7 +30,8 @@ if os.path.exists(os.path.join(src, "stats_configs", "configs_kernel_stats.csv")
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{rnd}_bench.json"))
 if os.path.exists(os.path.join(src, "configs.jsonl")):
     shutil.copy(os.path.join(src, "configs.jsonl"), os.path.join(out, f"{rnd}_all_configs.jsonl"))
-for extra in ("tolerance_audit.json", "latency_b1.txt", "pytest_gpu.txt"):
+for extra in ("tolerance_audit.json", "latency_b1.txt", "latency_breakdown.txt", "pytest_gpu.txt", "c4_breakdown.json", "c4_breakdown_full_window.json",
+              "traffic_configs.json", "pmc_all_configs.csv"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(out, f"{rnd}_{extra}"))
 fetch = medians(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"))
@@ -66,5 +67,10 @@ for prefix, label in plan.items():
             print(f"{label}: FETCHx2 {2*fk/1024:.1f} MB WRITE {wk/1024:.1f} MB | INSTS_VALU {big_median(s.get('SQ_INSTS_VALU', [])):.3g} "
                   f"INSTS_MFMA {big_median(s.get('SQ_INSTS_MFMA', [])):.3g} MFMA_BUSY {big_median(s.get('SQ_VALU_MFMA_BUSY_CYCLES', [])):.3g} "
                   f"LDS_ACTIVE {act:.3g} LDS_CONFLICT {big_median(s.get('SQ_LDS_BANK_CONFLICT', [])):.3g} SQ_BUSY {busy:.3g}")
+tc = os.path.join(src, "traffic_configs.json")
+if os.path.exists(tc):      # every kernel of the non-headline configs (tools/traffic_configs.sh), at the batch of its config
+    traffic["configs_per_kernel"] = {"_note": "C3 (B = 8192, fp32 and bf16 activations), C5 (B = 2048), C4 (1024 streams), e2e / gru (B = 4096): "
+                                              "FETCH_SIZE x 2 + WRITE_SIZE per launch, rocprofv3 --pmc, one counter per pass",
+                                     **json.load(open(tc))}
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(out)))

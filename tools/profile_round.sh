@@ -22,4 +22,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B 
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B > $OUT/pmc_sq.log 2>&1
 # every BASELINE config (tools/bench_configs.py) under the kernel trace: rocprofv3's own per-kernel averages beside the tool's events
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -o configs -- python $GRAFT_REPO_ROOT/tools/bench_configs.py > $OUT/stats_configs.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/c4_breakdown.py 1024 > $OUT/c4_breakdown.json 2>/dev/null
+NWW_STREAM_INC=0 python tools/c4_breakdown.py 1024 > $OUT/c4_breakdown_full_window.json 2>/dev/null
+# HBM bytes and SQ counters per kernel of the non-headline configs (separate --pmc passes)
+bash tools/traffic_configs.sh $R C3 C5 C4 e2e gru > $OUT/traffic_configs.txt 2>&1
+cp gpurun_out/${R}_traffic_configs.json $OUT/traffic_configs.json
+bash tools/pmc_configs.sh $R > $OUT/pmc_configs.txt 2>&1
+cp gpurun_out/${R}_pmc_configs.csv $OUT/pmc_all_configs.csv
 find $OUT -name "*.csv" | head -30

@@ -366,8 +366,9 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
     p.need(xg_id, (size_t)(T + 1) * G * H);                  // + one row per clip: the reverse direction's last-frame projection
     p.need(last_id, (size_t)2 * H);
     const int products = p.h->conv_products;                 // the recurrent product follows the handle's arithmetic switch
-    GruArgs probe; probe.H = H; probe.products = products; probe.w_hh = nullptr;
-    const bool x3 = rnn_x3_enabled(probe);                    // (weights come from hipMalloc: 16-byte aligned)
+    GruArgs probe; probe.H = H; probe.products = products;
+    probe.w_hh = p.W(prefix + ".weight_hh_l" + std::to_string(layers - 1));       // the pointer the fused launch will really get (alignment test)
+    const bool x3 = probe.w_hh != nullptr && rnn_x3_enabled(probe);
     int cur_in = in_id, cur_I = I;
     for (int l = 0; l < layers; ++l) {
         const bool last = l == layers - 1;
@@ -584,16 +585,20 @@ extern "C" int nww_finalize(nww_handle* h) {
         case NWW_HEAD_E2E_DNN: {                  // E2E_MelSpectrogram_CNN body: architectures.py:840-865,877-889
             const int Hh = T, Ww = F;             // (n_mels, frames)
             const int ch[3] = {16, 32, 64};
-            if (e2e_transposed_ok(p, Hh, Ww)) {
+            // the transposed plan; whatever goes wrong while it is built (a shape one of its kernels does not take after all, an
+            // allocation) drops what was planned and falls through to the reference's orientation below
+            const auto try_transposed = [&]() -> bool {
+                if (!e2e_transposed_ok(p, Hh, Ww)) return false;
+                const size_t steps_before = h->plan.size();
                 const int Ht = Ww, Wt = Hh;       // the plane the kernels see: (frames, n_mels)
                 float* wt = nullptr;
                 const int nf[3] = {16, 32 * 16, 64 * 32};
-                if (hipMalloc(&wt, (size_t)(nf[0] + nf[1] + nf[2]) * 9 * sizeof(float)) != hipSuccess) return fail(h, NWW_ERR_HIP, "hipMalloc failed");
+                if (hipMalloc(&wt, (size_t)(nf[0] + nf[1] + nf[2]) * 9 * sizeof(float)) != hipSuccess) return false;
                 p.h->packed_weights.push_back(wt);
                 float* wts[3] = {wt, wt + (size_t)nf[0] * 9, wt + (size_t)(nf[0] + nf[1]) * 9};
                 for (int i = 0; i < 3; ++i)
                     if (launch_transpose3x3(p.W("model.conv_block." + std::to_string(4 * i) + ".weight"), wts[i], nf[i], p.h->own_stream) != hipSuccess)
-                        return fail(h, NWW_ERR_HIP, "weight transpose failed");
+                        return false;
                 h->e2e_transposed = true;
                 p.need(2, (size_t)Hh * Ww);
                 p.add("transpose:mel-major features -> frames-major (skipped after the frontend)", [=](Run& r) {
@@ -602,19 +607,24 @@ extern "C" int nww_finalize(nww_handle* h) {
                     r.x = r.buf[2];
                     return e;
                 });
-                if (!add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
-                               p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
-                               p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act))
-                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed trunk does not fit");
                 const int h3 = Ht / 4, w3 = Wt / 4;           // (25, 16): AdaptiveAvgPool2d((1,4))'s windows run along the FRAMES, here y
                 const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
-                if (h3 < 4 || !add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
-                                   p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1))
-                    return fail(h, NWW_ERR_UNSUPPORTED, "e2e_dnn: the transposed third conv does not fit");
+                const bool ok = add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
+                                          p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
+                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act) &&
+                                h->plan.back().name.rfind("trunk_x3:", 0) == 0 && h3 >= 4 &&
+                                add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
+                                              p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1);
+                if (!ok) {
+                    h->plan.resize(steps_before);
+                    h->e2e_transposed = false;
+                    return false;
+                }
                 add_gemm(p, "fc1+bn1", 0, 1, 1, 128, 256, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, p.W("model.bn1.alpha"), p.W("model.bn1.beta"));
                 set_tail(p, "out", 1, 128, p.W("model.out.weight"), p.W("model.out.bias"));
-                break;
-            }
+                return true;
+            };
+            if (try_transposed()) break;
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
             int first = 0;
             bool fused_pool = false;

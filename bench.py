@@ -48,7 +48,7 @@ def parse():
                          "to reach its sustained clocks (20 cold steps run 10 %% slower than the same steps a second later)")
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
     ap.add_argument("--head", default="cnn")
-    ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6"],
+    ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6", "f16x3"],
                     help="arithmetic of the fused conv trunk's conv2 (all float32-grade; nww_config.conv_arith)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP events around the launches of every n-th timed step (an event per launch boundary costs the "
@@ -462,7 +462,7 @@ def main():
         ms_step = dt / a.steps * 1e3
         value = B * world * a.steps / dt
         # ---- roofline of the dominant kernel (largest share of device time in the timed region)
-        per = [(n, ms / max(c, 1), c, ms) for (n, ms, c) in prof if c > 0]
+        per = [(n.split(" [")[0], ms / max(c, 1), c, ms) for (n, ms, c) in prof if c > 0]      # " [f16x3]" marks a step's arithmetic
         dom = max(per, key=lambda r: r[3])
         kernel_ms = {n: round(avg, 4) for (n, avg, c, tot) in per}
         T, n_mels = 101, fe.n_mels
@@ -478,7 +478,7 @@ def main():
             algo["trunk:conv1+pool+conv2+pool"] = ("mfma", algo["conv3x3:conv1"][1] + algo["conv3x3:conv2"][1], "TFLOP/s", PEAK_F32_TFLOPS)
             # trunk_x3: BOTH convolutions run as P bf16 partial products per float32 product on v_mfma_f32_32x32x16_bf16
             # (trunk_b.hip), so the matrix-pipe speed of light for the algorithmic (float32-equivalent) flops is bf16_peak / P.
-            P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
+            P = {"bf16x6": 6, "bf16x9": 9, "f16x3": 3}.get(arith, 6)
             f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
             algo["trunk_x3:conv1+pool+conv2+pool"] = ("mfma", f1 + f2, "TFLOP/s", round(PEAK_BF16_TFLOPS / P, 1))
         name = dom[0]
@@ -504,10 +504,10 @@ def main():
                                       "(tools/collect_profiles.py), not measured in this run" if traffic is not None else None,
                     "avg_launch_ms": round(dom[1], 4), "launches": dom[2]}
         if name.startswith("trunk_x3"):
-            P = {"bf16x6": 6, "bf16x9": 9}.get(arith, 6)
+            P = {"bf16x6": 6, "bf16x9": 9, "f16x3": 3}.get(arith, 6)
             f1, f2 = algo["conv3x3:conv1"][1], algo["conv3x3:conv2"][1]
-            roofline["peak_definition"] = (f"dense bf16 MFMA peak ({PEAK_BF16_TFLOPS:.0f} TFLOP/s) / {P} partial products per float32 product: "
-                                           "both convolutions are issued as split-operand bf16 MFMAs")
+            roofline["peak_definition"] = (f"dense bf16 / f16 MFMA peak ({PEAK_BF16_TFLOPS:.0f} TFLOP/s) / {P} partial products per float32 product: "
+                                           "both convolutions are issued as split-operand 16-bit MFMAs")
             # rounds 2-3 priced conv1 at the f32-MFMA rate (it ran there in round 2); kept only so that rounds compare
             peak_r2 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
             roofline["frac_round2_definition"] = round(achieved / peak_r2, 4)
@@ -546,7 +546,8 @@ def main():
                        "clips_per_gpu": B, "n_samples": N,
                        "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
-                                      "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)"}[arith],
+                                      "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)",
+                                      "f16x3": "float32 operands, scaled by plan-time powers of two, split into 2 binary16 terms (22-23 of 24 significant bits), the 3 partial products >= 2^-22 of a product on v_mfma_f32_32x32x16_f16, f32 accumulate (float32-MFMA accuracy against float64: DESIGN.md 4.2c)"}[arith],
                        "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via})" if world > 1 else "")},
             "gather_via": gather_via,          # "capi" = RCCL all-gather inside the C-ABI on the kernels' stream; "none" at N = 1
             "roofline": roofline,

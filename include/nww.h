@@ -81,6 +81,12 @@ typedef struct nww_config {
          NWW_ARITH_BF16X9 each float32 operand split into three bf16 terms (exact), all nine partial products on
                           v_mfma_f32_32x32x16_bf16 - exact products, float32 accumulation
          NWW_ARITH_BF16X6 the six largest partial products; the dropped ones are < 2^-23 of a product
+         NWW_ARITH_F16X3  each operand, scaled by a power of two fixed at nww_finalize from bounds on the tensors (features
+                          are assumed inside +-NWW_F16_FEATURE_BOUND: log-mel dB values lie in [-100, 60]), split into TWO
+                          binary16 terms holding 22-23 of its 24 significant bits; the three partial products >= 2^-22 of a
+                          product on v_mfma_f32_32x32x16_f16, float32 accumulation - half the matrix instructions of
+                          BF16X6 at the float32 MFMA's accuracy against float64.  Layers without an f16x3 instance, or
+                          without a bound on their input, run as NWW_ARITH_BF16X6
          NWW_ARITH_DEFAULT lets the library choose (NWW_ARITH_BF16X6)                                            */
     int32_t conv_arith;
     /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
@@ -96,6 +102,8 @@ typedef struct nww_config {
 #define NWW_ACT_DTYPE_BF16 1
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1
+#define NWW_ARITH_F16X3 3
+#define NWW_F16_FEATURE_BOUND 512.0f
 #define NWW_ARITH_BF16X6 6
 #define NWW_ARITH_BF16X9 9
 

@@ -112,7 +112,7 @@ def load_library():
     return lib
 
 
-ARITH_CODE = {None: 0, "default": 0, "f32": 1, "bf16x6": 6, "bf16x9": 9}
+ARITH_CODE = {None: 0, "default": 0, "f32": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}
 ACT_DTYPE_CODE = {None: 0, "f32": 0, "bf16": 1}          # nww_config.act_dtype: storage of the activations between kernels
 
 

@@ -15,6 +15,10 @@
 // workgroups share a CU; the next k-tile's global loads travel in registers during the multiplication.  A is split
 // while it is staged into LDS (5.5 VALU ops per element, amortised over 32*CB columns); W is split once at
 // nww_finalize into the same [N][K/16][3][16] layout so its tiles are plain 16-byte copies.
+// H2 instances ("f16x3", GemmArgs::h2): the operands, scaled by powers of two fixed at plan time (a_scale on load, the weights
+// at pack time; c_scale undoes both on the way out), are split into TWO binary16 terms hi = RN16(v), lo = RN16(v - hi) holding
+// 22-23 of the 24 significant bits; hi*hi, hi*lo, lo*hi go to v_mfma_f32_32x32x16_f16 - half the matrix instructions, the
+// float32 MFMA's accuracy against float64 (trunk_b.hip has the argument).  LDS rows are [2 terms][32 k] + 16 B pad = 144 B.
 // Round 3, measured and not kept: an 8-wave version with two LDS stages, ONE barrier per k-tile, the split + store of tile
 // k + 1 placed between the MFMAs of tile k and global loads three tiles ahead (0 spills, parity-green, bit-identical
 // results) ran fc1 in 0.098 ms against 0.090 for this kernel.  The step draws 1350 W of the package's 1400 W cap
@@ -32,6 +36,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef X3_TRACE      // tools/ubench/gemm_x3_trace.hip: s_memtime stamps of workgroup 0's first k-tiles (phase boundaries per wave)
 __device__ unsigned long long x3_trace_buf[4 * 16 * 4];
@@ -42,8 +49,9 @@ __device__ unsigned long long x3_trace_buf[4 * 16 * 4];
 #define X3_STAMP(kt_rel, ph)
 #endif
 namespace {
-constexpr int X3_ROW = 208;                      // bytes per LDS row: 3 terms x 32 k x bf16 + 16 pad (conflict-free b128 reads)
 constexpr int X3_BM = 128;
+// bytes per LDS row: NT terms x 32 k x 2 bytes + 16 pad (an odd number of 16-byte slots: conflict-free b128 reads)
+template <bool H2> struct X3A { static constexpr int NT = H2 ? 2 : 3, ROW = 64 * NT + 16; };
 
 // 1 / (1 + e^-v) on the hardware exp2 and reciprocal (1 ulp each; relative error <= 3e-7): 4 instructions where
 // expf + IEEE division take ~35 - the epilogue of a short-K GEMM is as long as its main loop otherwise.
@@ -69,6 +77,34 @@ __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uin
 }
 // (a >> 16) | (b & 0xffff0000): bf16 of a in the low half (element k), of b in the high half (element k+1)
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// (a, b) -> binary16 pairs hi = RN(v), lo = RN(v - hi)
+__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+// the partial products of one 16-k block, small terms first: six of bf16 terms (a, w = hi / mid / lo) or three of binary16 terms
+template <bool H2>
+__device__ __forceinline__ void x3_products(const uint4* a, const uint4* w, f32x16& acc) {
+    if (H2) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, a[0]), al = __builtin_bit_cast(f16x8, a[1]);
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl = __builtin_bit_cast(f16x8, w[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+    } else {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), am = __builtin_bit_cast(bf16x8, a[1]), al = __builtin_bit_cast(bf16x8, a[H2 ? 1 : 2]);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[0]), wm = __builtin_bit_cast(bf16x8, w[1]), wl = __builtin_bit_cast(bf16x8, w[H2 ? 1 : 2]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+    }
+}
 }  // namespace
 
 // W [N][K] float32 -> [N][KB][3][16] bf16, KB = ceil(K/16), zero beyond K
@@ -88,20 +124,38 @@ __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __re
     o[0] = (uint16_t)(hi >> 16); o[16] = (uint16_t)(mid >> 16); o[32] = (uint16_t)(lo >> 16);
 }
 
+// W [N][K] float32 -> [N][KB][2][16] binary16 terms of W * scale, zero beyond K
+__global__ void __launch_bounds__(256) split_weights_h2_kernel(const float* __restrict__ W, uint16_t* __restrict__ out,
+                                                               int N, int K, int KB, float scale) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // one (n, k) element
+    const size_t total = (size_t)N * KB * 16;
+    if (idx >= total) return;
+    const int kk = (int)(idx & 15);
+    const size_t nb = idx >> 4;
+    const int kb = (int)(nb % KB), n = (int)(nb / KB);
+    const int k = kb * 16 + kk;
+    const float x = k < K ? W[(size_t)n * K + k] * scale : 0.0f;
+    uint32_t hi, lo;
+    split2h(x, 0.0f, hi, lo);
+    uint16_t* o = out + nb * 32 + kk;
+    o[0] = (uint16_t)hi; o[16] = (uint16_t)lo;
+}
+
 // NST = register stages of global loads in flight (k-tiles of lookahead).  The bulk shapes use 1 (two workgroups per
 // CU cover each other); the small-M instance <1, 8> (M <= 64: the interpreter's B = 1 .. 16 calls) is pure load
 // latency - 25 dependent k-tiles of ~2.4 us each - and runs 32-column tiles (4x the workgroups) with eight k-tiles in
 // flight (only rows 0..63 of A are staged, so a stage is 16 registers).  Per-output summation order is the same in every instance: same k-tile sequence, same products, same
 // split-K chunks - results stay bit-identical across batch sizes.
-template <int CB, int NST, int ACT>
+template <int CB, int NST, int ACT, bool H2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gemm_x3_kernel(GemmArgs g) {
+    constexpr int NT = X3A<H2>::NT, X3_ROW = X3A<H2>::ROW, PB = 2 * NT;   // terms, LDS row bytes, 16-byte pieces of a row's 16-k block
     // accumulators in AGPRs: two workgroups share a CU, and one's bf16 MFMAs run beside the other's split/stage VALU
     // work only in the AGPR form (tools/ubench/mfma_valu_overlap.hip).  The empty asm flips hipcc's
     // choice; the plain launch bound keeps the register file unsplit, amdgpu_num_vgpr caps the VGPR side so that
     // VGPRs + accumulator AGPRs <= 256 (two waves per SIMD).
     { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }
     constexpr int BN = 32 * CB;
-    constexpr int WPIECES = BN * 12;                           // 16-byte pieces of a W tile (32 k x 3 terms per row)
+    constexpr int WPIECES = BN * 2 * PB;                       // 16-byte pieces of a W tile (32 k x NT terms per row)
     constexpr int WLD = (WPIECES + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto As = [&](int) { return smem; };
@@ -144,31 +198,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
         for (int j = 0; j < WLD; ++j) {
             const int p = tid + 256 * j;
             if (WPIECES % 256 == 0 || p < WPIECES) {
-                const int row = p / 12, c = p - row * 12;
+                const int row = p / (2 * PB), c = p - row * (2 * PB);
                 const int n = min(bn + row, g.N - 1);
-                const int kb = 2 * kt + c / 6;                 // 16-k block of this piece
-                st.w[j] = kb < KB ? Wx[((size_t)n * KB + kb) * 6 + (c % 6)] : make_uint4(0, 0, 0, 0);
+                const int kb = 2 * kt + c / PB;                // 16-k block of this piece
+                st.w[j] = kb < KB ? Wx[((size_t)n * KB + kb) * PB + (c % PB)] : make_uint4(0, 0, 0, 0);
             }
         }
     };
+    const float a_scale = H2 ? g.a_scale : 1.0f;
     auto lstore = [&](int buf, const Stage& st) {
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
-            uint32_t hi[4], mid[4], lo[4];
-            split3(st.a[q].x, hi[0], mid[0], lo[0]); split3(st.a[q].y, hi[1], mid[1], lo[1]);
-            split3(st.a[q].z, hi[2], mid[2], lo[2]); split3(st.a[q].w, hi[3], mid[3], lo[3]);
             unsigned char* d = As(buf) + (lr + 32 * q) * X3_ROW + 8 * lq;
-            *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
-            *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
-            *reinterpret_cast<uint2*>(d + 128) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+            if (H2) {
+                uint32_t h0, l0, h1, l1;
+                split2h(st.a[q].x * a_scale, st.a[q].y * a_scale, h0, l0);
+                split2h(st.a[q].z * a_scale, st.a[q].w * a_scale, h1, l1);
+                *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(d + 64) = make_uint2(l0, l1);
+            } else {
+                uint32_t hi[4], mid[4], lo[4];
+                split3(st.a[q].x, hi[0], mid[0], lo[0]); split3(st.a[q].y, hi[1], mid[1], lo[1]);
+                split3(st.a[q].z, hi[2], mid[2], lo[2]); split3(st.a[q].w, hi[3], mid[3], lo[3]);
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
+                *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+                *reinterpret_cast<uint2*>(d + 128) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+            }
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) {
             const int p = tid + 256 * j;
             if (WPIECES % 256 == 0 || p < WPIECES) {
-                const int row = p / 12, c = p - row * 12;
-                const int c6 = c % 6;                          // (term, half) inside the 16-k block
-                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + (c6 >> 1) * 64 + (c / 6) * 32 + (c6 & 1) * 16) = st.w[j];
+                const int row = p / (2 * PB), c = p - row * (2 * PB);
+                const int cp = c % PB;                         // (term, half) inside the 16-k block
+                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + (cp >> 1) * 64 + (c / PB) * 32 + (cp & 1) * 16) = st.w[j];
             }
         }
     };
@@ -191,20 +254,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const unsigned char* ap = As(0) + a_off + 32 * kk;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + 64),
-                         al = *reinterpret_cast<const bf16x8*>(ap + 128);
+            uint4 af[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *reinterpret_cast<const uint4*>(ap + 64 * t);
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 const unsigned char* wp = Ws(0) + w_off + c * 32 * X3_ROW + 32 * kk;
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wp), wm = *reinterpret_cast<const bf16x8*>(wp + 64),
-                             wl = *reinterpret_cast<const bf16x8*>(wp + 128);
-                // small terms first, the dominant hi*hi last
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[c], 0, 0, 0);
+                uint4 wf[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(wp + 64 * t);
+                x3_products<H2>(af, wf, acc[c]);               // small terms first, the dominant hi*hi last
             }
         }
     };
@@ -227,6 +286,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
 
     const int m0 = bm + wave * 32;
     if (m0 >= g.M) return;
+    if (H2) {                     // back to the true scale (a power of two: every rounding behind this is the unscaled one's)
+        const float c_scale = g.c_scale;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] *= c_scale;
+    }
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
         const int n = bn + c * 32 + i;
@@ -287,7 +353,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
 // through 4 KB of LDS: no staging, one barrier per CH_TPW k-tiles.  Same products, same order, same chunks as every
 // other instance: results are bit-identical.
 constexpr int CH_NW = 8, CH_TPW = 4;
+template <bool H2>
 __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
+    constexpr int NT = X3A<H2>::NT, PB = 2 * NT;
+    const float a_scale = H2 ? g.a_scale : 1.0f, c_scale = H2 ? g.c_scale : 1.0f;
     __shared__ __attribute__((aligned(16))) float4 hand[4 * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 31, h = lane >> 5;
@@ -296,7 +365,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     const int kc = (KT + g.splitk - 1) / g.splitk;
     const int kt_begin = blockIdx.z * kc, kt_end = min(KT, kt_begin + kc);
     const int mrow = min(bm + i, g.M - 1);
-    const uint4* wrow = reinterpret_cast<const uint4*>(g.Wx3) + (size_t)min(bn + i, g.N - 1) * KB * 6 + h;
+    const uint4* wrow = reinterpret_cast<const uint4*>(g.Wx3) + (size_t)min(bn + i, g.N - 1) * KB * PB + h;
     const float* abase = g.a_blocked ? g.A + ((size_t)(mrow >> 7) * g.a_blocked * 128 + (mrow & 127)) * 32 + 8 * h
                                      : g.A + (size_t)mrow * g.lda + 8 * h;
     const size_t a_kstep = g.a_blocked ? 128 * 32 : 32;
@@ -318,7 +387,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     for (int round = kt_begin; round < kt_end; round += CH_NW * CH_TPW) {
         const int t0 = round + wave * CH_TPW;
         const int nt = max(0, min(CH_TPW, kt_end - t0));                      // this wave's k-tiles (wave-uniform)
-        uint4 wf[CH_TPW][2][3];
+        uint4 wf[CH_TPW][2][NT];
         float4 ar[CH_TPW][2][2];
         // straight-line loads: k-tiles beyond the wave's share repeat its last valid one (never multiplied)
 #pragma unroll
@@ -333,7 +402,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
                 if (!in_k) { ar[t][kk][0] = make_float4(0.f, 0.f, 0.f, 0.f); ar[t][kk][1] = ar[t][kk][0]; }
                 const int kb = min(2 * kt + kk, KB - 1);                      // a k-block beyond KB meets zeros of A
 #pragma unroll
-                for (int term = 0; term < 3; ++term) wf[t][kk][term] = wrow[(size_t)kb * 6 + 2 * term];
+                for (int term = 0; term < NT; ++term) wf[t][kk][term] = wrow[(size_t)kb * PB + 2 * term];
             }
         }
         const int active = min(CH_NW, (kt_end - round + CH_TPW - 1) / CH_TPW);    // waves that hold k-tiles of this round
@@ -356,20 +425,22 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
                         // fragments beside all of W's would not fit the register file)
                         const float x[8] = {ar[t][kk][0].x, ar[t][kk][0].y, ar[t][kk][0].z, ar[t][kk][0].w,
                                             ar[t][kk][1].x, ar[t][kk][1].y, ar[t][kk][1].z, ar[t][kk][1].w};
-                        uint32_t hi[8], mid[8], lo[8];
+                        uint4 af[NT];
+                        if (H2) {
+                            uint32_t hh[4], ll[4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) split3(x[j], hi[j], mid[j], lo[j]);
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7])));
-                        const bf16x8 am = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7])));
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7])));
-                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[t][kk][0]), wm = __builtin_bit_cast(bf16x8, wf[t][kk][1]),
-                                     wl = __builtin_bit_cast(bf16x8, wf[t][kk][2]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wm, acc, 0, 0, 0);      // gemm_x3_kernel's order
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wm, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+                            for (int j = 0; j < 4; ++j) split2h(x[2 * j] * a_scale, x[2 * j + 1] * a_scale, hh[j], ll[j]);
+                            af[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                            af[1] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                        } else {
+                            uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) split3(x[j], hi[j], mid[j], lo[j]);
+                            af[0] = make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7]));
+                            af[1] = make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7]));
+                            af[NT - 1] = make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7]));
+                        }
+                        x3_products<H2>(af, wf[t][kk], acc);                          // gemm_x3_kernel's order
                     }
                 }
                 if (last_round && s == active - 1) {                          // the chunk's partial sums
@@ -379,7 +450,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int m = bm + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if (m < g.M) part[(size_t)m * g.N + n] = acc[r];
+                            if (m < g.M) part[(size_t)m * g.N + n] = H2 ? acc[r] * c_scale : acc[r];
                         }
                     }
                 } else {
@@ -392,7 +463,15 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     }
 }
 
-size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * ((K + 15) / 16) * 96; }
+size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * ((K + 15) / 16) * 96; }      // (the two-term image needs 64 of the 96)
+
+hipError_t launch_split_weights_h2(const float* W, void* out, int N, int K, float scale, hipStream_t s) {
+    const int KB = (K + 15) / 16;
+    const size_t total = (size_t)N * KB * 16;
+    hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W,
+                       reinterpret_cast<uint16_t*>(out), N, K, KB, scale);
+    return hipGetLastError();
+}
 
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s) {
     const int KB = (K + 15) / 16;
@@ -423,12 +502,16 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     const int sk = (g.splitk > 1 && g.splitk_ws) ? g.splitk : 1;
     GemmArgs a = g;
     a.splitk = sk;
-#define X3_GO(CBV, NSTV, ACTV, GRID, LDSB)                                                                         \
+    const bool h2 = a.h2 != 0;
+    const size_t row_b = h2 ? X3A<true>::ROW : X3A<false>::ROW;
+#define X3_GO1(CBV, NSTV, ACTV, H2V, GRID, LDSB)                                                                   \
     {                                                                                                              \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV, NSTV, ACTV>), LDSB);        \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(gemm_x3_kernel<CBV, NSTV, ACTV, H2V>), LDSB);   \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((gemm_x3_kernel<CBV, NSTV, ACTV>), GRID, dim3(256), LDSB, s, a);                        \
+        hipLaunchKernelGGL((gemm_x3_kernel<CBV, NSTV, ACTV, H2V>), GRID, dim3(256), LDSB, s, a);                   \
     }
+#define X3_GO(CBV, NSTV, ACTV, GRID, LDSB)                                                                         \
+    if (h2) X3_GO1(CBV, NSTV, ACTV, true, GRID, LDSB) else X3_GO1(CBV, NSTV, ACTV, false, GRID, LDSB)
 #define X3_ACT(CBV, NSTV, GRID, LDSB)                                                                              \
     switch (sk > 1 ? (int)ACT_NONE : a.act) {      /* split-K partials take no epilogue: one instance serves them all */ \
         case ACT_RELU: X3_GO(CBV, NSTV, ACT_RELU, GRID, LDSB) break;                                               \
@@ -438,12 +521,13 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
         default: X3_GO(CBV, NSTV, ACT_NONE, GRID, LDSB) break;                                                     \
     }
     if (g.M <= 64 && sk > 1 && g.K % 8 == 0) {                                 // one memory round trip + one MFMA chain per chunk
-        hipLaunchKernelGGL(gemm_x3_chain_kernel, dim3((g.M + 31) / 32, (g.N + 31) / 32, sk), dim3(64 * CH_NW), 0, s, a);
+        if (h2) hipLaunchKernelGGL(gemm_x3_chain_kernel<true>, dim3((g.M + 31) / 32, (g.N + 31) / 32, sk), dim3(64 * CH_NW), 0, s, a);
+        else hipLaunchKernelGGL(gemm_x3_chain_kernel<false>, dim3((g.M + 31) / 32, (g.N + 31) / 32, sk), dim3(64 * CH_NW), 0, s, a);
         return hipGetLastError();
     }
     if (g.M <= 64) {                                           // small batches: latency, not throughput (see the kernel comment)
         dim3 grid1(1, (g.N + 31) / 32, sk);
-        const size_t lds1 = (size_t)(X3_BM + 32) * X3_ROW;
+        const size_t lds1 = (size_t)(X3_BM + 32) * row_b;
         X3_ACT(1, 8, grid1, lds1)
         return hipGetLastError();
     }
@@ -464,7 +548,7 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     }
     const int bn = 32 * cb;
     dim3 grid((g.M + X3_BM - 1) / X3_BM, (g.N + bn - 1) / bn, sk);
-    const size_t lds = (size_t)(X3_BM + bn) * X3_ROW;
+    const size_t lds = (size_t)(X3_BM + bn) * row_b;
     switch (cb) {
         case 2: X3_ACT(2, 1, grid, lds) break;
         case 3: X3_ACT(3, 1, grid, lds) break;
@@ -475,5 +559,6 @@ hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s) {
     }
 #undef X3_ACT
 #undef X3_GO
+#undef X3_GO1
     return hipGetLastError();
 }

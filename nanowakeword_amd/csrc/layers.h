@@ -48,6 +48,10 @@ struct GemmArgs {
     // W pre-split into three bf16 terms ([N][ceil(K/16)][3][16], gemm_x3.hip); when set the contraction runs on the
     // bf16 matrix cores with exact operand splitting (float32-equivalent), else on v_mfma_f32_32x32x2_f32
     const void* Wx3 = nullptr;
+    // h2 != 0: Wx3 holds TWO binary16 terms of W * (a power of two) ([N][ceil(K/16)][2][16], launch_split_weights_h2); A is
+    // multiplied by a_scale (a power of two that keeps it inside the binary16 range) before it is split the same way, three
+    // partial products per operand pair go to v_mfma_f32_32x32x16_f16 and the sums leave times c_scale = 1 / (a_scale x weight scale)
+    int h2 = 0; float a_scale = 1.0f, c_scale = 1.0f;
     // > 0 (split-operand kernel only): A is stored as [ceil(M/128)][a_blocked = K/32][128][32] tiles (written that way by
     // the fused conv trunk) instead of row-major - every tile load is one contiguous 16 KB block.  With row-major A
     // (row stride 51 KB for fc1) the same loads reach 2.5-2.9 TB/s (tools/ubench/strided_read.hip)
@@ -60,6 +64,7 @@ struct GemmArgs {
 size_t gemm_x3_weight_bytes(int N, int K);
 // wave-specialised form (gemm_x3s.hip): producer waves stage + split, consumer waves multiply; same results bit for bit
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s);
+hipError_t launch_split_weights_h2(const float* W, void* out, int N, int K, float scale, hipStream_t s);
 bool gemm_x3_usable(const GemmArgs& g);
 bool gemm_writes_partials(const GemmArgs& g);   // launch_gemm will take an MFMA kernel (split-K partials), not the VALU fallback
 hipError_t launch_gemm_x3(const GemmArgs& g, hipStream_t s);

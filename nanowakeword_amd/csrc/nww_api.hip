@@ -73,7 +73,8 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     const nww_config& c = *cfg;
     if (c.head_type < 0 || c.head_type > NWW_HEAD_E2E_DNN) return fail(nullptr, NWW_ERR_INVALID, "Unsupported model_type code %d", c.head_type);
     if (c.activation < 0 || c.activation > 2) return fail(nullptr, NWW_ERR_INVALID, "bad activation code %d", c.activation);
-    if (c.conv_arith != NWW_ARITH_DEFAULT && c.conv_arith != NWW_ARITH_F32 && c.conv_arith != NWW_ARITH_BF16X6 && c.conv_arith != NWW_ARITH_BF16X9)
+    if (c.conv_arith != NWW_ARITH_DEFAULT && c.conv_arith != NWW_ARITH_F32 && c.conv_arith != NWW_ARITH_BF16X6 && c.conv_arith != NWW_ARITH_BF16X9 &&
+        c.conv_arith != NWW_ARITH_F16X3)
         return fail(nullptr, NWW_ERR_INVALID, "bad conv_arith code %d", c.conv_arith);
     if (c.in_rows <= 0 || c.in_cols <= 0 || c.embedding_dim < 2 || c.layer_dim <= 0 || c.n_blocks < 0)
         return fail(nullptr, NWW_ERR_INVALID, "bad head dimensions");
@@ -104,7 +105,8 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
     {   // conv_arith: explicit config > library default
         int mode = c.conv_arith;
         if (mode == NWW_ARITH_DEFAULT) mode = NWW_DEFAULT_CONV_ARITH;
-        h->conv_products = mode == NWW_ARITH_BF16X6 ? 6 : mode == NWW_ARITH_BF16X9 ? 9 : 0;
+        h->conv_products = (mode == NWW_ARITH_BF16X6 || mode == NWW_ARITH_F16X3) ? 6 : mode == NWW_ARITH_BF16X9 ? 9 : 0;
+        h->f16 = mode == NWW_ARITH_F16X3;
     }
     h->fe.sample_rate = c.sample_rate; h->fe.n_fft = c.n_fft; h->fe.win_length = c.win_length; h->fe.hop = c.hop_length;
     h->fe.n_mels = c.n_mels; h->fe.center = c.center; h->fe.f_min = c.f_min; h->fe.f_max = c.f_max;

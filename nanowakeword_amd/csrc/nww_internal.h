@@ -118,6 +118,7 @@ struct nww_handle {
     std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
     std::vector<void*> packed_weights;             // other plan-time weight packings (ffn_x3.hip)
     int conv_products = 0;                         // fused trunk: 0 = float32 MFMA, 6 | 9 = bf16 split products
+    bool f16 = false;                              // NWW_ARITH_F16X3: conv_products = 6, and the layers that have a two-term binary16 instance and a bound on their input use it
     int cu_count = 256;
     // profiling: per forward, events[0..n] bracket the n launches; accumulated on nww_get_profile
     bool profiling = false;

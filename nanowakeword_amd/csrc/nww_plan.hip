@@ -147,6 +147,44 @@ struct PlanCtx {
     bool dnn_body = false; const float *dnn_ln0_w = nullptr, *dnn_ln0_b = nullptr; int dnn_n_mid = 0; const float* dnn_mid[4][4] = {};
 };
 
+// ---- two-term binary16 arithmetic (NWW_ARITH_F16X3): plan-time bounds and power-of-two scales
+// device array -> host (plan time only; pack kernels of own_stream may still be writing derived arrays)
+std::vector<float> f16_fetch(nww_handle* h, const float* d, size_t n) {
+    std::vector<float> v(n, 0.0f);
+    if (d && n) {
+        (void)hipStreamSynchronize(h->own_stream);
+        if (hipMemcpy(v.data(), d, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) v.assign(n, INFINITY);
+    }
+    return v;
+}
+double f16_pow2_floor(double x) { int e; (void)std::frexp(x, &e); return std::ldexp(1.0, e - 1); }      // largest power of two <= x
+// scale that keeps |v| <= bound inside the binary16 range (65504), with 2 % to spare for the host / device difference of the bound
+float f16_scale(double bound) {
+    if (!(bound > 1e-30)) bound = 1e-30;
+    if (!(bound < 1e30)) return 0.0f;                             // no usable bound
+    double s = f16_pow2_floor(65504.0 / (bound * 1.02));
+    if (s > 1099511627776.0) s = 1099511627776.0;                // 2^40
+    return (float)s;
+}
+float f16_wscale(const std::vector<float>& w) {                   // the largest weight lands in [2^14, 2^15)
+    double m = 0;
+    for (float x : w) m = std::fmax(m, std::fabs((double)x));
+    return f16_scale(m * 2.0);
+}
+// |act((sum_k w[c][k] x[k] + b[c]) al[c] + be[c])| <= max_c (sum_k |w[c][k]| bound + |b[c]|) |al[c]| + |be[c]| for ReLU / GELU / SiLU
+double f16_layer_bound(const std::vector<float>& w, int Cout, int K, const std::vector<float>& b, bool has_b,
+                       const std::vector<float>& al, const std::vector<float>& be, bool has_bn, double in_bound) {
+    double worst = 0;
+    for (int c = 0; c < Cout; ++c) {
+        double t = 0;
+        for (int k = 0; k < K; ++k) t += std::fabs((double)w[(size_t)c * K + k]);
+        t = t * in_bound + (has_b ? std::fabs((double)b[c]) : 0.0);
+        if (has_bn) t = t * std::fabs((double)al[c]) + std::fabs((double)be[c]);
+        worst = std::fmax(worst, t);
+    }
+    return worst;
+}
+
 // source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
 inline const float* src(Run& r, int id) { return id == -1 ? r.x : id == -2 ? r.emb : id == -3 ? r.hid : r.buf[id]; }
 inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid : id == -4 ? r.logits : r.buf[id]; }
@@ -154,7 +192,8 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 // rows_per_clip: M = B*rows_per_clip
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
-              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false) {
+              int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false,
+              double a_bound = 0.0) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -170,12 +209,19 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
                          : x3_mode == 3 ? (K >= 4096 && N >= 64 && N <= 256)
                          : (x3_mode == 1 && N >= 64 && K >= 32 && !small_square));
     const void* wx3 = nullptr;
+    // two binary16 terms (NWW_ARITH_F16X3) when the caller knows a bound on |A|: A times a_scale stays inside the binary16 range
+    float h2_as = 0.0f, h2_ws = 0.0f;
+    if (use_x3 && p.h->f16 && a_bound > 0.0) {
+        h2_as = f16_scale(a_bound);
+        if (h2_as > 0.0f) h2_ws = f16_wscale(f16_fetch(p.h, W, (size_t)N * K));
+    }
+    const bool h2 = h2_as > 0.0f && h2_ws > 0.0f;
     if (use_x3) {
         auto it = p.h->x3_weights.find(W);
         if (it == p.h->x3_weights.end()) {
             void* d = nullptr;
             if (hipMalloc(&d, gemm_x3_weight_bytes(N, K)) == hipSuccess &&
-                launch_split_weights_x3(W, d, N, K, p.h->own_stream) == hipSuccess)
+                (h2 ? launch_split_weights_h2(W, d, N, K, h2_ws, p.h->own_stream) : launch_split_weights_x3(W, d, N, K, p.h->own_stream)) == hipSuccess)
                 it = p.h->x3_weights.emplace(W, d).first;
             else if (d) (void)hipFree(d);
         }
@@ -185,12 +231,13 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
     const int a_blocked = (a_blocked_inout && *a_blocked_inout && wx3 && K % 32 == 0 && rows_per_clip == 1) ? K / 32 : 0;
     if (a_blocked_inout) *a_blocked_inout = a_blocked != 0;
     if (K >= 2048 && (size_t)16 * rows_per_clip * N > p.h->splitk_per_clip) p.h->splitk_per_clip = (size_t)16 * rows_per_clip * N;
-    p.add("gemm:" + name, [=](Run& r) {
+    p.add("gemm:" + name + (h2 && wx3 ? " [f16x3]" : ""), [=](Run& r) {
         GemmArgs g;
         g.A = src(r, in_id); g.lda = K; g.W = W; g.C = dst(r, out_id); g.ldc = N;
         g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
         g.Wx3 = wx3;
+        if (h2) { g.h2 = 1; g.a_scale = h2_as; g.c_scale = 1.0f / (h2_as * h2_ws); }
         g.a_blocked = a_blocked;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
         // split-operand layers: chunks of ~16-25 k-tiles, so that a small batch's chunk is ONE round of gemm_x3_chain_kernel
@@ -264,7 +311,9 @@ static int trunk_fits(int C1, int H, int W) { int per_cu = 0; return trunk_pick_
 // fused conv1+pool+conv2+pool (trunk.hip) when the 1->16->32 pattern fits LDS; returns false if not applicable
 bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
                const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
-               const float* b2, const float* al2, const float* be2, int act, const bool* out_blocked = nullptr) {
+               const float* b2, const float* al2, const float* be2, int act, const bool* out_blocked = nullptr,
+               double in_bound = 0.0, double* out_bound = nullptr) {
+    if (out_bound) *out_bound = 0.0;
     static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
@@ -275,13 +324,29 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
         // both convolutions' weights as the MFMA register images, split into bf16 terms once (trunk_b.hip)
         void* packed = nullptr;
         if (hipMalloc(&packed, trunk_b_packed_bytes()) != hipSuccess) return false;
-        if (launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+        // NWW_ARITH_F16X3: two binary16 terms per operand when the input is bounded; the scales from bounds on conv1's / conv2's outputs
+        float f_in = 0.0f, f_s1 = 0.0f, f_w1 = 0.0f, f_w2 = 0.0f;
+        double bound2 = 0.0;
+        if (p.h->f16 && x3 == 6 && in_bound > 0.0 && (act == ACT_RELU || act == ACT_GELU || act == ACT_SILU)) {
+            const auto hw1 = f16_fetch(p.h, w1, (size_t)C1 * 9), hw2 = f16_fetch(p.h, w2, (size_t)C2 * C1 * 9);
+            const auto hb1 = f16_fetch(p.h, b1, C1), hb2 = f16_fetch(p.h, b2, C2);
+            const auto ha1 = f16_fetch(p.h, al1, C1), he1 = f16_fetch(p.h, be1, C1), ha2 = f16_fetch(p.h, al2, C2), he2 = f16_fetch(p.h, be2, C2);
+            const double bound1 = f16_layer_bound(hw1, C1, 9, hb1, b1 != nullptr, ha1, he1, al1 != nullptr, in_bound);
+            bound2 = f16_layer_bound(hw2, C2, C1 * 9, hb2, b2 != nullptr, ha2, he2, al2 != nullptr, bound1);
+            f_in = f16_scale(in_bound); f_s1 = f16_scale(bound1); f_w1 = f16_wscale(hw1); f_w2 = f16_wscale(hw2);
+        }
+        const bool f16 = f_in > 0.0f && f_s1 > 0.0f && f_w1 > 0.0f && f_w2 > 0.0f;
+        if ((f16 ? launch_trunk_b_pack_f16(w1, w2, static_cast<unsigned char*>(packed), f_w1, f_w2, p.h->own_stream)
+                 : launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream)) != hipSuccess) { (void)hipFree(packed); return false; }
         p.h->packed_weights.push_back(packed);
+        if (f16 && out_bound) *out_bound = bound2;
+        const int products = f16 ? 3 : x3;
         if (in_id == -1 && !p.h->e2e_transposed) p.h->x_stride_ok = true;                   // this step reads the head input with any clip stride
-        p.add("trunk_x3:" + name, [=](Run& r) {
+        p.add("trunk_x3:" + name + (f16 ? " [f16x3]" : ""), [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
             a.wpack = static_cast<const unsigned char*>(packed);
+            if (f16) { a.f16_in = f_in; a.f16_k1 = f_in * f_w1; a.f16_s1 = f_s1; a.f16_k2 = f_s1 * f_w2; a.f16_so = 1.0f; }
             if (in_id == -1) a.in_clip_stride = r.x_stride;
             if (r.stream_mode) {                        // streaming hop: pooled rows into the per-stream rings, all of them or the invalidated ones
                 a.out = r.a2_ring; a.out_ring_rows = r.a2_rows; a.out_row0 = r.a2_row0;
@@ -289,7 +354,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
                 a.n_sub = r.stream_mode == 2 ? r.a2_nsub : 0;
                 for (int q = 0; q < a.n_sub; ++q) { a.sub_a[q] = r.a2_sub_a[q]; a.sub_b[q] = r.a2_sub_b[q]; }
             }
-            return launch_cnn_trunk_b(a, x3, max_grid, r.stream);
+            return launch_cnn_trunk_b(a, products, max_grid, r.stream);
         });
         return true;
     }
@@ -527,7 +592,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
             static const int body_on = [] { const char* e = getenv("NWW_DNN_BODY"); return e ? atoi(e) : 1; }();
             if (tail_on && body_on && L <= 256 && nb <= 4 && tail_supported(L, E)) {
-                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
+                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND);
                 p.dnn_body = true;
                 p.dnn_ln0_w = p.W("model.layernorm1.weight"); p.dnn_ln0_b = p.W("model.layernorm1.bias");
                 p.dnn_n_mid = nb;
@@ -539,7 +604,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 set_tail(p, "layernorm1+blocks+last_layer", 0, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
                 break;
             }
-            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true);
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND);
             {
                 const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
                 p.add("layernorm:layernorm1", [=](Run& r) {
@@ -568,8 +633,10 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int H2 = T / 4, W2 = F / 4;
             h->trunk_blocked = (h->conv_products == 6 || h->conv_products == 9) && trunk_b_pick_strips(T, F) > 0 &&
                                (W2 % 4) == 0 && ((H2 * W2) % 4) == 0 && ((32 * H2 * W2) % 32) == 0;
+            double a2_bound = 0.0;                // NWW_ARITH_F16X3: a bound on the trunk's output, fc1's operand
             const bool fused = add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
-                                         p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked);
+                                         p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked,
+                                         NWW_F16_FEATURE_BOUND, &a2_bound);
             if (!fused) {
                 h->trunk_blocked = false;
                 add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
@@ -578,7 +645,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             // fc1's split-K partials are reduced by the classifier tail itself when that is the fused kernel
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
             add_gemm(p, "fc1", 1, 0, 1, 128, 32 * H2 * W2, p.W("model.fc1.weight"), p.W("model.fc1.bias"), act, nullptr, nullptr, 99, 1.f,
-                     &h->trunk_blocked, tail_on && tail_supported(128, E));
+                     &h->trunk_blocked, tail_on && tail_supported(128, E), false, a2_bound);
             set_tail(p, "fc2", 0, 128, p.W("model.fc2.weight"), p.W("model.fc2.bias"));
             break;
         }

@@ -26,6 +26,10 @@ struct TrunkArgs {
     size_t in_clip_stride = 0, out_clip_stride = 0, out_ch_stride = 0;
     int out_ring_rows = 0, out_row0 = 0;
     int n_sub = 0, sub_a[4] = {0, 0, 0, 0}, sub_b[4] = {0, 0, 0, 0};
+    // trunk_b, products = 3 (two binary16 terms per operand): powers of two fixed at plan time from bounds on the operands -
+    // f16_in scales the input, the conv1 / conv2 accumulators are f16_k1 / f16_k2 times the true sums (operand scale x weight
+    // scale), conv1's output is kept as f16_s1 times its value (conv2's operand), the output leaves f16_so times its value
+    float f16_in = 1.0f, f16_k1 = 1.0f, f16_s1 = 1.0f, f16_k2 = 1.0f, f16_so = 1.0f;
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;
@@ -112,8 +116,11 @@ hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hip
 // product is formed from `products` = 9 (all partial products, exact) or 6 (the terms below 2^-23 of the product dropped)
 // v_mfma_f32_32x32x16_bf16; conv1 as a transposed product per pooled pixel, conv1's output kept in LDS as three bf16 terms
 // per value, channels last.
-size_t trunk_b_lds_bytes(int H, int W, int strips);
+// products = 3: two binary16 terms per operand, three partial products on v_mfma_f32_32x32x16_f16 (weights packed by
+// launch_trunk_b_pack_f16 with their power-of-two scales; TrunkArgs::f16_*).
+size_t trunk_b_lds_bytes(int H, int W, int strips, int products = 6);
 int trunk_b_pick_strips(int H, int W);
 size_t trunk_b_packed_bytes();
 hipError_t launch_trunk_b_pack(const float* w1, const float* w2, unsigned char* packed, hipStream_t s);   // a.wpack
+hipError_t launch_trunk_b_pack_f16(const float* w1, const float* w2, unsigned char* packed, float sw1, float sw2, hipStream_t s);
 hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s);

@@ -6,6 +6,12 @@
 // Arithmetic: every float32 operand v is hi + mid + lo, three bf16 numbers holding its 24 significant bits exactly; a
 // float32 product is the sum of nine bf16 x bf16 partial products, each exact in float32, accumulated in float32 by
 // v_mfma_f32_32x32x16_bf16.  PRODUCTS = 9 issues all of them, PRODUCTS = 6 drops the three below 2^-23 of the product.
+// PRODUCTS = 3 ("f16x3"): every operand v, scaled by a power of two fixed at plan time so that it cannot leave the binary16 range,
+// is hi + lo with hi = RN16(v), lo = RN16(v - hi) - two binary16 numbers holding 22-23 of its 24 significant bits (the
+// remainder v - hi has at most 12 significant bits left, lo keeps 11 of them: a value is off by at most 2^-23 of itself, and
+// exact half of the time); the products hi*hi, hi*lo, lo*hi go to v_mfma_f32_32x32x16_f16 (each exact in float32, float32
+// accumulation), lo*lo is < 2^-22 of the product.  Half the matrix instructions of the six-product form; measured against
+// float64 the logits are as close as with the float32 MFMA (tools/x3_accuracy.py).  The scales: TrunkArgs::f16_*.
 //
 // conv1 is a TRANSPOSED split-operand product per pooled pixel:
 //     M = 32 rows = (16 channels x 2 conv columns dx) for one conv row dy,   K = 16 = the pixel's 4 x 4 input patch,
@@ -34,6 +40,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef NWW_TRACE      // phase stamps of the first items of the first and last eight workgroups (tools/ubench/trunk_trace.hip)
@@ -62,13 +71,23 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TB_ABL 0      // ablation mask of tools/ubench/trunk_trace.hip builds: 1 conv2 without per-tap LDS reads, 2 no conv2 epilogue,
 #endif                // 4 no conv1, 8 no conv2, 16 no conv1 epilogue (pool / split / A1 stores), 32 no input staging, 64 no input loads either
 namespace {
-constexpr int PS = 96;                  // bytes per A1 pixel: 3 terms x 16 channels x bf16
 constexpr int C1 = 16, C2 = 32;
 constexpr int NW = 8;                   // waves per workgroup
 constexpr int NTHR = 64 * NW;
-constexpr int NWL = 3;                  // conv2 weight fragments fetched from LDS per tile (the last tap's terms)
-constexpr int NWA = 27 - NWL;           // ... and the ones resident in registers
-constexpr int NFRAG = 27 + 6;           // packed fragments: conv2 (tap, term), then conv1 (dy, term); 1 KB each
+// what depends on the arithmetic: terms per value, bytes per A1 pixel (terms x 16 channels x 2 bytes; the two-term form pads
+// the pixel to 80 bytes: at 64 the sixteen pixels of a conv2 tile row would share four 16-byte bank slots), conv2 weight
+// fragments fetched from LDS per tile (the last tap's terms) / resident in registers, packed fragments (conv2 (tap, term),
+// then conv1 (dy, term); 1 KB each)
+template <int PRODUCTS>
+struct TbA {
+    static constexpr bool F16 = PRODUCTS == 3;
+    static constexpr int NT = F16 ? 2 : 3;
+    static constexpr int PS = F16 ? 80 : 96;
+    static constexpr int NF2 = 9 * NT, NF1 = 2 * NT;
+    static constexpr int NWL = F16 ? 0 : 3;
+    static constexpr int NWA = NF2 - NWL;
+};
+constexpr int NFRAG = 27 + 6;           // packed image size (the three-term form's; the two-term form uses 18 + 4 of them)
 
 template <int ACT>
 __device__ __forceinline__ float tb_act(float v) {
@@ -86,6 +105,14 @@ __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uin
 }
 // (a >> 16) | (b & 0xffff0000): bf16 of a in the low half, of b in the high half
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// (a, b) -> binary16 pairs hi = RN(v), lo = RN(v - hi) (v_cvt_pk_f16_f32, two v_cvt_f32_f16, two subtractions, v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
 __device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const u32x4 v = {a, b, c, d};
     return __builtin_bit_cast(bf16x8, v);
@@ -100,6 +127,14 @@ __device__ __forceinline__ bf16x8 to_agpr(bf16x8 f) {
 // acc += the PRODUCTS largest partial products of x (MFMA A operand, terms hi/mid/lo) and y (B operand), smallest first
 template <int PRODUCTS>
 __device__ __forceinline__ void x3_mfma(const bf16x8* x, const bf16x8* y, f32x16& acc) {
+    if (PRODUCTS == 3) {        // binary16 terms (fragments are carried as 128-bit bags typed bf16x8): lo*hi, hi*lo, hi*hi
+        const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+        const f16x8 yh = __builtin_bit_cast(f16x8, y[0]), yl = __builtin_bit_cast(f16x8, y[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc, 0, 0, 0);
+        return;
+    }
     if (PRODUCTS == 9) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[1], acc, 0, 0, 0);
@@ -116,13 +151,19 @@ __device__ __forceinline__ void x3_mfma(const bf16x8* x, const bf16x8* y, f32x16
 // bias/BN/act of the four values of a pooling window, then their maximum.  Without BN and with ReLU the maximum
 // commutes with the (monotone) bias add and ReLU, bit for bit, and relu(m + b) = max(m, -b) + b exactly: two v_max3_f32
 // and one add (the asm also keeps hipcc from canonicalising every MFMA output with a v_max x, x first).
-template <int ACT, bool BN>
-__device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be) {
+// SC (two-term binary16 form): the accumulators are k times the true sums (k = input scale x weight scale) and the result
+// leaves s times the true value (the next operand's scale); k, s powers of two, so every rounding below is the unscaled
+// one's: the caller passes bias k, and
+//   ReLU without BN: post = s / k                          ((u + bias k) s / k)
+//   ReLU with BN:    al s / k, be s                        (nothing else changes)
+//   other:           al / k (1 / k without BN), be, post = s   (the activation sees the true value)
+template <int ACT, bool BN, bool SC = false>
+__device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be, float post = 1.0f) {
     if (ACT == ACT_RELU && !BN) {
         float t, u;
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(t), "v"(v3), "v"(nbias));
-        return u + bias;
+        return SC ? (u + bias) * post : u + bias;
     }
     if (ACT == ACT_RELU && BN) {
         // v -> relu((v + bias) * al + be) is a chain of monotone roundings: non-decreasing for al >= 0, non-increasing for al < 0,
@@ -143,36 +184,38 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
         if (BN) t = t * al + be;
         m = fmaxf(m, tb_act<ACT>(t));
     }
-    return m;
+    return SC ? m * post : m;
 }
 
 // conv2 of one tile: 32 pixels (2 rows x 16 columns) x 32 output channels, 9 taps x (K = 16 input channels = one MFMA
 // per product).  The lane's pixel contributes three 16-byte fragments per tap (8 channels of one term).  pa: the
 // lane's pixel of the tile, dst: where its four pooled columns of output channel i go, nv: how many of them exist.
 template <int ACT, int PRODUCTS, bool BN>
-__device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, const bf16x8 (&bw)[NWA], const unsigned char* wl,
-                                           float bias2, float nbias2, float al2, float be2, float* dst, int nv) {
+__device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, const bf16x8 (&bw)[TbA<PRODUCTS>::NWA], const unsigned char* wl,
+                                           float bias2, float nbias2, float al2, float be2, float post2, float* dst, int nv) {
+    using AR = TbA<PRODUCTS>;
+    constexpr int NT = AR::NT, PS = AR::PS, NWL = AR::NWL, NWA = AR::NWA;
     f32x16 acc0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
-    bf16x8 na[3], wlast[NWL];
+    bf16x8 na[NT], wlast[NWL > 0 ? NWL : 1];
 #pragma unroll
-    for (int tm = 0; tm < 3; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + 32 * tm);
+    for (int tm = 0; tm < NT; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + 32 * tm);
 #pragma unroll
     for (int j = 0; j < NWL; ++j) wlast[j] = *reinterpret_cast<const bf16x8*>(wl + j * 1024);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        bf16x8 ca[3];
+        bf16x8 ca[NT];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) ca[tm] = na[tm];
+        for (int tm = 0; tm < NT; ++tm) ca[tm] = na[tm];
         if (tap + 1 < 9 && !(TB_ABL & 1)) {
             const int off = ((tap + 1) / 3) * rowB + ((tap + 1) % 3) * PS;
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 32 * tm);
+            for (int tm = 0; tm < NT; ++tm) na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 32 * tm);
         }
         // next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc otherwise sinks them to their first use)
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8* w = 3 * tap < NWA ? &bw[3 * tap] : &wlast[3 * tap - NWA];
+        const bf16x8* w = NT * tap < NWA ? &bw[NT * tap] : &wlast[NT * tap - NWA];
         x3_mfma<PRODUCTS>(ca, w, acc0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -183,7 +226,7 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
     float own[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)                      // pooled column 8X + 2k + hi
-        own[k] = pool_quad<ACT, BN>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2);
+        own[k] = pool_quad<ACT, BN, AR::F16>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2);
     // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7: v_permlane32_swap hands the upper half of
     // its first operand to the lower half of the second and vice versa - after it both halves hold (x, y) and (z, w)
     const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
@@ -204,15 +247,25 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
 // zero halos written once stay valid.  The 16 bytes of padding per A1 row put the two pixel rows of a
 // conv2 tile on disjoint 16-byte bank slots (rows 3264 bytes apart land on the SAME eight slots of the 256-byte bank
 // row: every ds_read_b128 of the round-2 layout was a two-way conflict).
+// Two-term form (80-byte pixels): the eight x positions of a 16-lane read group land on eight distinct 16-byte slots whose
+// complement is the same set shifted by eight slots, so the row pitch is 128 mod 256.
 struct TbGeom { int Wp0, Wp1, rowB, plane_b, a1_b; };
-__host__ __device__ inline TbGeom tb_geom(int W, const TrunkStrip& g) {
+__host__ __device__ inline TbGeom tb_geom(int W, const TrunkStrip& g, bool f16) {
     TbGeom r;
     r.Wp0 = (W + 3) & ~1;                                  // W + 2 columns (zero halo), even so rows stay dword aligned
     r.Wp1 = W / 2 + 2;
-    r.rowB = r.Wp1 * PS + 16;
+    if (f16) {
+        const int raw = r.Wp1 * 80;
+        r.rowB = raw + ((128 - raw % 256) + 256) % 256;
+    } else {
+        r.rowB = r.Wp1 * 96 + 16;
+    }
     r.plane_b = (g.in_rows * r.Wp0 * 2 + 15) & ~15;
     r.a1_b = (g.a1_rows * r.rowB + 64 + 15) & ~15;
     return r;
+}
+__host__ __device__ inline size_t tb_lds_total(const TbGeom& gg, bool f16) {
+    return (f16 ? 2 : 3) * (size_t)gg.plane_b + (size_t)gg.a1_b + (f16 ? 4 : 6) * 1024 + (f16 ? 0 : 3) * 1024;
 }
 
 // Weight fragments, computed once per model: [conv2 (tap, term)][64 lanes] then [conv1 (dy, term)][64 lanes], 16 bytes
@@ -246,8 +299,38 @@ __global__ void __launch_bounds__(64) trunk_b_pack_kernel(const float* __restric
     }
 }
 
+// the two-term binary16 image: [conv2 (tap, term)] 18 fragments then [conv1 (dy, term)] 4, weights times sw2 / sw1 (powers of two)
+__global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __restrict__ w1, const float* __restrict__ w2, unsigned char* __restrict__ out,
+                                                              float sw1, float sw2) {
+    const int lane = threadIdx.x, i = lane & 31, hi = lane >> 5;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out);
+    for (int tap = 0; tap < 9; ++tap) {
+        uint32_t th[4], tl[4];
+        for (int j = 0; j < 4; ++j)
+            split2h(w2[((size_t)i * C1 + 8 * hi + 2 * j) * 9 + tap] * sw2, w2[((size_t)i * C1 + 8 * hi + 2 * j + 1) * 9 + tap] * sw2, th[j], tl[j]);
+        o[(2 * tap + 0) * 64 + lane] = frag4(th[0], th[1], th[2], th[3]);
+        o[(2 * tap + 1) * 64 + lane] = frag4(tl[0], tl[1], tl[2], tl[3]);
+    }
+    const int m = i, cw = 8 * ((m >> 2) & 1) + 2 * (m >> 3) + ((m >> 1) & 1), dxw = m & 1;
+    for (int dy = 0; dy < 2; ++dy) {
+        float v[8];
+        for (int kk = 0; kk < 8; ++kk) {
+            const int ty = 2 * hi + (kk >> 2) - dy, tx = (kk & 3) - dxw;
+            const bool in = ty >= 0 && ty < 3 && tx >= 0 && tx < 3;
+            v[kk] = in ? w1[cw * 9 + ty * 3 + tx] * sw1 : 0.0f;
+        }
+        uint32_t th[4], tl[4];
+        for (int j = 0; j < 4; ++j) split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
+        o[(18 + dy * 2 + 0) * 64 + lane] = frag4(th[0], th[1], th[2], th[3]);
+        o[(18 + dy * 2 + 1) * 64 + lane] = frag4(tl[0], tl[1], tl[2], tl[3]);
+    }
+}
+
 template <int ACT, int PRODUCTS, bool BN>
 __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
+    using AR = TbA<PRODUCTS>;
+    constexpr bool F16 = AR::F16;
+    constexpr int NT = AR::NT, PS = AR::PS, NWA = AR::NWA, NWL = AR::NWL, NF2 = AR::NF2, NF1 = AR::NF1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     TB_STAMP_WG(0);
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
@@ -273,7 +356,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
             bstep = (int)gridDim.x / S;
         }
         const TrunkStrip sg = a.n_sub > 0 ? trunk_strip_rows(H, a.sub_a[sidx], a.sub_b[sidx]) : trunk_strip(H, S, sidx);
-        const TbGeom gg = tb_geom(W, sg);
+        const TbGeom gg = tb_geom(W, sg, F16);
         Wp0 = gg.Wp0; rowB = gg.rowB; plane_b = gg.plane_b; a1_b = gg.a1_b;
         n_a1 = sg.a1_hi - sg.a1_lo + 1;
         a1_shift = sg.a1_lo - sg.a1_base;
@@ -288,17 +371,17 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     const int ring_r0 = ring ? (a.out_row0 + (int)(out_off / W2)) % ring : 0;      // ring row of the strip's first pooled row
     const int pitch0 = 2 * Wp0;
     unsigned char* const In3 = lds_raw;
-    unsigned char* const A1 = lds_raw + 3 * plane_b;
+    unsigned char* const A1 = lds_raw + NT * plane_b;
     unsigned char* const W1F = A1 + a1_b;
-    unsigned char* const W2L = W1F + 6 * 1024;
+    unsigned char* const W2L = W1F + NF1 * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hi = lane >> 5;
 
     // zero the planes and A1 once: halos stay zero, interiors are rewritten per item
-    for (int k = tid; k < (3 * plane_b + a1_b) / 4; k += NTHR) reinterpret_cast<uint32_t*>(lds_raw)[k] = 0u;
+    for (int k = tid; k < (NT * plane_b + a1_b) / 4; k += NTHR) reinterpret_cast<uint32_t*>(lds_raw)[k] = 0u;
 
-    // weight fragments: conv2's first 24 stay in registers, its last three and conv1's six are parked in LDS by wave 0
+    // weight fragments: conv2's first NWA (24 of 27, or all 18) stay in registers, the rest and conv1's are parked in LDS by wave 0
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpack) + lane;
     bf16x8 bw[NWA];
 #pragma unroll
@@ -307,20 +390,32 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
 #pragma unroll
         for (int j = 0; j < NWL; ++j) *reinterpret_cast<bf16x8*>(W2L + j * 1024 + lane * 16) = wp[(NWA + j) * 64];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<bf16x8*>(W1F + j * 1024 + lane * 16) = wp[(27 + j) * 64];
+        for (int j = 0; j < NF1; ++j) *reinterpret_cast<bf16x8*>(W1F + j * 1024 + lane * 16) = wp[(NF2 + j) * 64];
     }
 #pragma unroll
     for (int j = 0; j < NWA; ++j) bw[j] = to_agpr(bw[j]);
     const unsigned char* wl = W2L + lane * 16;
-    const float bias2 = a.b2 ? a.b2[i] : 0.0f;
-    const float al2 = a.al2 ? a.al2[i] : 1.0f, be2 = a.al2 ? a.be2[i] : 0.0f;
+    // epilogue constants; in the two-term form rescaled as pool_quad's comment says (k = accumulator scale, s = output scale)
+    const float k1 = F16 ? a.f16_k1 : 1.0f, s1 = F16 ? a.f16_s1 : 1.0f, k2 = F16 ? a.f16_k2 : 1.0f, s2 = F16 ? a.f16_so : 1.0f;
+    constexpr bool RELU = ACT == ACT_RELU;
+    const float post1 = RELU ? s1 / k1 : s1, post2 = RELU ? s2 / k2 : s2;
+    float bias2 = a.b2 ? a.b2[i] : 0.0f;
+    float al2 = (BN && a.al2) ? a.al2[i] : 1.0f, be2 = (BN && a.al2) ? a.be2[i] : 0.0f;
+    if (F16) {
+        bias2 *= k2;
+        if (RELU) { al2 *= s2 / k2; be2 *= s2; } else al2 /= k2;
+    }
     float b1v[8], nb1v[8], al1v[8], be1v[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
         b1v[cc] = a.b1 ? a.b1[8 * hi + cc] : 0.0f;
-        nb1v[cc] = -b1v[cc];
         al1v[cc] = (BN && a.al1) ? a.al1[8 * hi + cc] : 1.0f;
         be1v[cc] = (BN && a.al1) ? a.be1[8 * hi + cc] : 0.0f;
+        if (F16) {
+            b1v[cc] *= k1;
+            if (RELU) { al1v[cc] *= s1 / k1; be1v[cc] *= s1; } else al1v[cc] /= k1;
+        }
+        nb1v[cc] = -b1v[cc];
     }
 
     // conv2 tiling of this strip (tile rows are local pooled rows).  SIMD s (waves s and s + 4) owns tiles s, s + 4, ...
@@ -334,30 +429,50 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     const int blk_kt = a.out_blocked;
     const int out_lane = ring ? i * (int)a.out_ch_stride + 4 * hi : i * H2 * W2 + 4 * hi;
 
-    // input rows -> the three bf16 planes (zero halo): value (y, x) at column x + 1 of local row y + row_shift
+    // input rows -> the NT planes of 16-bit terms (zero halo): value (y, x) at column x + 1 of local row y + row_shift
+    const float s_in = F16 ? a.f16_in : 1.0f;
     auto store4 = [&](unsigned char* planes, int idx, float4 v) {
         const int y = idx / W, x = idx - y * W;
         unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
-        uint32_t w[3][4];
-        split3(v.x, w[0][0], w[1][0], w[2][0]); split3(v.y, w[0][1], w[1][1], w[2][1]);
-        split3(v.z, w[0][2], w[1][2], w[2][2]); split3(v.w, w[0][3], w[1][3], w[2][3]);
+        if (F16) {
+            uint32_t hA, lA, hB, lB;                        // (v1, v2) share a dword; v0 and v3 are its neighbours' halves
+            split2h(v.y * s_in, v.z * s_in, hA, lA);
+            split2h(v.x * s_in, v.w * s_in, hB, lB);
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)hB;
+            *reinterpret_cast<uint32_t*>(d + 2) = hA;
+            *reinterpret_cast<uint16_t*>(d + 6) = (uint16_t)(hB >> 16);
+            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)lB;
+            *reinterpret_cast<uint32_t*>(d + plane_b + 2) = lA;
+            *reinterpret_cast<uint16_t*>(d + plane_b + 6) = (uint16_t)(lB >> 16);
+        } else {
+            uint32_t w[3][4];
+            split3(v.x, w[0][0], w[1][0], w[2][0]); split3(v.y, w[0][1], w[1][1], w[2][1]);
+            split3(v.z, w[0][2], w[1][2], w[2][2]); split3(v.w, w[0][3], w[1][3], w[2][3]);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            unsigned char* p = d + t * plane_b;
-            *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
-            *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
-            *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+            for (int t = 0; t < 3; ++t) {
+                unsigned char* p = d + t * plane_b;
+                *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
+                *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
+                *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+            }
         }
     };
     auto load_plane_sync = [&](unsigned char* planes, const float* xin) {
         for (int idx = tid; idx < n_in; idx += NTHR) {
             const int y = idx / W, x = idx - y * W;
-            uint32_t wh, wm, wlo;
-            split3(xin[idx], wh, wm, wlo);
             unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
-            *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
-            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
-            *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+            if (F16) {
+                uint32_t h, l;
+                split2h(xin[idx] * s_in, 0.0f, h, l);
+                *reinterpret_cast<uint16_t*>(d) = (uint16_t)h;
+                *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)l;
+            } else {
+                uint32_t wh, wm, wlo;
+                split3(xin[idx], wh, wm, wlo);
+                *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
+                *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
+                *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+            }
         }
     };
     constexpr int NPRE = 2;                                     // float4 registers per thread for the rows of the next item
@@ -369,16 +484,16 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     // conv1 of one item: groups first, first + stride, ... from `planes` into `a1buf`
     auto conv1_groups = [&](const unsigned char* planes, unsigned char* a1buf, int first, int stride) {
         if (TB_ABL & 4) return;
-        bf16x8 wf[2][3];
+        bf16x8 wf[2][NT];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) wf[q / 3][q % 3] = *reinterpret_cast<const bf16x8*>(W1F + q * 1024 + lane * 16);
+        for (int q = 0; q < NF1; ++q) wf[q / NT][q % NT] = *reinterpret_cast<const bf16x8*>(W1F + q * 1024 + lane * 16);
         const unsigned char* in_lane = planes + (2 * hi) * pitch0;
         unsigned char* a1w_lane = a1buf + a1_shift * rowB + PS + 16 * hi;        // pixel x of A1 row R at + R * rowB + x * PS
-        auto load_patch = [&](int R, int gx, bf16x8 (&f)[3]) {
+        auto load_patch = [&](int R, int gx, bf16x8 (&f)[NT]) {
             const int xc = min(32 * gx + i, W1 - 1);
             const unsigned char* base = in_lane + (2 * R) * pitch0 + 4 * xc;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(base + t * plane_b);
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(base + t * plane_b + pitch0);
                 f[t] = frag4(p[0], p[1], q[0], q[1]);
@@ -386,12 +501,12 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         };
         const int dR = stride / ngx, dX = stride - dR * ngx;
         int R = first / ngx, X = first - R * ngx;
-        bf16x8 nf[3];
+        bf16x8 nf[NT];
         if (first < nG) load_patch(R, X, nf);
         for (int g = first; g < nG; g += stride) {
-            bf16x8 cf[3];
+            bf16x8 cf[NT];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) cf[t] = nf[t];
+            for (int t = 0; t < NT; ++t) cf[t] = nf[t];
             const int Rc = R, Xc = X;
             R += dR; X += dX;
             if (X >= ngx) { X -= ngx; ++R; }
@@ -407,22 +522,28 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
             uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
-                uint32_t th[2], tm[2], tl[2];
+                float m2[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int cc = 2 * c2 + e;
-                    const float m = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1],
-                                                       b1v[cc], nb1v[cc], al1v[cc], be1v[cc]);
-                    split3(m, th[e], tm[e], tl[e]);
+                    m2[e] = pool_quad<ACT, BN, F16>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1],
+                                                    b1v[cc], nb1v[cc], al1v[cc], be1v[cc], post1);
                 }
-                ph[c2] = pack_hi16(th[0], th[1]); pm[c2] = pack_hi16(tm[0], tm[1]); pl[c2] = pack_hi16(tl[0], tl[1]);
+                if (F16) {
+                    split2h(m2[0], m2[1], ph[c2], pm[c2]);
+                } else {
+                    uint32_t th[2], tm[2], tl[2];
+                    split3(m2[0], th[0], tm[0], tl[0]);
+                    split3(m2[1], th[1], tm[1], tl[1]);
+                    ph[c2] = pack_hi16(th[0], th[1]); pm[c2] = pack_hi16(tm[0], tm[1]); pl[c2] = pack_hi16(tl[0], tl[1]);
+                }
             }
             const int x = 32 * Xc + i;
             if (x < W1) {
                 unsigned char* wq = a1w_lane + Rc * rowB + x * PS;
                 *reinterpret_cast<uint4*>(wq) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
                 *reinterpret_cast<uint4*>(wq + 32) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-                *reinterpret_cast<uint4*>(wq + 64) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                if (!F16) *reinterpret_cast<uint4*>(wq + 64) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
             }
         }
     };
@@ -445,7 +566,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         auto tile_pa = [&](int Rr, int Xx) { return a1buf + a1_lane + (2 * Rr) * rowB + (16 * Xx) * PS; };
         auto step = [&](int& Rr, int& Xx) { Xx += 4; while (Xx >= nX) { Xx -= nX; ++Rr; } };
         for (int n = 0; n < cnt; ++n) {
-            conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, tile_dst(R, X), tile_nv(X));
+            conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
             if (n < 4) TB_STAMP(2 + n);
             step(R, X);
         }
@@ -749,20 +870,26 @@ hipError_t launch_trunk_b_pack(const float* w1, const float* w2, unsigned char* 
     return hipGetLastError();
 }
 
-size_t trunk_b_lds_bytes(int H, int W, int S) {
+hipError_t launch_trunk_b_pack_f16(const float* w1, const float* w2, unsigned char* packed, float sw1, float sw2, hipStream_t s) {
+    hipLaunchKernelGGL(trunk_b_pack_f16_kernel, dim3(1), dim3(64), 0, s, w1, w2, packed, sw1, sw2);
+    return hipGetLastError();
+}
+
+size_t trunk_b_lds_bytes(int H, int W, int S, int products) {
     size_t worst = 0;
     for (int s = 0; s < S; ++s) {
         const TrunkStrip g = trunk_strip(H, S, s);
-        const TbGeom gg = tb_geom(W, g);
-        const size_t b = 3 * (size_t)gg.plane_b + (size_t)gg.a1_b + 6 * 1024 + NWL * 1024;
+        const size_t b = tb_lds_total(tb_geom(W, g, products == 3), products == 3);
         if (b > worst) worst = b;
     }
     return worst;
 }
+// The strip count follows the three-term form's LDS need in EVERY arithmetic (the two-term form would fit fewer, larger strips
+// for some shapes): how a clip is cut then never depends on the arithmetic switch.
 int trunk_b_pick_strips(int H, int W) {
     const int H2 = H / 4;
     for (int S = 1; S <= H2; ++S)
-        if (trunk_b_lds_bytes(H, W, S) <= 160 * 1024) return S;
+        if (trunk_b_lds_bytes(H, W, S, 6) <= 160 * 1024) return S;
     return 0;
 }
 
@@ -770,8 +897,10 @@ int trunk_b_pick_strips(int H, int W) {
     {                                                                                                                  \
         const bool bn_ = (aa).al1 != nullptr || (aa).al2 != nullptr;                                                   \
         hipError_t e_ = hipErrorInvalidValue;                                                                          \
-        const int key_ = ((aa).act == ACT_RELU ? 0 : (aa).act == ACT_GELU ? 1 : (aa).act == ACT_SILU ? 2 : 3) * 4 + (products == 6 ? 0 : 2) + (bn_ ? 1 : 0); \
+        int key_ = ((aa).act == ACT_RELU ? 0 : (aa).act == ACT_GELU ? 1 : (aa).act == ACT_SILU ? 2 : 3) * 4 + (products == 6 ? 0 : 2) + (bn_ ? 1 : 0); \
+        if (products == 3) key_ = (aa).act == ACT_RELU ? (bn_ ? 13 : 12) : (aa).act == ACT_GELU ? 14 : (aa).act == ACT_SILU ? 15 : 99; \
         switch (key_) {                                                                                                \
+            TB_CASE(12, ACT_RELU, 3, false) TB_CASE(13, ACT_RELU, 3, true) TB_CASE(14, ACT_GELU, 3, true) TB_CASE(15, ACT_SILU, 3, true) \
             TB_CASE(0, ACT_RELU, 6, false) TB_CASE(1, ACT_RELU, 6, true) TB_CASE(2, ACT_RELU, 9, false) TB_CASE(3, ACT_RELU, 9, true)   \
             TB_CASE(4, ACT_GELU, 6, false) TB_CASE(5, ACT_GELU, 6, true) TB_CASE(6, ACT_GELU, 9, false) TB_CASE(7, ACT_GELU, 9, true)   \
             TB_CASE(8, ACT_SILU, 6, false) TB_CASE(9, ACT_SILU, 6, true) TB_CASE(10, ACT_SILU, 9, false) TB_CASE(11, ACT_SILU, 9, true) \
@@ -800,8 +929,7 @@ static hipError_t launch_cnn_trunk_b_stream(TrunkArgs aa, int products, int max_
         S = aa.n_sub;
         for (int q = 0; q < S; ++q) {
             if (aa.sub_a[q] < 0 || aa.sub_b[q] <= aa.sub_a[q] || aa.sub_b[q] > H2) return hipErrorInvalidValue;
-            const TbGeom gg = tb_geom(aa.W, trunk_strip_rows(aa.H, aa.sub_a[q], aa.sub_b[q]));
-            const size_t b = 3 * (size_t)gg.plane_b + (size_t)gg.a1_b + 6 * 1024 + NWL * 1024;
+            const size_t b = tb_lds_total(tb_geom(aa.W, trunk_strip_rows(aa.H, aa.sub_a[q], aa.sub_b[q]), products == 3), products == 3);
             if (b > lds) lds = b;
         }
         if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -810,7 +938,7 @@ static hipError_t launch_cnn_trunk_b_stream(TrunkArgs aa, int products, int max_
         if (S < 1) return hipErrorInvalidValue;
         for (int small_strips : {8, 6, 4})
             if (small_strips > S && (long)aa.B * small_strips * 4 <= max_grid && small_strips <= aa.H / 4) { S = small_strips; break; }
-        lds = trunk_b_lds_bytes(aa.H, aa.W, S);
+        lds = trunk_b_lds_bytes(aa.H, aa.W, S, products);
     }
     aa.strips = S;
     const int per_cu = 1;                                        // eight waves x ~220 registers: one workgroup per CU whatever its LDS
@@ -824,7 +952,7 @@ static hipError_t launch_cnn_trunk_b_stream(TrunkArgs aa, int products, int max_
 }
 
 hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s) {
-    if (!a.wpack) return hipErrorInvalidValue;
+    if (!a.wpack || (products != 3 && products != 6 && products != 9)) return hipErrorInvalidValue;
     TrunkArgs aa = a;
     static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
     if (a.n_sub > 0 || a.out_ring_rows > 0) return launch_cnn_trunk_b_stream(aa, products, max_grid, s);
@@ -838,7 +966,7 @@ hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hi
         for (int small_strips : {8, 6, 4})
             if (small_strips > S && (long)a.B * small_strips * 4 <= max_grid && small_strips <= a.H / 4) { S = small_strips; break; }
     aa.strips = S;
-    const size_t lds = trunk_b_lds_bytes(a.H, a.W, S);
+    const size_t lds = trunk_b_lds_bytes(a.H, a.W, S, products);
     long want = (long)a.B * S;
     int grid = (int)(want < max_grid ? want : (long)max_grid);
     for (int q = 0; q < 8; ++q) aa.wg_end[q] = 0;

@@ -39,15 +39,15 @@ def cnn_f64(feats, sd):
 
 cfg = HeadConfig("cnn", (101, 64))
 sd = synth_state_dict(cfg)
-feats = synth_features(64, (101, 64), seed=5)
+feats = synth_features(int(os.environ.get("N_CLIPS", "64")), (101, 64), seed=5)
 emb64, logit64 = cnn_f64(feats, sd)
 res = {}
-for mode in ("f32", "bf16x9", "bf16x6"):
+for mode in ("f32", "bf16x9", "bf16x6", "f16x3"):
     m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith=mode)
     lg, _, emb = m.forward_features(feats, return_embedding=True)
     res[mode] = (emb.astype(np.float64), lg.astype(np.float64))
     print(f"{mode:7s} vs float64: max|d emb| {np.abs(res[mode][0] - emb64).max():.3e} (|emb| max {np.abs(emb64).max():.2f})"
           f"   max|d logit| {np.abs(res[mode][1] - logit64).max():.3e}   rms d logit {np.sqrt(np.mean((res[mode][1] - logit64) ** 2)):.3e}")
     m.close()
-for a, b in (("bf16x9", "f32"), ("bf16x6", "f32"), ("bf16x6", "bf16x9")):
+for a, b in (("bf16x9", "f32"), ("bf16x6", "f32"), ("bf16x6", "bf16x9"), ("f16x3", "f32"), ("f16x3", "bf16x9")):
     print(f"{a} vs {b}: max|d logit| {np.abs(res[a][1] - res[b][1]).max():.3e}  max|d emb| {np.abs(res[a][0] - res[b][0]).max():.3e}")

@@ -82,7 +82,7 @@ typedef struct nww_config {
                           v_mfma_f32_32x32x16_bf16 - exact products, float32 accumulation
          NWW_ARITH_BF16X6 the six largest partial products; the dropped ones are < 2^-23 of a product
          NWW_ARITH_F16X3  each operand, scaled by a power of two fixed at nww_finalize from bounds on the tensors (features
-                          are assumed inside +-NWW_F16_FEATURE_BOUND: log-mel dB values lie in [-100, 60]), split into TWO
+                          are clamped to +-NWW_F16_FEATURE_BOUND = 8192: log-mel dB values lie in [-100, 60]; the accuracy does not depend on how generous the bound is), split into TWO
                           binary16 terms holding 22-23 of its 24 significant bits; the three partial products >= 2^-22 of a
                           product on v_mfma_f32_32x32x16_f16, float32 accumulation - half the matrix instructions of
                           BF16X6 at the float32 MFMA's accuracy against float64.  Layers without an f16x3 instance, or
@@ -103,7 +103,7 @@ typedef struct nww_config {
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1
 #define NWW_ARITH_F16X3 3
-#define NWW_F16_FEATURE_BOUND 512.0f
+#define NWW_F16_FEATURE_BOUND 8192.0f
 #define NWW_ARITH_BF16X6 6
 #define NWW_ARITH_BF16X9 9
 

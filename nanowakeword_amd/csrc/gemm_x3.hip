@@ -39,6 +39,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 #ifdef X3_TRACE      // tools/ubench/gemm_x3_trace.hip: s_memtime stamps of workgroup 0's first k-tiles (phase boundaries per wave)
 __device__ unsigned long long x3_trace_buf[4 * 16 * 4];
@@ -107,7 +109,7 @@ __device__ __forceinline__ void x3_products(const uint4* a, const uint4* w, f32x
 }
 }  // namespace
 
-// W [N][K] float32 -> [N][KB][3][16] bf16, KB = ceil(K/16), zero beyond K
+// W [N][K] float32 -> [N][KB][3][16] bf16, KB = 2 ceil(K/32) (whole 32-k tiles: the kernels load without a bound check), zero beyond K
 __global__ void __launch_bounds__(256) split_weights_x3_kernel(const float* __restrict__ W, uint16_t* __restrict__ out,
                                                                int N, int K, int KB) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // one (n, k) element
@@ -162,12 +164,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
     auto Ws = [&](int) { return smem + X3_BM * X3_ROW; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int bm = blockIdx.x * X3_BM, bn = blockIdx.y * BN;
-    const int KB = (g.K + 15) >> 4, KT = (g.K + 31) >> 5;      // 16-k blocks of the split weights, 32-k tiles
+    const int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    // (an XCD-aware tile map - every XCD keeping a few W chunks in its L2 - measured no change: rocprofv3 FETCH_SIZE of fc1 is A's
+    // 211 MB already, the split W is served from L2 as it is)
+    const int bm = bxi * X3_BM, bn = byi * BN;
+    const int KT = (g.K + 31) >> 5, KB = 2 * KT;               // 32-k tiles, 16-k blocks of the split weights (zero padded to whole tiles)
     int kt_begin = 0, kt_end = KT;
     if (g.splitk > 1) {
         const int kc = (KT + g.splitk - 1) / g.splitk;
-        kt_begin = blockIdx.z * kc;
+        kt_begin = bzi * kc;
         kt_end = min(KT, kt_begin + kc);
     }
     const uint4* Wx = reinterpret_cast<const uint4*>(g.Wx3);
@@ -180,19 +185,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
         arow[q] = g.a_blocked ? g.A + ((size_t)(bm >> 7) * g.a_blocked * 128 + lr + 32 * q) * 32 + 4 * lq
                               : g.A + (size_t)min(bm + lr + 32 * q, g.M - 1) * g.lda + 4 * lq;
     const int a_kstep = g.a_blocked ? 128 * 32 : 32;           // floats between consecutive k-tiles of a row
-    constexpr int AQ = NST > 1 ? 2 : 4;                        // the small-M instance (M <= 64) stages rows 0..63 only
-    struct Stage { float4 a[AQ]; uint4 w[WLD]; };
+    constexpr int AQ = (NST > 1 && CB == 1) ? 2 : 4;           // the small-M instance (M <= 64) stages rows 0..63 only
+    struct Stage { f32x4v a[AQ]; u32x4v w[WLD]; };
+    // Unconditional loads: the split weights are zero padded to whole k-tiles, and a float4 of A beyond K (K % 4 == 0:
+    // gemm_x3_usable) is fetched from the row's first tile instead - finite values that meet those zeros.  Loads under exec-mask
+    // branches (bound checks, or a select that hipcc turns back into a branch) made its wait-count pass put s_waitcnt vmcnt(0)
+    // behind every group of them: no load of a later stage stayed in flight across a k-tile, NST > 1 bought nothing.
     auto gload = [&](int kt, Stage& st) {
         const int k = kt * 32 + 4 * lq;
+        const size_t a_off = k + 4 <= g.K ? (size_t)kt * a_kstep : 0;
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
-            if (k + 4 <= g.K) {
-                st.a[q] = *reinterpret_cast<const float4*>(arow[q] + (size_t)kt * a_kstep);
-            } else {                                           // K tail: element-wise, zero beyond K
-                const float* p = arow[q] + (size_t)kt * a_kstep;
-                st.a[q].x = k + 0 < g.K ? p[0] : 0.0f; st.a[q].y = k + 1 < g.K ? p[1] : 0.0f;
-                st.a[q].z = k + 2 < g.K ? p[2] : 0.0f; st.a[q].w = k + 3 < g.K ? p[3] : 0.0f;
-            }
+            st.a[q] = *reinterpret_cast<const f32x4v*>(arow[q] + a_off);
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) {
@@ -201,25 +205,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
                 const int row = p / (2 * PB), c = p - row * (2 * PB);
                 const int n = min(bn + row, g.N - 1);
                 const int kb = 2 * kt + c / PB;                // 16-k block of this piece
-                st.w[j] = kb < KB ? Wx[((size_t)n * KB + kb) * PB + (c % PB)] : make_uint4(0, 0, 0, 0);
+                st.w[j] = *reinterpret_cast<const u32x4v*>(Wx + ((size_t)n * KB + kb) * PB + (c % PB));
             }
         }
     };
     const float a_scale = H2 ? g.a_scale : 1.0f;
+    const float a_lim = H2 ? (g.a_clamp > 0.0f ? g.a_clamp * a_scale : 65504.0f) : 0.0f;      // scaled clamp (65504: no clamp asked - saturate instead of inf)
     auto lstore = [&](int buf, const Stage& st) {
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
             unsigned char* d = As(buf) + (lr + 32 * q) * X3_ROW + 8 * lq;
             if (H2) {
                 uint32_t h0, l0, h1, l1;
-                split2h(st.a[q].x * a_scale, st.a[q].y * a_scale, h0, l0);
-                split2h(st.a[q].z * a_scale, st.a[q].w * a_scale, h1, l1);
+                split2h(__builtin_amdgcn_fmed3f(st.a[q][0] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][1] * a_scale, -a_lim, a_lim), h0, l0);
+                split2h(__builtin_amdgcn_fmed3f(st.a[q][2] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][3] * a_scale, -a_lim, a_lim), h1, l1);
                 *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(d + 64) = make_uint2(l0, l1);
             } else {
                 uint32_t hi[4], mid[4], lo[4];
-                split3(st.a[q].x, hi[0], mid[0], lo[0]); split3(st.a[q].y, hi[1], mid[1], lo[1]);
-                split3(st.a[q].z, hi[2], mid[2], lo[2]); split3(st.a[q].w, hi[3], mid[3], lo[3]);
+                split3(st.a[q][0], hi[0], mid[0], lo[0]); split3(st.a[q][1], hi[1], mid[1], lo[1]);
+                split3(st.a[q][2], hi[2], mid[2], lo[2]); split3(st.a[q][3], hi[3], mid[3], lo[3]);
                 *reinterpret_cast<uint2*>(d) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
                 *reinterpret_cast<uint2*>(d + 64) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
                 *reinterpret_cast<uint2*>(d + 128) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
             if (WPIECES % 256 == 0 || p < WPIECES) {
                 const int row = p / (2 * PB), c = p - row * (2 * PB);
                 const int cp = c % PB;                         // (term, half) inside the 16-k block
-                *reinterpret_cast<uint4*>(Ws(buf) + row * X3_ROW + (cp >> 1) * 64 + (c / PB) * 32 + (cp & 1) * 16) = st.w[j];
+                *reinterpret_cast<u32x4v*>(Ws(buf) + row * X3_ROW + (cp >> 1) * 64 + (c / PB) * 32 + (cp & 1) * 16) = st.w[j];
             }
         }
     };
@@ -245,9 +250,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
     // One LDS stage per workgroup (53 KB for BN = 128, so two workgroups share a CU and cover each other's staging
     // phases); global loads run NST k-tiles ahead in NST register stages.
     Stage st[NST];
+    // every load is issued unconditionally (a k-tile index beyond the chunk repeats its last tile and is never multiplied): loads
+    // under "is there another tile" / bound-check branches get an s_waitcnt vmcnt(0) behind every group from hipcc's wait-count
+    // pass, and the next tile's loads then do not stay in flight under this tile's products (fc1: 0.096 -> 0.064 ms).
+    // (Measured and not kept: more than one register stage in flight for the bulk instances.  hipcc drains ALL stages at the loop
+    // head - 0.082 ms with the old branchy loads, no better than one stage with these; inline-asm loads with hand-counted vmcnt
+    // are not safe here: the allocator re-uses a destination register of a load it believes complete.)
 #pragma unroll
-    for (int q = 0; q < NST; ++q)
-        if (kt_begin + q < kt_end) gload(kt_begin + q, st[q]);
+    for (int q = 0; q < NST; ++q) gload(min(kt_begin + q, kt_end - 1), st[q]);
     const bool has_rows = bm + wave * 32 < g.M;                  // waves whose 32 rows lie beyond M only help with the staging
     const int a_off = (wave * 32 + i) * X3_ROW + 16 * h, w_off = i * X3_ROW + 16 * h;
     auto multiply = [&]() {
@@ -277,10 +287,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
                 lstore(0, st[q]);
                 __syncthreads();
                 X3_STAMP(kt + q - kt_begin, 2)
-                if (kt + q + NST < kt_end) gload(kt + q + NST, st[q]);
-                if (NST == 1 || has_rows) multiply();
-                X3_STAMP(kt + q - kt_begin, 3)
             }
+            gload(min(kt + q + NST, kt_end - 1), st[q]);
+            if (kt + q < kt_end && (NST == 1 || has_rows)) multiply();
+            X3_STAMP(kt + q - kt_begin, 3)
         }
     }
 
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
         const int n = bn + c * 32 + i;
         if (n >= g.N) continue;
         if (g.splitk > 1) {
-            float* part = g.splitk_ws + (size_t)blockIdx.z * g.M * g.N;
+            float* part = g.splitk_ws + (size_t)bzi * g.M * g.N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -357,11 +367,12 @@ template <bool H2>
 __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     constexpr int NT = X3A<H2>::NT, PB = 2 * NT;
     const float a_scale = H2 ? g.a_scale : 1.0f, c_scale = H2 ? g.c_scale : 1.0f;
+    const float a_lim = H2 ? (g.a_clamp > 0.0f ? g.a_clamp * a_scale : 65504.0f) : 0.0f;
     __shared__ __attribute__((aligned(16))) float4 hand[4 * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 31, h = lane >> 5;
     const int bm = blockIdx.x * 32, bn = blockIdx.y * 32;
-    const int KB = (g.K + 15) >> 4, KT = (g.K + 31) >> 5;
+    const int KT = (g.K + 31) >> 5, KB = 2 * KT;
     const int kc = (KT + g.splitk - 1) / g.splitk;
     const int kt_begin = blockIdx.z * kc, kt_end = min(KT, kt_begin + kc);
     const int mrow = min(bm + i, g.M - 1);
@@ -400,7 +411,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
                 ar[t][kk][0] = *reinterpret_cast<const float4*>(ap);
                 ar[t][kk][1] = *reinterpret_cast<const float4*>(ap + 4);
                 if (!in_k) { ar[t][kk][0] = make_float4(0.f, 0.f, 0.f, 0.f); ar[t][kk][1] = ar[t][kk][0]; }
-                const int kb = min(2 * kt + kk, KB - 1);                      // a k-block beyond KB meets zeros of A
+                const int kb = 2 * kt + kk;
 #pragma unroll
                 for (int term = 0; term < NT; ++term) wf[t][kk][term] = wrow[(size_t)kb * PB + 2 * term];
             }
@@ -429,7 +440,8 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
                         if (H2) {
                             uint32_t hh[4], ll[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) split2h(x[2 * j] * a_scale, x[2 * j + 1] * a_scale, hh[j], ll[j]);
+                            for (int j = 0; j < 4; ++j)
+                                split2h(__builtin_amdgcn_fmed3f(x[2 * j] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(x[2 * j + 1] * a_scale, -a_lim, a_lim), hh[j], ll[j]);
                             af[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
                             af[1] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
                         } else {
@@ -463,10 +475,10 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
     }
 }
 
-size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * ((K + 15) / 16) * 96; }      // (the two-term image needs 64 of the 96)
+size_t gemm_x3_weight_bytes(int N, int K) { return (size_t)N * (2 * ((K + 31) / 32)) * 96; }      // (the two-term image needs 64 of the 96)
 
 hipError_t launch_split_weights_h2(const float* W, void* out, int N, int K, float scale, hipStream_t s) {
-    const int KB = (K + 15) / 16;
+    const int KB = 2 * ((K + 31) / 32);
     const size_t total = (size_t)N * KB * 16;
     hipLaunchKernelGGL(split_weights_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W,
                        reinterpret_cast<uint16_t*>(out), N, K, KB, scale);
@@ -474,7 +486,7 @@ hipError_t launch_split_weights_h2(const float* W, void* out, int N, int K, floa
 }
 
 hipError_t launch_split_weights_x3(const float* W, void* out, int N, int K, hipStream_t s) {
-    const int KB = (K + 15) / 16;
+    const int KB = 2 * ((K + 31) / 32);
     const size_t total = (size_t)N * KB * 16;
     hipLaunchKernelGGL(split_weights_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W,
                        reinterpret_cast<uint16_t*>(out), N, K, KB);
@@ -494,7 +506,7 @@ static int x3_pick_cb(int N) {
 }
 
 bool gemm_x3_usable(const GemmArgs& g) {
-    return g.Wx3 != nullptr && g.N >= 32 && g.K >= 32 && (g.lda % 4 == 0) && (!g.a_blocked || g.K % 32 == 0) &&
+    return g.Wx3 != nullptr && g.N >= 32 && g.K >= 32 && (g.K % 4 == 0) && (g.lda % 4 == 0) && (!g.a_blocked || g.K % 32 == 0) &&
            ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
 }
 

@@ -51,7 +51,8 @@ struct GemmArgs {
     // h2 != 0: Wx3 holds TWO binary16 terms of W * (a power of two) ([N][ceil(K/16)][2][16], launch_split_weights_h2); A is
     // multiplied by a_scale (a power of two that keeps it inside the binary16 range) before it is split the same way, three
     // partial products per operand pair go to v_mfma_f32_32x32x16_f16 and the sums leave times c_scale = 1 / (a_scale x weight scale)
-    int h2 = 0; float a_scale = 1.0f, c_scale = 1.0f;
+    // a_clamp > 0: A is clamped to +-a_clamp first (an ASSUMED bound - the head's input features; bounds derived from the weights hold by themselves)
+    int h2 = 0; float a_scale = 1.0f, c_scale = 1.0f, a_clamp = 0.0f;
     // > 0 (split-operand kernel only): A is stored as [ceil(M/128)][a_blocked = K/32][128][32] tiles (written that way by
     // the fused conv trunk) instead of row-major - every tile load is one contiguous 16 KB block.  With row-major A
     // (row stride 51 KB for fc1) the same loads reach 2.5-2.9 TB/s (tools/ubench/strided_read.hip)

@@ -52,7 +52,7 @@ static size_t numel(const Shape& s) { size_t n = 1; for (auto v : s) n *= (size_
 
 // ------------------------------------------------------------------------------------------ create / load
 // bf16x6 is float32-grade (tools/x3_accuracy.py: max |dlogit| vs float64 5.2e-6, the float32 MFMA path 5.0e-6) and 1.7x faster
-#define NWW_DEFAULT_CONV_ARITH NWW_ARITH_BF16X6
+#define NWW_DEFAULT_CONV_ARITH NWW_ARITH_F16X3
 extern "C" void nww_default_config(nww_config* c) {
     std::memset(c, 0, sizeof(*c));
     c->sample_rate = 16000; c->n_fft = 400; c->win_length = 400; c->hop_length = 160; c->n_mels = 64; c->center = 1;

@@ -193,7 +193,7 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false,
-              double a_bound = 0.0) {
+              double a_bound = 0.0, bool a_bound_assumed = false) {
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -237,7 +237,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         g.M = r.B * rows_per_clip; g.N = N; g.K = K; g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
         g.res = res_id == 99 ? nullptr : src(r, res_id); g.ldres = N; g.rscale = rscale;
         g.Wx3 = wx3;
-        if (h2) { g.h2 = 1; g.a_scale = h2_as; g.c_scale = 1.0f / (h2_as * h2_ws); }
+        if (h2) { g.h2 = 1; g.a_scale = h2_as; g.c_scale = 1.0f / (h2_as * h2_ws); g.a_clamp = a_bound_assumed ? (float)a_bound : 0.0f; }
         g.a_blocked = a_blocked;
         g.splitk = gemm_recommended_splitk(g.M, N, K, r.cu_count);
         // split-operand layers: chunks of ~16-25 k-tiles, so that a small batch's chunk is ONE round of gemm_x3_chain_kernel
@@ -346,7 +346,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
             a.wpack = static_cast<const unsigned char*>(packed);
-            if (f16) { a.f16_in = f_in; a.f16_k1 = f_in * f_w1; a.f16_s1 = f_s1; a.f16_k2 = f_s1 * f_w2; a.f16_so = 1.0f; }
+            if (f16) { a.f16_in = f_in; a.f16_k1 = f_in * f_w1; a.f16_s1 = f_s1; a.f16_k2 = f_s1 * f_w2; a.f16_so = 1.0f; a.f16_clamp = (float)in_bound; }
             if (in_id == -1) a.in_clip_stride = r.x_stride;
             if (r.stream_mode) {                        // streaming hop: pooled rows into the per-stream rings, all of them or the invalidated ones
                 a.out = r.a2_ring; a.out_ring_rows = r.a2_rows; a.out_row0 = r.a2_row0;
@@ -592,7 +592,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
             static const int body_on = [] { const char* e = getenv("NWW_DNN_BODY"); return e ? atoi(e) : 1; }();
             if (tail_on && body_on && L <= 256 && nb <= 4 && tail_supported(L, E)) {
-                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND);
+                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND, true);
                 p.dnn_body = true;
                 p.dnn_ln0_w = p.W("model.layernorm1.weight"); p.dnn_ln0_b = p.W("model.layernorm1.bias");
                 p.dnn_n_mid = nb;
@@ -604,7 +604,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 set_tail(p, "layernorm1+blocks+last_layer", 0, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
                 break;
             }
-            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND);
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND, true);
             {
                 const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
                 p.add("layernorm:layernorm1", [=](Run& r) {
@@ -678,7 +678,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
                 const bool ok = add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
                                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
-                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act) &&
+                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND) &&
                                 h->plan.back().name.rfind("trunk_x3:", 0) == 0 && h3 >= 4 &&
                                 add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
                                               p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1);
@@ -697,7 +697,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             bool fused_pool = false;
             if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
-                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act)) {
+                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND)) {
                 first = 2; cin = 32; hh = Hh / 4; ww = Ww / 4; cur = 1;
             }
             for (int i = first; i < 3; ++i) {
@@ -739,7 +739,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
                 add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
                           p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
-                          p.W("model.cnn.5.beta"), act)) {
+                          p.W("model.cnn.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND)) {
                 first = 2; cin = 32; hh = T / 4; ww = F / 4; cur = 1;
             }
             for (int i = first; i < c.n_crnn_channels; ++i) {

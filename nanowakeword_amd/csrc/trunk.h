@@ -29,7 +29,8 @@ struct TrunkArgs {
     // trunk_b, products = 3 (two binary16 terms per operand): powers of two fixed at plan time from bounds on the operands -
     // f16_in scales the input, the conv1 / conv2 accumulators are f16_k1 / f16_k2 times the true sums (operand scale x weight
     // scale), conv1's output is kept as f16_s1 times its value (conv2's operand), the output leaves f16_so times its value
-    float f16_in = 1.0f, f16_k1 = 1.0f, f16_s1 = 1.0f, f16_k2 = 1.0f, f16_so = 1.0f;
+    // the input is clamped to +-f16_clamp (the bound f16_in was derived from) before it is scaled
+    float f16_in = 1.0f, f16_k1 = 1.0f, f16_s1 = 1.0f, f16_k2 = 1.0f, f16_so = 1.0f, f16_clamp = 65504.0f;
 };
 struct TrunkStrip {
     int R2a, R2b, a1_base, a1_lo, a1_hi, a1_rows, iy0, in_rows, y_lo, y_hi;

@@ -242,6 +242,56 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
     }
 }
 
+// The two-term form of conv2_tile.  A tap is three MFMAs (96 matrix-pipe clocks) here, less than an LDS read takes to come back
+// with eight waves reading: fetched one tap ahead (conv2_tile) every tap waited for its fragments and a tile took 2.3 k clocks
+// per wave for 864 clocks of MFMAs (tools/ubench/trunk_trace.hip).  The fragments travel THREE taps ahead in a ring of
+// registers instead, across the tile boundary too: the last three taps of a tile request the first three of the wave's next
+// tile (pa_next; null behind the last tile).  ring: taps 0..2 of this tile on entry, of the next tile on exit.
+template <int ACT, bool BN>
+__device__ __forceinline__ void conv2_tile_h2(const unsigned char* pa, const unsigned char* pa_next, int rowB, const bf16x8 (&bw)[18],
+                                              bf16x8 (&ring)[3][2], float bias2, float nbias2, float al2, float be2, float post2,
+                                              float* dst, int nv) {
+    constexpr int PS = TbA<3>::PS;
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 ca[2] = {ring[tap % 3][0], ring[tap % 3][1]};
+        if (!(TB_ABL & 1)) {
+            const int nt = tap + 3 < 9 ? tap + 3 : tap + 3 - 9;
+            const unsigned char* src = tap + 3 < 9 ? pa : pa_next;
+            if (src) {
+                const int off = (nt / 3) * rowB + (nt % 3) * PS;
+                ring[tap % 3][0] = *reinterpret_cast<const bf16x8*>(src + off);
+                ring[tap % 3][1] = *reinterpret_cast<const bf16x8*>(src + off + 32);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the reads stay ABOVE this tap's MFMAs (hipcc otherwise sinks them to their first use)
+        x3_mfma<3>(ca, &bw[2 * tap], acc0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TB_ABL & 2) {
+        asm volatile("" ::"a"(acc0));
+        return;
+    }
+    float own[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        own[k] = pool_quad<ACT, BN, true>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2);
+    const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[1]), __float_as_uint(own[3]), false, false);
+    float4 o;
+    o.x = __uint_as_float(s02[0]); o.y = __uint_as_float(s02[1]); o.z = __uint_as_float(s13[0]); o.w = __uint_as_float(s13[1]);
+    if (nv >= 4) {
+        *reinterpret_cast<float4*>(dst) = o;
+    } else {
+        if (nv > 0) dst[0] = o.x;
+        if (nv > 1) dst[1] = o.y;
+        if (nv > 2) dst[2] = o.z;
+    }
+}
+
 // LDS map (bytes): [3 input planes: in_rows x Wp0 bf16 each][A1: a1_rows x (Wp1 x 96 + 16) (+64 slack)][conv1
 // weight fragments 6 KB][conv2 last-tap fragments 3 KB].  A workgroup keeps ONE strip index for its whole life, so the
 // zero halos written once stay valid.  The 16 bytes of padding per A1 row put the two pixel rows of a
@@ -252,7 +302,7 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
 struct TbGeom { int Wp0, Wp1, rowB, plane_b, a1_b; };
 __host__ __device__ inline TbGeom tb_geom(int W, const TrunkStrip& g, bool f16) {
     TbGeom r;
-    r.Wp0 = (W + 3) & ~1;                                  // W + 2 columns (zero halo), even so rows stay dword aligned
+    r.Wp0 = (W + 5) & ~3;                                  // W + 2 columns (zero halo), a multiple of four: a row is whole 8-byte chunks of four columns
     r.Wp1 = W / 2 + 2;
     if (f16) {
         const int raw = r.Wp1 * 80;
@@ -327,7 +377,7 @@ __global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __res
 }
 
 template <int ACT, int PRODUCTS, bool BN>
-__global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
+__device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
     using AR = TbA<PRODUCTS>;
     constexpr bool F16 = AR::F16;
     constexpr int NT = AR::NT, PS = AR::PS, NWA = AR::NWA, NWL = AR::NWL, NF2 = AR::NF2, NF1 = AR::NF1;
@@ -392,6 +442,8 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
 #pragma unroll
         for (int j = 0; j < NF1; ++j) *reinterpret_cast<bf16x8*>(W1F + j * 1024 + lane * 16) = wp[(NF2 + j) * 64];
     }
+    // (measured for the two-term form: without any AGPR constraint hipcc allocates 183 VGPRs and VGPR-form MFMAs, whose operand
+    // traffic starves the SIMD's other wave of VALU issue - 0.254 ms against 0.236 with the fragments pinned here)
 #pragma unroll
     for (int j = 0; j < NWA; ++j) bw[j] = to_agpr(bw[j]);
     const unsigned char* wl = W2L + lane * 16;
@@ -429,32 +481,42 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
     const int blk_kt = a.out_blocked;
     const int out_lane = ring ? i * (int)a.out_ch_stride + 4 * hi : i * H2 * W2 + 4 * hi;
 
-    // input rows -> the NT planes of 16-bit terms (zero halo): value (y, x) at column x + 1 of local row y + row_shift
-    const float s_in = F16 ? a.f16_in : 1.0f;
-    auto store4 = [&](unsigned char* planes, int idx, float4 v) {
-        const int y = idx / W, x = idx - y * W;
-        unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
+    // input rows -> the NT planes of 16-bit terms (zero halo): value (y, x) at column x + 1 of local row y + row_shift.
+    // A thread moves CHUNKS of four plane columns 4 j .. 4 j + 3 = inputs x = 4 j - 1 .. 4 j + 2 (W / 4 + 1 chunks per row): one
+    // 16-byte load (dword aligned) and one aligned 8-byte LDS store per term.  Chunks of four INPUTS land two bytes off an
+    // 8-byte boundary, and those misaligned LDS stores cost 3.7 k of an item's 19 k clocks (tools/ubench/trunk_trace.hip, -DTB_ABL=32).
+    // (two-term form: the input is clamped to +-f16_clamp, the bound the plan-time scales were derived from - whatever comes in,
+    // no term can leave the binary16 range.  Log-mel dB values never reach it.)
+    const float s_in = F16 ? a.f16_in : 1.0f, c_in = F16 ? a.f16_clamp * s_in : 0.0f;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NPRE = 2;                                     // chunks per thread for the rows of an item in flight
+    const int CPR = W / 4 + 1, n_chunks = (n_in / W) * CPR;
+    const bool vec_in = (W & 3) == 0 && (in_clip & 3) == 0 && n_chunks <= NPRE * NTHR;
+    int ch_src[NPRE], ch_dst[NPRE], ch_kind[NPRE];              // float offset in the item's rows, byte offset in a plane, 0 / 1 / 2 = first / inner / last chunk of a row
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int c = tid + q * NTHR, y = c / CPR, j = c - y * CPR;
+        ch_kind[q] = c >= n_chunks ? -1 : j == 0 ? 0 : j == CPR - 1 ? 2 : 1;
+        ch_src[q] = y * W + (j == 0 ? 0 : j == CPR - 1 ? W - 4 : 4 * j - 1);
+        ch_dst[q] = ((y + row_shift) * Wp0 + 4 * j) * 2;
+    }
+    auto store_chunk = [&](unsigned char* planes, int q, float4 v) {
+        if (ch_kind[q] == 0) v = make_float4(0.0f, v.x, v.y, v.z);             // column 0 is the halo
+        else if (ch_kind[q] == 2) v = make_float4(v.w, 0.0f, 0.0f, 0.0f);     // input W - 1, then the halo
+        unsigned char* d = planes + ch_dst[q];
         if (F16) {
-            uint32_t hA, lA, hB, lB;                        // (v1, v2) share a dword; v0 and v3 are its neighbours' halves
-            split2h(v.y * s_in, v.z * s_in, hA, lA);
-            split2h(v.x * s_in, v.w * s_in, hB, lB);
-            *reinterpret_cast<uint16_t*>(d) = (uint16_t)hB;
-            *reinterpret_cast<uint32_t*>(d + 2) = hA;
-            *reinterpret_cast<uint16_t*>(d + 6) = (uint16_t)(hB >> 16);
-            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)lB;
-            *reinterpret_cast<uint32_t*>(d + plane_b + 2) = lA;
-            *reinterpret_cast<uint16_t*>(d + plane_b + 6) = (uint16_t)(lB >> 16);
+            uint32_t h0, l0, h1, l1;
+            split2h(__builtin_amdgcn_fmed3f(v.x * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.y * s_in, -c_in, c_in), h0, l0);
+            split2h(__builtin_amdgcn_fmed3f(v.z * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.w * s_in, -c_in, c_in), h1, l1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + plane_b) = make_uint2(l0, l1);
         } else {
             uint32_t w[3][4];
             split3(v.x, w[0][0], w[1][0], w[2][0]); split3(v.y, w[0][1], w[1][1], w[2][1]);
             split3(v.z, w[0][2], w[1][2], w[2][2]); split3(v.w, w[0][3], w[1][3], w[2][3]);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                unsigned char* p = d + t * plane_b;
-                *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
-                *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
-                *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
-            }
+            for (int t = 0; t < 3; ++t)
+                *reinterpret_cast<uint2*>(d + t * plane_b) = make_uint2(pack_hi16(w[t][0], w[t][1]), pack_hi16(w[t][2], w[t][3]));
         }
     };
     auto load_plane_sync = [&](unsigned char* planes, const float* xin) {
@@ -463,7 +525,7 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
             unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
             if (F16) {
                 uint32_t h, l;
-                split2h(xin[idx] * s_in, 0.0f, h, l);
+                split2h(__builtin_amdgcn_fmed3f(xin[idx] * s_in, -c_in, c_in), 0.0f, h, l);
                 *reinterpret_cast<uint16_t*>(d) = (uint16_t)h;
                 *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)l;
             } else {
@@ -475,8 +537,6 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
             }
         }
     };
-    constexpr int NPRE = 2;                                     // float4 registers per thread for the rows of the next item
-    const bool vec_in = (W & 3) == 0 && (in_clip & 3) == 0 && n_in <= 4 * NPRE * NTHR;
 
     [[maybe_unused]] int item_no = -1;                          // trace builds only
     // conv1 groups: 32 consecutive pooled pixels of one A1 row; group g = (row g / ngx, block g % ngx)
@@ -565,20 +625,54 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         auto tile_nv = [&](int Xx) { return (W2 & 3) == 0 ? (8 * Xx + 4 * hi + 3 < W2 ? 4 : 0) : max(0, min(4, W2 - (8 * Xx + 4 * hi))); };
         auto tile_pa = [&](int Rr, int Xx) { return a1buf + a1_lane + (2 * Rr) * rowB + (16 * Xx) * PS; };
         auto step = [&](int& Rr, int& Xx) { Xx += 4; while (Xx >= nX) { Xx -= nX; ++Rr; } };
-        for (int n = 0; n < cnt; ++n) {
-            conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
-            if (n < 4) TB_STAMP(2 + n);
-            step(R, X);
+        if constexpr (F16) {
+            bf16x8 ring[3][2];
+            const unsigned char* pa = tile_pa(R, X);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ring[t][0] = *reinterpret_cast<const bf16x8*>(pa + t * PS);
+                ring[t][1] = *reinterpret_cast<const bf16x8*>(pa + t * PS + 32);
+            }
+            for (int n = 0; n < cnt; ++n) {
+                int Rn = R, Xn = X;
+                step(Rn, Xn);
+                const unsigned char* pa_next = n + 1 < cnt ? tile_pa(Rn, Xn) : nullptr;
+                conv2_tile_h2<ACT, BN>(pa, pa_next, rowB, bw, ring, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
+                if (n < 4) TB_STAMP(2 + n);
+                R = Rn; X = Xn; pa = pa_next;
+            }
+        } else {
+            for (int n = 0; n < cnt; ++n) {
+                conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
+                if (n < 4) TB_STAMP(2 + n);
+                step(R, X);
+            }
         }
     };
 
+    // rows of item bb -> registers (a float4 or two per thread)
+    float4 pre[NPRE];
+    auto fetch_rows = [&](int bb) {
+        if (TB_ABL & 64) return;
+        const float* xin = a.in + (size_t)bb * in_clip + in_off;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+            if (ch_kind[q] >= 0) {
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(xin + ch_src[q]);
+                pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    };
     __syncthreads();
     if (b0 < a.B) load_plane_sync(In3, a.in + (size_t)b0 * in_clip + in_off);
+    if (vec_in && b0 + bstep < a.B) fetch_rows(b0 + bstep);
     __syncthreads();
-    // ---- two phases per item, all eight waves in each: conv1 -> A1 | conv2 (the next item's rows in flight) -> planes
+    // ---- two phases per item, all eight waves in each: conv1 (planes -> A1) | the next item's rows -> planes, conv2.
+    // The rows are requested a whole item ahead and stored right behind the barrier that frees the planes: stored behind conv2
+    // instead, their s_waitcnt vmcnt(0) also covered conv2's last output stores (gfx9 counts loads and stores in one counter) -
+    // 1.5-3 k clocks per item with every wave parked (tools/ubench/trunk_trace.hip).
     TB_STAMP_WG(1);
     for (int b = b0; b < a.B; b += bstep) {
-        const int b1 = b + bstep;
+        const int b1 = b + bstep, b2 = b1 + bstep;
         const bool has1 = b1 < a.B;
         ++item_no;
         TB_STAMP(0);
@@ -589,33 +683,27 @@ __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) {
         float* outb = ring ? a.out + (size_t)b * a.out_clip_stride
                     : blk_kt ? a.out + ((size_t)(b >> 7) * blk_kt * 128 + (b & 127)) * 32
                              : a.out + (size_t)b * C2 * H2 * W2 + out_off;
-        float4 pre[NPRE];
-        if (has1 && vec_in && !(TB_ABL & 64)) {
-            const float4* xin4 = reinterpret_cast<const float4*>(a.in + (size_t)b1 * in_clip + in_off);
-#pragma unroll
-            for (int q = 0; q < NPRE; ++q) {
-                const int idx4 = tid + q * NTHR;
-                if (idx4 < n_in / 4) pre[q] = xin4[idx4];
-            }
-        }
-        if (wave < 4) conv2_tiles(A1, outb, simd + 4 * tB, tA);
-        else conv2_tiles(A1, outb, simd, tB);
         if (has1 && !(TB_ABL & (32 | 64))) {
             if (vec_in) {
 #pragma unroll
-                for (int q = 0; q < NPRE; ++q) {
-                    const int idx4 = tid + q * NTHR;
-                    if (idx4 < n_in / 4) store4(In3, idx4 * 4, pre[q]);
-                }
+                for (int q = 0; q < NPRE; ++q)
+                    if (ch_kind[q] >= 0) store_chunk(In3, q, pre[q]);
             } else {
                 load_plane_sync(In3, a.in + (size_t)b1 * in_clip + in_off);
             }
         }
+        if (vec_in && b2 < a.B) fetch_rows(b2);
+        if (wave < 4) conv2_tiles(A1, outb, simd + 4 * tB, tA);
+        else conv2_tiles(A1, outb, simd, tB);
         __syncthreads();
         TB_STAMP(7);
     }
     TB_STAMP_WG(2);
 }
+template <int ACT, int PRODUCTS, bool BN>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, PRODUCTS, BN>(a); }
+template <int ACT, bool BN>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_h2_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, 3, BN>(a); }
 
 
 // ---------------------------------------------------------------------------------------------- BcResNet front
@@ -900,7 +988,7 @@ int trunk_b_pick_strips(int H, int W) {
         int key_ = ((aa).act == ACT_RELU ? 0 : (aa).act == ACT_GELU ? 1 : (aa).act == ACT_SILU ? 2 : 3) * 4 + (products == 6 ? 0 : 2) + (bn_ ? 1 : 0); \
         if (products == 3) key_ = (aa).act == ACT_RELU ? (bn_ ? 13 : 12) : (aa).act == ACT_GELU ? 14 : (aa).act == ACT_SILU ? 15 : 99; \
         switch (key_) {                                                                                                \
-            TB_CASE(12, ACT_RELU, 3, false) TB_CASE(13, ACT_RELU, 3, true) TB_CASE(14, ACT_GELU, 3, true) TB_CASE(15, ACT_SILU, 3, true) \
+            TB_CASE_H2(12, ACT_RELU, false) TB_CASE_H2(13, ACT_RELU, true) TB_CASE_H2(14, ACT_GELU, true) TB_CASE_H2(15, ACT_SILU, true) \
             TB_CASE(0, ACT_RELU, 6, false) TB_CASE(1, ACT_RELU, 6, true) TB_CASE(2, ACT_RELU, 9, false) TB_CASE(3, ACT_RELU, 9, true)   \
             TB_CASE(4, ACT_GELU, 6, false) TB_CASE(5, ACT_GELU, 6, true) TB_CASE(6, ACT_GELU, 9, false) TB_CASE(7, ACT_GELU, 9, true)   \
             TB_CASE(8, ACT_SILU, 6, false) TB_CASE(9, ACT_SILU, 6, true) TB_CASE(10, ACT_SILU, 9, false) TB_CASE(11, ACT_SILU, 9, true) \
@@ -908,6 +996,11 @@ int trunk_b_pick_strips(int H, int W) {
         }                                                                                                              \
         if (e_ != hipSuccess) return e_;                                                                               \
     }
+#define TB_CASE_H2(K, ACTV, BNV)                                                                                       \
+    case K:                                                                                                            \
+        e_ = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_h2_kernel<ACTV, BNV>), lds);                        \
+        if (e_ == hipSuccess) hipLaunchKernelGGL((cnn_trunk_h2_kernel<ACTV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa); \
+        break;
 #define TB_CASE(K, ACTV, PRODV, BNV)                                                                                   \
     case K:                                                                                                            \
         e_ = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_b_kernel<ACTV, PRODV, BNV>), lds);                  \

@@ -1,7 +1,7 @@
 // Phase timeline of the fused trunk (trunk_b.hip compiled with -DNWW_TRACE): s_memtime stamps per wave at the phase
 // boundaries of the first items of the first workgroups, plus plain launch timing of the shapes.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DNWW_TRACE -I nanowakeword_amd/csrc -I include tools/ubench/trunk_trace.hip -o tools/ubench/trunk_trace
-// run:   tools/ubench/trunk_trace [B=4096]      (NWW_TRUNK_STRIPS / NWW_TB_KAPPA as in the library)
+// run:   tools/ubench/trunk_trace [B=4096] [grid=256] [products=6]      (NWW_TRUNK_STRIPS as in the library)
 #include "../../nanowakeword_amd/csrc/trunk_b.hip"
 #include <stdio.h>
 #include <vector>
@@ -9,6 +9,7 @@
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4096, H = 101, W = 64, G = argc > 2 ? atoi(argv[2]) : 256;
     const int NWv = 8;
+    const int P = argc > 3 ? atoi(argv[3]) : 6;                  // products: 6 / 9 (bf16 terms) or 3 (two binary16 terms)
     std::vector<float> x((size_t)B * H * W), w1(16 * 9), b1(16), w2(32 * 16 * 9), b2(32);
     uint32_t st = 12345;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -27,18 +28,23 @@ int main(int argc, char** argv) {
     TrunkArgs a{dx, dw1, db1, nullptr, nullptr, dw2, db2, nullptr, nullptr, dout, B, H, W, ACT_RELU};
     hipStream_t s; hipStreamCreate(&s);
     unsigned char* dpack; hipMalloc(&dpack, trunk_b_packed_bytes());
-    launch_trunk_b_pack(dw1, dw2, dpack, s);
+    if (P == 3) {
+        launch_trunk_b_pack_f16(dw1, dw2, dpack, 32768.0f, 65536.0f, s);
+        a.f16_in = 64.0f; a.f16_k1 = 64.0f * 32768.0f; a.f16_s1 = 256.0f; a.f16_k2 = 256.0f * 65536.0f; a.f16_so = 1.0f;
+    } else {
+        launch_trunk_b_pack(dw1, dw2, dpack, s);
+    }
     a.wpack = dpack;
-    for (int i = 0; i < 20; ++i) launch_cnn_trunk_b(a, 6, G, s);
+    for (int i = 0; i < 20; ++i) launch_cnn_trunk_b(a, P, G, s);
     hipStreamSynchronize(s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, s);
-    for (int i = 0; i < 50; ++i) launch_cnn_trunk_b(a, 6, G, s);
+    for (int i = 0; i < 50; ++i) launch_cnn_trunk_b(a, P, G, s);
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("trunk_b B=%d grid<=%d: %.4f ms per launch\n", B, G, ms / 50);
     a.trace = dtr;
-    launch_cnn_trunk_b(a, 6, G, s);
+    launch_cnn_trunk_b(a, P, G, s);
     hipStreamSynchronize(s);
     std::vector<unsigned long long> tr(ntr);
     hipMemcpy(tr.data(), dtr, ntr * 8, hipMemcpyDeviceToHost);

@@ -50,6 +50,7 @@ def test_config_struct_mirrors_header():
         assert int(re.search(rf"#define {code} (\d+)", hdr).group(1)) == _lib.ARITH_CODE[key]
     cfg = _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="bf16x9")
     assert cfg.conv_arith == 9 and _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig()).conv_arith == 0
+    assert _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="f16x3").conv_arith == 3
     with pytest.raises(ValueError):
         _lib.make_config(HeadConfig("cnn", (101, 64)), FrontendConfig(), conv_arith="fp8")
 

@@ -285,9 +285,9 @@ def test_cnn_trunk_row_strips_for_large_inputs(hip, shape):
 
 
 def test_conv_arithmetic_modes_agree(hip, golden_frontend):
-    """conv2 of the fused trunk on the float32 MFMA, or on the bf16 MFMA from exactly split operands with nine (exact
-    products) or six partial products: all three are float32-grade - each sits as close to the oracle as the others,
-    and every mode is deterministic and batch invariant."""
+    """The fused trunk and fc1 on the float32 MFMA, on the bf16 MFMA from exactly split operands with nine (exact products) or
+    six partial products, or on the f16 MFMA from two binary16 terms per operand (three partial products, the default): all
+    four are float32-grade - each sits as close to the oracle as the others, and every mode is deterministic and batch invariant."""
     HipModel, _ = hip
     g = golden_frontend
     cfg = HeadConfig("cnn", (101, 64))
@@ -295,9 +295,10 @@ def test_conv_arithmetic_modes_agree(hip, golden_frontend):
     feats = synth_features(40, cfg.input_shape, seed=77)
     ref = oracle.model_forward(feats, sd, cfg).ravel()
     out = {}
-    for mode in ("f32", "bf16x9", "bf16x6"):
+    for mode in ("f32", "bf16x9", "bf16x6", "f16x3", None):
         m = HipModel(cfg, _fe_cfg(64, True), state_dict=sd, window=g["window"], mel_fb=g["fb64"], conv_arith=mode)
         assert ("trunk_x3:" in m.describe_plan()) == (mode != "f32")
+        assert ("[f16x3]" in m.describe_plan()) == (mode in ("f16x3", None))      # the library default is f16x3
         lg, _ = m.forward_features(feats)
         lg2, _ = m.forward_features(feats[::-1].copy())
         assert np.array_equal(lg, lg2[::-1]), mode                     # batch position does not matter, bit for bit
@@ -310,12 +311,13 @@ def test_conv_arithmetic_modes_agree(hip, golden_frontend):
     assert max(err.values()) <= 2e-5                                   # 5x tighter than the 1e-4 parity bar
     assert max(err.values()) <= 3 * min(err.values()) + 2e-6           # no mode is meaningfully worse than another
     assert np.abs(out["bf16x6"] - out["f32"]).max() <= 2e-5 and np.abs(out["bf16x9"] - out["f32"]).max() <= 2e-5
+    assert np.abs(out["f16x3"] - out["f32"]).max() <= 2e-5 and np.array_equal(out["f16x3"], out[None])
     with pytest.raises(ValueError):
         HipModel(cfg, _fe_cfg(64, True), conv_arith="fp8")
 
 
 @pytest.mark.parametrize("shape", [(37, 28), (64, 64), (100, 100), (17, 130), (12, 12), (41, 18), (256, 32)])
-@pytest.mark.parametrize("arith", ["bf16x6", "f32"])
+@pytest.mark.parametrize("arith", ["f16x3", "bf16x6", "f32"])
 def test_cnn_trunk_odd_shapes(hip, shape, arith):
     """Edge geometry of the fused trunk: odd sizes (floor pooling drops a row/column), widths that leave partial
     MFMA tiles, strips of unequal height, tiny and tall inputs - in both arithmetics."""
@@ -328,6 +330,51 @@ def test_cnn_trunk_odd_shapes(hip, shape, arith):
     e_or = oracle.head_forward(feats, sd, cfg)
     assert np.abs(emb - e_or).max() <= FEAT_EMB_RTOL * max(1.0, np.abs(e_or).max()), (shape, arith)
     assert np.abs(logits - oracle.model_forward(feats, sd, cfg).ravel()).max() <= FEAT_LOGIT_ATOL
+    m.close()
+
+
+def test_f16x3_scales_clamp_and_activations(hip):
+    """The two-term binary16 arithmetic (nww_config.conv_arith = NWW_ARITH_F16X3, the default): power-of-two scales fixed at plan
+    time from bounds on the tensors.  (i) every activation / BatchNorm form of the fused trunk (CNN: bias only; CRNN / E2E: folded
+    BN) against the oracle; (ii) weights scaled by 2^-12 .. 2^12 (the bounds, hence the scales, move with them) change nothing
+    beyond float32 rounding; (iii) features far outside the log-mel range stay finite - inputs are clamped to +-8192, the bound
+    the scales were derived from - and features inside it are not touched by the clamp."""
+    HipModel, _ = hip
+    for head, shape, kw in (("cnn", (101, 64), {}), ("cnn", (40, 36), {"activation": "gelu"}), ("cnn", (44, 40), {"activation": "silu"}),
+                            ("crnn", (101, 64), {}), ("crnn", (48, 40), {"activation": "gelu"}), ("e2e_dnn", (64, 101), {}),
+                            ("e2e_dnn", (40, 61), {"activation": "silu"}), ("dnn", (98, 40), {}), ("dnn", (16, 96), {})):
+        cfg = HeadConfig(head, shape, **kw)
+        sd = synth_state_dict(cfg)
+        feats = synth_features(9, cfg.input_shape, seed=5)
+        m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith="f16x3")
+        assert "[f16x3]" in m.describe_plan(), m.describe_plan()
+        lg, _ = m.forward_features(feats)
+        ref = oracle.model_forward(feats, sd, cfg).ravel()
+        assert np.abs(lg - ref).max() <= FEAT_LOGIT_ATOL, (head, shape, kw, float(np.abs(lg - ref).max()))
+        m.close()
+    cfg = HeadConfig("cnn", (101, 64))
+    base = synth_state_dict(cfg)
+    feats = synth_features(6, cfg.input_shape, seed=9)
+    for e1, e2, e3 in ((-12, 0, 12), (12, -12, 0), (0, 12, -12), (6, 6, -12)):
+        sd = {k: v.copy() for k, v in base.items()}
+        for name, e in (("model.conv1", e1), ("model.conv2", e2), ("model.fc1", e3)):       # total scale 2^(e1 + e2 + e3) = 1 on the logits
+            sd[name + ".weight"] = (sd[name + ".weight"] * np.float32(2.0 ** e)).astype(np.float32)
+        sd["model.conv1.bias"] = (base["model.conv1.bias"] * np.float32(2.0 ** e1)).astype(np.float32)
+        sd["model.conv2.bias"] = (base["model.conv2.bias"] * np.float32(2.0 ** (e1 + e2))).astype(np.float32)
+        sd["model.fc1.bias"] = (base["model.fc1.bias"] * np.float32(2.0 ** (e1 + e2 + e3))).astype(np.float32)
+        m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith="f16x3")
+        lg, _ = m.forward_features(feats)
+        ref = oracle.model_forward(feats, sd, cfg).ravel()
+        assert np.abs(lg - ref).max() <= FEAT_LOGIT_ATOL, ((e1, e2, e3), float(np.abs(lg - ref).max()))
+        m.close()
+    m = HipModel(cfg, FrontendConfig(), state_dict=base, conv_arith="f16x3")
+    wild = feats.copy()
+    wild[0] *= 1e6; wild[1, 3, 5] = 3e38; wild[2, :, 0] = -1e9
+    lg, _ = m.forward_features(wild)
+    assert np.isfinite(lg).all()
+    ref = oracle.model_forward(np.clip(wild, -8192.0, 8192.0), base, cfg).ravel()
+    assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), float(np.abs(lg - ref).max())
+    assert np.array_equal(lg[3:], m.forward_features(feats)[0][3:])                                   # untouched clips: bit-identical
     m.close()
 
 

@@ -125,7 +125,9 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_CONV_MFMA": "0"}, [_CRNN, _CRNN4, _E2E, _BC], [], ["conv3x3_mfma", "conv1_mfma"], False),   # VALU 3x3 convs
     ({"NWW_GRU16": "0"}, [_CRNN, _GRU, _CRNN_LSTM], [], [], False),                     # streaming recurrent kernels
     ({"TEST_CONV_ARITH": "f32"}, [_CNN, _E2E], ["trunk:"], ["trunk_x3"], False),        # float32-MFMA fused trunk (nww_config.conv_arith)
-    ({"TEST_CONV_ARITH": "bf16x9"}, [_CNN, _E2E, _CRNN], ["trunk_x3"], [], False),      # all nine partial products
+    ({"TEST_CONV_ARITH": "bf16x9"}, [_CNN, _E2E, _CRNN], ["trunk_x3"], ["[f16x3]"], False),      # all nine partial products
+    ({"TEST_CONV_ARITH": "bf16x6"}, [_CNN, _E2E, _CRNN], ["trunk_x3"], ["[f16x3]"], False),      # three bf16 terms, six partial products (the default of rounds 2-3)
+    ({"TEST_CONV_ARITH": "bf16x6"}, [dict(model_type="dnn", input_shape=(98, 40))], ["gemm:layer1"], ["[f16x3]"], False),   # ... DNN layer1
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
     ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),  # one-lane-per-query attention core

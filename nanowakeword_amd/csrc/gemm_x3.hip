@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "layers.h"
+#include "split_h2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -79,14 +80,6 @@ __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uin
 }
 // (a >> 16) | (b & 0xffff0000): bf16 of a in the low half (element k), of b in the high half (element k+1)
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-// (a, b) -> binary16 pairs hi = RN(v), lo = RN(v - hi)
-__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {a, b};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 r = v - __builtin_convertvector(h, f32x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-}
 // the partial products of one 16-k block, small terms first: six of bf16 terms (a, w = hi / mid / lo) or three of binary16 terms
 template <bool H2>
 __device__ __forceinline__ void x3_products(const uint4* a, const uint4* w, f32x16& acc) {
@@ -138,7 +131,7 @@ __global__ void __launch_bounds__(256) split_weights_h2_kernel(const float* __re
     const int k = kb * 16 + kk;
     const float x = k < K ? W[(size_t)n * K + k] * scale : 0.0f;
     uint32_t hi, lo;
-    split2h(x, 0.0f, hi, lo);
+    nww_split2h(x, 0.0f, hi, lo);
     uint16_t* o = out + nb * 32 + kk;
     o[0] = (uint16_t)hi; o[16] = (uint16_t)lo;
 }
@@ -217,8 +210,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gem
             unsigned char* d = As(buf) + (lr + 32 * q) * X3_ROW + 8 * lq;
             if (H2) {
                 uint32_t h0, l0, h1, l1;
-                split2h(__builtin_amdgcn_fmed3f(st.a[q][0] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][1] * a_scale, -a_lim, a_lim), h0, l0);
-                split2h(__builtin_amdgcn_fmed3f(st.a[q][2] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][3] * a_scale, -a_lim, a_lim), h1, l1);
+                nww_split2h(__builtin_amdgcn_fmed3f(st.a[q][0] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][1] * a_scale, -a_lim, a_lim), h0, l0);
+                nww_split2h(__builtin_amdgcn_fmed3f(st.a[q][2] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(st.a[q][3] * a_scale, -a_lim, a_lim), h1, l1);
                 *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(d + 64) = make_uint2(l0, l1);
             } else {
@@ -441,7 +434,7 @@ __global__ void __launch_bounds__(64 * CH_NW) gemm_x3_chain_kernel(GemmArgs g) {
                             uint32_t hh[4], ll[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                split2h(__builtin_amdgcn_fmed3f(x[2 * j] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(x[2 * j + 1] * a_scale, -a_lim, a_lim), hh[j], ll[j]);
+                                nww_split2h(__builtin_amdgcn_fmed3f(x[2 * j] * a_scale, -a_lim, a_lim), __builtin_amdgcn_fmed3f(x[2 * j + 1] * a_scale, -a_lim, a_lim), hh[j], ll[j]);
                             af[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
                             af[1] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
                         } else {

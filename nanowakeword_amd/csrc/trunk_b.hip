@@ -36,6 +36,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "layers.h"
+#include "split_h2.h"
 #include "trunk.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -105,14 +106,6 @@ __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uin
 }
 // (a >> 16) | (b & 0xffff0000): bf16 of a in the low half, of b in the high half
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-// (a, b) -> binary16 pairs hi = RN(v), lo = RN(v - hi) (v_cvt_pk_f16_f32, two v_cvt_f32_f16, two subtractions, v_cvt_pk_f16_f32)
-__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {a, b};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 r = v - __builtin_convertvector(h, f32x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-}
 __device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const u32x4 v = {a, b, c, d};
     return __builtin_bit_cast(bf16x8, v);
@@ -162,7 +155,8 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
     if (ACT == ACT_RELU && !BN) {
         float t, u;
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(t), "v"(v3), "v"(nbias));
+        asm("v_max3_f32 %0, %1, %2, -%3" : "=v"(u) : "v"(t), "v"(v3), "v"(bias));      // (-bias as a source modifier: no register, no v_xor for it)
+        (void)nbias;
         return SC ? (u + bias) * post : u + bias;
     }
     if (ACT == ACT_RELU && BN) {
@@ -292,6 +286,60 @@ __device__ __forceinline__ void conv2_tile_h2(const unsigned char* pa, const uns
     }
 }
 
+// Two tiles of one wave in flight: a wave with one accumulator chain leaves the matrix pipe to its partner (or idle) through its own
+// epilogue and prologue - a lone wave takes 2.0 k clocks per tile for 864 clocks of MFMAs, and the SIMD's two waves own 3 + 4 tiles.
+// Per tap the fragments of both tiles are fetched one tap ahead (six MFMAs cover the LDS round trip) and share the weight fragments.
+template <int ACT, bool BN>
+__device__ __forceinline__ void conv2_pair_h2(const unsigned char* pa0, const unsigned char* pa1, int rowB, const bf16x8 (&bw)[18],
+                                              float bias2, float nbias2, float al2, float be2, float post2,
+                                              float* dst0, int nv0, float* dst1, int nv1) {
+    constexpr int PS = TbA<3>::PS;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    bf16x8 n0[2], n1[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        n0[tm] = *reinterpret_cast<const bf16x8*>(pa0 + 32 * tm);
+        n1[tm] = *reinterpret_cast<const bf16x8*>(pa1 + 32 * tm);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 c0[2] = {n0[0], n0[1]}, c1[2] = {n1[0], n1[1]};
+        if (tap + 1 < 9) {
+            const int off = ((tap + 1) / 3) * rowB + ((tap + 1) % 3) * PS;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                n0[tm] = *reinterpret_cast<const bf16x8*>(pa0 + off + 32 * tm);
+                n1[tm] = *reinterpret_cast<const bf16x8*>(pa1 + off + 32 * tm);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        x3_mfma<3>(c0, &bw[2 * tap], acc0);
+        x3_mfma<3>(c1, &bw[2 * tap], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto finish = [&](const f32x16& acc, float* dst, int nv) {
+        float own[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            own[k] = pool_quad<ACT, BN, true>(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3], bias2, nbias2, al2, be2, post2);
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[1]), __float_as_uint(own[3]), false, false);
+        float4 o;
+        o.x = __uint_as_float(s02[0]); o.y = __uint_as_float(s02[1]); o.z = __uint_as_float(s13[0]); o.w = __uint_as_float(s13[1]);
+        if (nv >= 4) {
+            *reinterpret_cast<float4*>(dst) = o;
+        } else {
+            if (nv > 0) dst[0] = o.x;
+            if (nv > 1) dst[1] = o.y;
+            if (nv > 2) dst[2] = o.z;
+        }
+    };
+    finish(acc0, dst0, nv0);
+    finish(acc1, dst1, nv1);
+}
+
 // LDS map (bytes): [3 input planes: in_rows x Wp0 bf16 each][A1: a1_rows x (Wp1 x 96 + 16) (+64 slack)][conv1
 // weight fragments 6 KB][conv2 last-tap fragments 3 KB].  A workgroup keeps ONE strip index for its whole life, so the
 // zero halos written once stay valid.  The 16 bytes of padding per A1 row put the two pixel rows of a
@@ -357,7 +405,7 @@ __global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __res
     for (int tap = 0; tap < 9; ++tap) {
         uint32_t th[4], tl[4];
         for (int j = 0; j < 4; ++j)
-            split2h(w2[((size_t)i * C1 + 8 * hi + 2 * j) * 9 + tap] * sw2, w2[((size_t)i * C1 + 8 * hi + 2 * j + 1) * 9 + tap] * sw2, th[j], tl[j]);
+            nww_split2h(w2[((size_t)i * C1 + 8 * hi + 2 * j) * 9 + tap] * sw2, w2[((size_t)i * C1 + 8 * hi + 2 * j + 1) * 9 + tap] * sw2, th[j], tl[j]);
         o[(2 * tap + 0) * 64 + lane] = frag4(th[0], th[1], th[2], th[3]);
         o[(2 * tap + 1) * 64 + lane] = frag4(tl[0], tl[1], tl[2], tl[3]);
     }
@@ -370,12 +418,17 @@ __global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __res
             v[kk] = in ? w1[cw * 9 + ty * 3 + tx] * sw1 : 0.0f;
         }
         uint32_t th[4], tl[4];
-        for (int j = 0; j < 4; ++j) split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
+        for (int j = 0; j < 4; ++j) nww_split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
         o[(18 + dy * 2 + 0) * 64 + lane] = frag4(th[0], th[1], th[2], th[3]);
         o[(18 + dy * 2 + 1) * 64 + lane] = frag4(tl[0], tl[1], tl[2], tl[3]);
     }
 }
 
+// Measured and not kept for the two-term form (round 4): conv2 of item k on waves 0-3 - one per SIMD, two tiles in flight - BESIDE
+// conv1 of item k + 1 on waves 4-7, planes and A1 double-buffered in three strips, one barrier per item.  conv1's phase is VALU-bound
+// (pooling, splitting: ~110 instructions per 6 MFMAs), conv2's MFMA-bound, and one after the other the matrix pipe is busy 45 % of
+// an item - but beside a wave that issues MFMAs back to back the VALU wave ran 2.4 k clocks per group instead of 1.2 k and set the
+// pace: 12.5 k clocks per third of a clip against 2 x 16.3 k per clip here (0.247 ms against 0.233; tools/ubench/trunk_trace.hip).
 template <int ACT, int PRODUCTS, bool BN>
 __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
     using AR = TbA<PRODUCTS>;
@@ -506,8 +559,8 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
         unsigned char* d = planes + ch_dst[q];
         if (F16) {
             uint32_t h0, l0, h1, l1;
-            split2h(__builtin_amdgcn_fmed3f(v.x * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.y * s_in, -c_in, c_in), h0, l0);
-            split2h(__builtin_amdgcn_fmed3f(v.z * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.w * s_in, -c_in, c_in), h1, l1);
+            nww_split2h(__builtin_amdgcn_fmed3f(v.x * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.y * s_in, -c_in, c_in), h0, l0);
+            nww_split2h(__builtin_amdgcn_fmed3f(v.z * s_in, -c_in, c_in), __builtin_amdgcn_fmed3f(v.w * s_in, -c_in, c_in), h1, l1);
             *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(d + plane_b) = make_uint2(l0, l1);
         } else {
@@ -525,7 +578,7 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
             unsigned char* d = planes + ((y + row_shift) * Wp0 + x + 1) * 2;
             if (F16) {
                 uint32_t h, l;
-                split2h(__builtin_amdgcn_fmed3f(xin[idx] * s_in, -c_in, c_in), 0.0f, h, l);
+                nww_split2h(__builtin_amdgcn_fmed3f(xin[idx] * s_in, -c_in, c_in), 0.0f, h, l);
                 *reinterpret_cast<uint16_t*>(d) = (uint16_t)h;
                 *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)l;
             } else {
@@ -590,7 +643,7 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
                                                     b1v[cc], nb1v[cc], al1v[cc], be1v[cc], post1);
                 }
                 if (F16) {
-                    split2h(m2[0], m2[1], ph[c2], pm[c2]);
+                    nww_split2h(m2[0], m2[1], ph[c2], pm[c2]);
                 } else {
                     uint32_t th[2], tm[2], tl[2];
                     split3(m2[0], th[0], tm[0], tl[0]);
@@ -626,20 +679,26 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
         auto tile_pa = [&](int Rr, int Xx) { return a1buf + a1_lane + (2 * Rr) * rowB + (16 * Xx) * PS; };
         auto step = [&](int& Rr, int& Xx) { Xx += 4; while (Xx >= nX) { Xx -= nX; ++Rr; } };
         if constexpr (F16) {
-            bf16x8 ring[3][2];
-            const unsigned char* pa = tile_pa(R, X);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                ring[t][0] = *reinterpret_cast<const bf16x8*>(pa + t * PS);
-                ring[t][1] = *reinterpret_cast<const bf16x8*>(pa + t * PS + 32);
+            // tiles in pairs (two accumulator chains per wave, conv2_pair_h2; -3.6 % of the launch), an odd last one by itself
+            int n = 0;
+            for (; n + 1 < cnt; n += 2) {
+                int R1 = R, X1 = X;
+                step(R1, X1);
+                conv2_pair_h2<ACT, BN>(tile_pa(R, X), tile_pa(R1, X1), rowB, bw, bias2, -bias2, al2, be2, post2,
+                                       tile_dst(R, X), tile_nv(X), tile_dst(R1, X1), tile_nv(X1));
+                if (n < 4) TB_STAMP(2 + n / 2);
+                R = R1; X = X1;
+                step(R, X);
             }
-            for (int n = 0; n < cnt; ++n) {
-                int Rn = R, Xn = X;
-                step(Rn, Xn);
-                const unsigned char* pa_next = n + 1 < cnt ? tile_pa(Rn, Xn) : nullptr;
-                conv2_tile_h2<ACT, BN>(pa, pa_next, rowB, bw, ring, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
-                if (n < 4) TB_STAMP(2 + n);
-                R = Rn; X = Xn; pa = pa_next;
+            if (n < cnt) {
+                bf16x8 ring[3][2];
+                const unsigned char* pa = tile_pa(R, X);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    ring[t][0] = *reinterpret_cast<const bf16x8*>(pa + t * PS);
+                    ring[t][1] = *reinterpret_cast<const bf16x8*>(pa + t * PS + 32);
+                }
+                conv2_tile_h2<ACT, BN>(pa, nullptr, rowB, bw, ring, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
             }
         } else {
             for (int n = 0; n < cnt; ++n) {
@@ -704,6 +763,7 @@ template <int ACT, int PRODUCTS, bool BN>
 __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, PRODUCTS, BN>(a); }
 template <int ACT, bool BN>
 __global__ void __launch_bounds__(512, 2) cnn_trunk_h2_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, 3, BN>(a); }
+
 
 
 // ---------------------------------------------------------------------------------------------- BcResNet front

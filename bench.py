@@ -48,8 +48,8 @@ def parse():
                          "to reach its sustained clocks (20 cold steps run 10 %% slower than the same steps a second later)")
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
     ap.add_argument("--head", default="cnn")
-    ap.add_argument("--conv-arith", default="bf16x6", choices=["f32", "bf16x9", "bf16x6", "f16x3"],
-                    help="arithmetic of the fused conv trunk's conv2 (all float32-grade; nww_config.conv_arith)")
+    ap.add_argument("--conv-arith", default="f16x3", choices=["f32", "bf16x9", "bf16x6", "f16x3"],
+                    help="arithmetic of the MFMA contractions (all float32-grade; nww_config.conv_arith; the library default is f16x3)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP events around the launches of every n-th timed step (an event per launch boundary costs the "
                          "stream ~10 us: n = 1 slows the timed loop by ~10 %%)")
@@ -229,7 +229,8 @@ def config_legs(torch, dev):
 
 def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logits):
     """Self-audit legs of the N = 1 line (never part of `value`):
-      arith      the same step with conv2 on the plain f32 MFMA and with all nine bf16 partial products
+      arith      the same step in the other arithmetics: plain f32 MFMA, three bf16 terms with nine (exact products) or six
+                 partial products, two binary16 terms with three
       h2d_inclusive  PCM starting in pinned host memory: double-buffered uploads on a copy stream overlapped with the
                  previous batch's kernels, logits copied back to the host (the PCIe-inclusive rate; Gen5 x16 ceiling
                  = 63 GB/s / 32 kB per clip = 1.97 M clips/s)"""
@@ -239,10 +240,22 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     pcm = torch.from_numpy(pcm_host).to(dev)
     logits = torch.empty(B, dtype=torch.float32, device=dev)
     arith = {}
-    for mode in ("f32", "bf16x9"):
-        if mode == a.conv_arith:
-            continue
+    # every arithmetic against the SAME network evaluated in float64 by the oracle (checker only) on the device's own log-mel of the
+    # first 32 clips: the arithmetics are float32-grade when they sit as close to exact arithmetic as the float32 MFMA does
+    import oracle
+    n_acc = 32
+    acc_feats = acc_ref = None
+    acc = {}
+    for mode in ("f32", "bf16x9", "bf16x6", "f16x3"):
         m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=mode)
+        if acc_feats is None:
+            acc_feats = np.ascontiguousarray(m.frontend(pcm_host[:n_acc]).transpose(0, 2, 1))
+            acc_ref = oracle.model_forward(acc_feats, sd, cfg, dtype=np.float64).ravel()
+        lg_acc, _ = m.forward_features(acc_feats)
+        acc[mode] = float(np.abs(lg_acc.astype(np.float64) - acc_ref).max())
+        if mode == a.conv_arith:
+            m.close()
+            continue
         m.reserve(B, N)
         for _ in range(3):
             m.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
@@ -256,6 +269,8 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
                        "max_abs_dlogit_vs_headline_arith": float(np.abs(logits.cpu().numpy() - ref_logits).max())}
         m.close()
     out["arith"] = arith
+    out["arith_accuracy"] = {"clips": n_acc, "max_abs_dlogit_vs_float64": {k: float(f"{v:.3e}") for k, v in acc.items()},
+                             "reference": "the same network in float64 (oracle, checker only) on the device's log-mel features"}
     m = HipModel(cfg, fe, device=dev.index, state_dict=sd, window=window, mel_fb=fb, conv_arith=a.conv_arith)
     m.reserve(B, N)
     # ---- PCIe-inclusive: pinned host PCM -> (copy stream) -> device double buffer -> kernels -> host logits

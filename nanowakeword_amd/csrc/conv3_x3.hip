@@ -26,22 +26,29 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
+// H2 instances ("f16x3", ConvMfmaArgs::h2_in > 0): the planes times h2_in and the weights times h2_w (powers of two fixed at plan
+// time from bounds on the tensors) are split into TWO binary16 terms (split_h2.h), three partial products per operand pair go
+// to v_mfma_f32_32x32x16_f16 and the sums are scaled back before the epilogue: half the MFMAs, 144-byte pixels, 36 KB of weights.
 #include "layers.h"
 #include "trunk.h"
 #include "conv_tile_epilogue.h"
+#include "split_h2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int PS3 = 208;                 // bytes per A3 pixel
-constexpr int WT_BYTES = 9 * 2 * 3 * 1024;
+template <bool H2> struct C3A { static constexpr int NT = H2 ? 2 : 3, PS3 = 64 * NT + 16, WT_BYTES = 9 * 2 * NT * 1024; };
+constexpr int PS3_MAX = 208, WT_BYTES_MAX = 9 * 2 * 3 * 1024;
 // A3 row pitch.  A 16-lane group of a fragment read covers 2 rows x 8 pixels; with 208-byte pixels the 8 pixels of a row take the
 // 16-byte slots {0, 13, 10, 7, 4, 1, 14, 11} of the 256-byte bank row, so the second row must sit 8 slots (128 bytes mod 256) away to
 // take the other eight.  (W + 2) * 208 is 160 mod 256 for the 16-wide planes of the E2E / CRNN heads: both rows on the same slots,
 // 36-44 % of the kernel's LDS cycles were conflict cycles (profiles/r03_pmc_all_configs.csv).  The pitch is padded - or, by up to
 // 32 bytes, SHORTENED: the tail of the right halo pixel then overlaps the head of the next row's left halo pixel, both zero for ever.
 // Planes that would no longer fit the CU's LDS with the padding keep the dense pitch.
-static int conv3_row_pitch(int H, int W, int avg_ow) {
+// (144-byte pixels of the two-term form take the slots {0, 9, 6, 15, 10, 3, 12, 5}: the same rule)
+static int conv3_row_pitch(int H, int W, int avg_ow, bool h2) {
+    const int PS3 = h2 ? C3A<true>::PS3 : C3A<false>::PS3, WT_BYTES = h2 ? C3A<true>::WT_BYTES : C3A<false>::WT_BYTES;
     const int dense = (W + 2) * PS3;
     static const int padded = [] { const char* e = getenv("NWW_CONV3_PITCH"); return e ? atoi(e) : 1; }();      // 0: dense rows (round 3), for A/B runs
     if (!padded) return dense;
@@ -60,9 +67,11 @@ __device__ __forceinline__ void split3c(float x, uint32_t& hi, uint32_t& mid, ui
     lo = __float_as_uint(r - __uint_as_float(mid));
 }
 
-template <int ACT, bool POOL, bool AVG>
+template <int ACT, bool POOL, bool AVG, bool H2>
 __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     constexpr int NW = 8, NTHR = 512, C1 = 32;
+    constexpr int NT = C3A<H2>::NT, PS3 = C3A<H2>::PS3, WT_BYTES = C3A<H2>::WT_BYTES;
+    const float s_in = H2 ? a.h2_in : 1.0f, s_w = H2 ? a.h2_w : 1.0f, c_out = H2 ? 1.0f / (a.h2_in * a.h2_w) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     const int H = a.H, W = a.W, Wp = W + 2;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
@@ -78,13 +87,21 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     for (int k = tid; k < a3_bytes / 4; k += NTHR) reinterpret_cast<uint32_t*>(A3)[k] = 0u;
     for (int idx = tid; idx < 32 * C1 * 9; idx += NTHR) {      // (cout, cin, tap)
         const int co = idx / (C1 * 9), r = idx - co * (C1 * 9), ci = r / 9, tap = r - ci * 9;
-        uint32_t th, tm, tl;
-        split3c(a.w[((size_t)(32 * grp + co) * C1 + ci) * 9 + tap], th, tm, tl);
+        const float wv = a.w[((size_t)(32 * grp + co) * C1 + ci) * 9 + tap];
         const int kb = ci >> 4, kh = (ci >> 3) & 1, e = ci & 7;
-        unsigned char* d = Wt + ((tap * 2 + kb) * 3) * 1024 + (kh * 32 + co) * 16 + e * 2;
-        *reinterpret_cast<uint16_t*>(d) = (uint16_t)(th >> 16);
-        *reinterpret_cast<uint16_t*>(d + 1024) = (uint16_t)(tm >> 16);
-        *reinterpret_cast<uint16_t*>(d + 2048) = (uint16_t)(tl >> 16);
+        unsigned char* d = Wt + ((tap * 2 + kb) * NT) * 1024 + (kh * 32 + co) * 16 + e * 2;
+        if (H2) {
+            uint32_t th, tl;
+            nww_split2h(wv * s_w, 0.0f, th, tl);
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)th;
+            *reinterpret_cast<uint16_t*>(d + 1024) = (uint16_t)tl;
+        } else {
+            uint32_t th, tm, tl;
+            split3c(wv, th, tm, tl);
+            *reinterpret_cast<uint16_t*>(d) = (uint16_t)(th >> 16);
+            *reinterpret_cast<uint16_t*>(d + 1024) = (uint16_t)(tm >> 16);
+            *reinterpret_cast<uint16_t*>(d + 2 * 1024) = (uint16_t)(tl >> 16);
+        }
     }
     const int seq_ch = (POOL && a.seq_out) ? a.Cout * Ho : 0;
     const int cout = 32 * grp + i;
@@ -161,41 +178,49 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-        bf16x8 na[3], nb[3], nw[3];
+        bf16x8 na[NT], nb[NT], nw[NT];
         auto fetch = [&](int step) {                           // step = tap * 2 + k-block
             const int tap = step >> 1, kb = step & 1;
             const int off = (tap / 3) * rowB + (tap % 3) * PS3 + 32 * kb;
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
+            for (int tm = 0; tm < NT; ++tm) {
                 na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 64 * tm);
                 if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + off + 64 * tm);
-                nw[tm] = *reinterpret_cast<const bf16x8*>(wlane + (step * 3 + tm) * 1024);
+                nw[tm] = *reinterpret_cast<const bf16x8*>(wlane + (step * NT + tm) * 1024);
+            }
+        };
+        // terms 0 = hi, 1 = mid / lo, 2 = lo; smallest products first (the order of trunk_x3's tap_mfma<6>)
+        auto products = [&](const bf16x8* x, const bf16x8* w, f32x16& acc) {
+            if (H2) {
+                const f16x8 xh = __builtin_bit_cast(f16x8, x[0]), xl = __builtin_bit_cast(f16x8, x[1]);
+                const f16x8 wh = __builtin_bit_cast(f16x8, w[0]), wl2 = __builtin_bit_cast(f16x8, w[1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], w[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[NT - 1], w[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], w[NT - 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], w[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], w[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], w[0], acc, 0, 0, 0);
             }
         };
         fetch(0);
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
-            bf16x8 ca[3], cb[3], cw[3];
+            bf16x8 ca[NT], cb[NT], cw[NT];
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; cw[tm] = nw[tm]; }
+            for (int tm = 0; tm < NT; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; cw[tm] = nw[tm]; }
             if (step + 1 < 18) fetch(step + 1);
             __builtin_amdgcn_sched_barrier(0);                 // next step's LDS reads stay above this step's MFMAs
-            // terms 0 = hi, 1 = mid, 2 = lo; smallest products first (the order of trunk_x3's tap_mfma<6>)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], cw[1], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[2], cw[0], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[2], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[1], cw[0], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[1], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[0], cw[0], acc0, 0, 0, 0);
-            if (TWO) {
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[1], cw[1], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[2], cw[0], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[2], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[1], cw[0], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[1], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[0], cw[0], acc1, 0, 0, 0);
-            }
+            products(ca, cw, acc0);
+            if (TWO) products(cb, cw, acc1);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (H2) {                                              // back to the true scale (a power of two)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] *= c_out; if (TWO) acc1[r] *= c_out; }
         }
         if (AVG) {
             avg_epilogue(acc0, R0, X0, wsum, aw);
@@ -233,7 +258,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     // (the right halo column is left out: with a shortened pitch its pad overlaps the next row's left halo pixel)
     const int npix = (H + 3) * (Wp - 1);
     auto part_ptr = [&](int t) {
-        return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + 192 : Wt + WT_BYTES + (size_t)(t - npix) * 16);
+        return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + 64 * NT : Wt + WT_BYTES + (size_t)(t - npix) * 16);
     };
     float* my_part = part_ptr(tid);
     prefetch(b_first);
@@ -242,19 +267,27 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         if (stager) {
 #pragma unroll
             for (int c8 = 0; c8 < 4; ++c8) {
-                uint32_t th[4], tm[4], tl[4];
+                if (H2) {
+                    uint32_t th[4], tl[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uint32_t h0, m0, l0, h1, m1, l1;
-                    split3c(pre[8 * c8 + 2 * e], h0, m0, l0);
-                    split3c(pre[8 * c8 + 2 * e + 1], h1, m1, l1);
-                    th[e] = (h0 >> 16) | (h1 & 0xffff0000u);
-                    tm[e] = (m0 >> 16) | (m1 & 0xffff0000u);
-                    tl[e] = (l0 >> 16) | (l1 & 0xffff0000u);
+                    for (int e = 0; e < 4; ++e) nww_split2h(pre[8 * c8 + 2 * e] * s_in, pre[8 * c8 + 2 * e + 1] * s_in, th[e], tl[e]);
+                    *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
+                    *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+                } else {
+                    uint32_t th[4], tm[4], tl[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t h0, m0, l0, h1, m1, l1;
+                        split3c(pre[8 * c8 + 2 * e], h0, m0, l0);
+                        split3c(pre[8 * c8 + 2 * e + 1], h1, m1, l1);
+                        th[e] = (h0 >> 16) | (h1 & 0xffff0000u);
+                        tm[e] = (m0 >> 16) | (m1 & 0xffff0000u);
+                        tl[e] = (l0 >> 16) | (l1 & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
+                    *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
+                    *reinterpret_cast<uint4*>(my_px + 2 * 64 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
                 }
-                *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
-                *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
-                *reinterpret_cast<uint4*>(my_px + 128 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
             }
         }
         __syncthreads();
@@ -293,13 +326,15 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 }
 }  // namespace
 
-static size_t conv3_x3_a3_bytes(int H, int W, int avg_ow) { return ((size_t)(H + 3) * conv3_row_pitch(H, W, avg_ow) + 32 + 15) & ~(size_t)15; }
+static size_t conv3_x3_a3_bytes(int H, int W, int avg_ow, bool h2) { return ((size_t)(H + 3) * conv3_row_pitch(H, W, avg_ow, h2) + 32 + 15) & ~(size_t)15; }
 
-size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) {
+static size_t conv3_x3_lds(int H, int W, int avg_ow, bool h2) {
     const int npix = (H + 3) * (W + 1);                        // the avg-pool partials live in the pixels' pads; the rest behind the weights
-    return conv3_x3_a3_bytes(H, W, avg_ow) + WT_BYTES + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
+    return conv3_x3_a3_bytes(H, W, avg_ow, h2) + (h2 ? C3A<true>::WT_BYTES : C3A<false>::WT_BYTES) + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
 }
+size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) { return conv3_x3_lds(H, W, avg_ow, false); }
 
+// (decided on the three-term form's footprint in every arithmetic: which kernel a shape takes does not depend on the arithmetic switch)
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
     if (Cout % 32 != 0 || H < 2 || W < 2 || H * W > 512) return false;
     if (avg_ow > 0 && (pool || avg_ow > 4)) return false;
@@ -308,20 +343,23 @@ bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
 
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     if (!conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
-    const size_t lds = conv3_x3_lds_bytes(a.H, a.W, a.avg_ow);
+    const bool h2 = a.h2_in > 0.0f;
+    const size_t lds = conv3_x3_lds(a.H, a.W, a.avg_ow, h2);
     ConvMfmaArgs aa = a;
-    aa.row_pitch = conv3_row_pitch(a.H, a.W, a.avg_ow);
+    aa.row_pitch = conv3_row_pitch(a.H, a.W, a.avg_ow, h2);
     const int ngroups = a.Cout / 32;
     long want = (long)a.B * ngroups;
     int grid = (int)(want < max_grid ? want : max_grid);
     grid -= grid % ngroups;
     if (grid < ngroups) grid = ngroups;
-#define C3_LAUNCH(ACTV, POOLV, AVGV)                                                                               \
+#define C3_LAUNCH1(ACTV, POOLV, AVGV, H2V)                                                                         \
     {                                                                                                              \
-        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, POOLV, AVGV>), lds);      \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, POOLV, AVGV, H2V>), lds); \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, AVGV>), dim3(grid), dim3(512), lds, s, aa);                \
+        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, AVGV, H2V>), dim3(grid), dim3(512), lds, s, aa);           \
     }
+#define C3_LAUNCH(ACTV, POOLV, AVGV)                                                                               \
+    if (h2) C3_LAUNCH1(ACTV, POOLV, AVGV, true) else C3_LAUNCH1(ACTV, POOLV, AVGV, false)
 #define C3_ACT(ACTV)                                                                                               \
     if (a.avg_ow > 0) C3_LAUNCH(ACTV, false, true) else if (a.pool) C3_LAUNCH(ACTV, true, false) else C3_LAUNCH(ACTV, false, false)
     switch (a.act) {
@@ -332,5 +370,6 @@ hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     }
 #undef C3_ACT
 #undef C3_LAUNCH
+#undef C3_LAUNCH1
     return hipGetLastError();
 }

@@ -368,7 +368,9 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 // 3x3 conv stage with 32 input channels on MFMA (trunk.hip) when it fits; false -> caller uses the VALU kernel
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
-                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0, bool* ring_in = nullptr) {
+                   int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0, bool* ring_in = nullptr,
+                   double in_bound = 0.0, double* out_bound = nullptr) {
+    if (out_bound) *out_bound = 0.0;
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
@@ -384,9 +386,20 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
         const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
         const bool ring_ok = ring_in && *ring_in;                                             // ... and may hand the input over in rings
-        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name, [=](Run& r) {
+        // NWW_ARITH_F16X3: two binary16 terms when the input is bounded (the fused trunk's plan-time bound)
+        float h2_in = 0.0f, h2_w = 0.0f;
+        if (p.h->f16 && in_bound > 0.0) {
+            const auto hw = f16_fetch(p.h, w, (size_t)Cout * Cin * 9);
+            h2_in = f16_scale(in_bound); h2_w = f16_wscale(hw);
+            if (out_bound && h2_in > 0.0f && h2_w > 0.0f)
+                *out_bound = f16_layer_bound(hw, Cout, Cin * 9, f16_fetch(p.h, bias, Cout), bias != nullptr, f16_fetch(p.h, alpha, Cout),
+                                             f16_fetch(p.h, beta, Cout), alpha != nullptr, in_bound);
+        }
+        const bool h2 = h2_in > 0.0f && h2_w > 0.0f;
+        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name + (h2 ? " [f16x3]" : ""), [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
             a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out; a.avg_y = avg_y;
+            if (h2) { a.h2_in = h2_in; a.h2_w = h2_w; }
             if (ring_ok && r.stream_mode) {             // streaming hop: the fused trunk's pooled rows are read from their rings
                 a.in = r.a2_ring; a.in_ring_rows = r.a2_rows; a.in_row0 = r.a2_row0;
                 a.in_ch_stride = r.a2_ch_stride; a.in_clip_stride = r.a2_clip_stride;
@@ -676,12 +689,13 @@ extern "C" int nww_finalize(nww_handle* h) {
                 });
                 const int h3 = Ht / 4, w3 = Wt / 4;           // (25, 16): AdaptiveAvgPool2d((1,4))'s windows run along the FRAMES, here y
                 const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
+                double tbound = 0.0;                          // NWW_ARITH_F16X3: a bound on the trunk's output, the third conv's operand
                 const bool ok = add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
                                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
-                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND) &&
+                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &tbound) &&
                                 h->plan.back().name.rfind("trunk_x3:", 0) == 0 && h3 >= 4 &&
                                 add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
-                                              p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1);
+                                              p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1, nullptr, tbound);
                 if (!ok) {
                     h->plan.resize(steps_before);
                     h->e2e_transposed = false;
@@ -695,9 +709,10 @@ extern "C" int nww_finalize(nww_handle* h) {
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
             int first = 0;
             bool fused_pool = false;
+            double cbound = 0.0;                              // NWW_ARITH_F16X3: bound on the current stage's input (0: unknown)
             if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
-                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND)) {
+                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &cbound)) {
                 first = 2; cin = 32; hh = Hh / 4; ww = Ww / 4; cur = 1;
             }
             for (int i = first; i < 3; ++i) {
@@ -706,13 +721,19 @@ extern "C" int nww_finalize(nww_handle* h) {
                 if (i == 2 && ww >= 4) {
                     // conv3 + AdaptiveAvgPool2d((1,4)) in its exported AvgPool2d form, fused when the MFMA kernel applies
                     const int sw4 = ww / 4, kw4 = ww - 3 * sw4;
-                    if (add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4)) {
+                    if (add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 0, kw4, sw4, 4,
+                                      nullptr, 0, nullptr, cbound)) {
                         fused_pool = true; cin = ch[i]; cur = out;
                         continue;
                     }
                 }
-                if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2))
-                    add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
+                {
+                    double nb = 0.0;
+                    if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2,
+                                       0, 0, 0, nullptr, 0, nullptr, cbound, &nb))
+                        add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
+                    cbound = nb;
+                }
                 if (i < 2) { hh /= 2; ww /= 2; }
                 cin = ch[i]; cur = out;
             }
@@ -735,11 +756,12 @@ extern "C" int nww_finalize(nww_handle* h) {
             int cin = 1, hh = T, ww = F, cur = -1;
             int first = 0;
             bool seq_written = false;
+            double cbound = 0.0;                              // NWW_ARITH_F16X3: bound on the current stage's input (0: unknown)
             const size_t steps_before = h->plan.size();
             if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
                 add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
                           p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
-                          p.W("model.cnn.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND)) {
+                          p.W("model.cnn.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &cbound)) {
                 first = 2; cin = 32; hh = T / 4; ww = F / 4; cur = 1;
             }
             for (int i = first; i < c.n_crnn_channels; ++i) {
@@ -749,7 +771,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                 bool seq = i == c.n_crnn_channels - 1;
                 // the stage right behind a fused split-operand trunk may take its input from the streaming rings (nww_stream.hip)
                 bool ring = i == 2 && first == 2 && h->plan.size() == steps_before + 1 && h->plan.back().name.rfind("trunk_x3:", 0) == 0 && ((F / 4) % 4) == 0;
-                if (!add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring)) {
+                double nb = 0.0;
+                const bool mf = add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring, cbound, &nb);
+                cbound = nb;
+                if (!mf) {
                     ring = false;
                     seq = false;
                     add_conv(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1);

@@ -80,6 +80,9 @@ struct ConvMfmaArgs {
     int avg_y = 0;         // conv3_x3 only: the windows run along y and cover all columns (the same pool on a transposed plane)
     // conv3_x3 only, pooled mode: write out [B][W/2][Cout * H/2] (feature = channel * H/2 + row), the recurrent layers' input
     int seq_out = 0;
+    // conv3_x3, two binary16 terms per operand (NWW_ARITH_F16X3): h2_in > 0 - the input times h2_in and the weights times h2_w
+    // (powers of two from plan-time bounds) stay inside the binary16 range
+    float h2_in = 0.0f, h2_w = 1.0f;
 };
 size_t conv_mfma_lds_bytes(int C1, int H, int W);
 hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipStream_t s);

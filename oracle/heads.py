@@ -281,16 +281,17 @@ _NETS = {"dnn": net_dnn, "cnn": net_cnn, "crnn": net_crnn, "gru": net_gru,
          "bcresnet": net_bcresnet, "conformer": net_conformer, "e2e_dnn": net_e2e_cnn_body}
 
 
-def head_forward(x, sd, cfg):
-    """features [B,T,F] float32 -> embedding [B,E]."""
-    x = np.ascontiguousarray(x, dtype=F32)
-    sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
-    return _NETS[cfg.model_type](x, sd, cfg).astype(F32)
+def head_forward(x, sd, cfg, dtype=F32):
+    """features [B,T,F] float32 -> embedding [B,E].  dtype = numpy.float64 evaluates the same network in double precision
+    (every primitive above follows its input's dtype): the yardstick the arithmetic modes of the HIP path are measured against."""
+    x = np.ascontiguousarray(x, dtype=dtype)
+    sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
+    return _NETS[cfg.model_type](x, sd, cfg).astype(dtype)
 
 
-def model_forward(x, sd, cfg):
+def model_forward(x, sd, cfg, dtype=F32):
     """Model.forward (model.py:562-571): embedding -> classifier MLP (model.py:291-296) -> logits [B,1]."""
-    sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items()}
-    e = head_forward(x, sd, cfg)
+    sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
+    e = head_forward(x, sd, cfg, dtype)
     h = act(linear(e, sd["classifier.0.weight"], sd["classifier.0.bias"]), cfg.activation)
-    return linear(h, sd["classifier.3.weight"], sd["classifier.3.bias"]).astype(F32)
+    return linear(h, sd["classifier.3.weight"], sd["classifier.3.bias"]).astype(dtype)

@@ -333,6 +333,28 @@ def test_cnn_trunk_odd_shapes(hip, shape, arith):
     m.close()
 
 
+def test_arithmetic_modes_against_float64(hip):
+    """Every arithmetic against the same network evaluated in float64 (oracle, dtype = float64), CNN and DNN heads, 48 clips: the
+    two-term binary16 form (default) and the three-term bf16 forms are as close to exact arithmetic as the float32 MFMA path -
+    none is more than 2x + 2e-6 worse than it, all are 10x inside the 1e-4 bar."""
+    HipModel, _ = hip
+    for head, shape in (("cnn", (101, 64)), ("dnn", (98, 40))):
+        cfg = HeadConfig(head, shape)
+        sd = synth_state_dict(cfg)
+        feats = synth_features(48, cfg.input_shape, seed=21)
+        ref = oracle.model_forward(feats, sd, cfg, dtype=np.float64).ravel()
+        err = {}
+        for mode in ("f32", "bf16x9", "bf16x6", "f16x3"):
+            m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith=mode)
+            lg, _ = m.forward_features(feats)
+            err[mode] = float(np.abs(lg.astype(np.float64) - ref).max())
+            m.close()
+        print(head, "max |dlogit| vs float64:", err)
+        assert max(err.values()) <= 1e-5, (head, err)
+        for mode in ("bf16x9", "bf16x6", "f16x3"):
+            assert err[mode] <= 2.0 * err["f32"] + 2e-6, (head, mode, err)
+
+
 def test_f16x3_scales_clamp_and_activations(hip):
     """The two-term binary16 arithmetic (nww_config.conv_arith = NWW_ARITH_F16X3, the default): power-of-two scales fixed at plan
     time from bounds on the tensors.  (i) every activation / BatchNorm form of the fused trunk (CNN: bias only; CRNN / E2E: folded

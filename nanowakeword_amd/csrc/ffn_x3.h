@@ -10,15 +10,21 @@ struct FfnArgs {
     const float* b2;                 // [D]
     int M;
     float rscale;
+    // h2_x > 0: the two-term binary16 arithmetic (NWW_ARITH_F16X3; weights packed by launch_ffn_x3_pack with sw1 / sw2 > 0).
+    // Powers of two from plan-time bounds: the LayerNorm-ed rows times h2_x, W1 times h2_w1, the hidden activations times
+    // h2_h, W2 times h2_w2 all stay inside the binary16 range (|LayerNorm| <= sqrt(D) max|w| + max|b|, |swish(v)| <= |v|)
+    float h2_x = 0.0f, h2_w1 = 1.0f, h2_h = 1.0f, h2_w2 = 1.0f;
 };
 
 // One packed hidden block = a W1 part (D/16 x 3 fragments of 1 KB) and a W2 part (ceil(D/32) x 2 x 3 fragments, then the
 // block's 32 biases), each padded to whole 4 KB copy steps (256 lanes x 16 B)
-__host__ __device__ inline size_t ffn_x3_w1_bytes(int D) { return ((size_t)(D / 16) * 3072 + 4095) & ~(size_t)4095; }
-__host__ __device__ inline size_t ffn_x3_w2_bytes(int D) { return ((size_t)((D + 31) / 32) * 6144 + 128 + 4095) & ~(size_t)4095; }
-__host__ __device__ inline size_t ffn_x3_block_bytes(int D) { return ffn_x3_w1_bytes(D) + ffn_x3_w2_bytes(D); }
+// (nt = terms per value: 3 bf16 or 2 binary16)
+__host__ __device__ inline size_t ffn_x3_w1_bytes(int D, int nt = 3) { return ((size_t)(D / 16) * nt * 1024 + 4095) & ~(size_t)4095; }
+__host__ __device__ inline size_t ffn_x3_w2_bytes(int D, int nt = 3) { return ((size_t)((D + 31) / 32) * 2 * nt * 1024 + 128 + 4095) & ~(size_t)4095; }
+__host__ __device__ inline size_t ffn_x3_block_bytes(int D, int nt = 3) { return ffn_x3_w1_bytes(D, nt) + ffn_x3_w2_bytes(D, nt); }
 size_t ffn_x3_packed_bytes(int D);
 bool ffn_x3_supported(int D);        // D (= d_model; hidden = 4 D) for which an instance is compiled
 // W1 [4D][D], b1 [4D], W2 [D][4D] float32 -> packed
-hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s);
+// sw1, sw2 > 0: two binary16 terms of W1 sw1 / W2 sw2 instead of three bf16 terms
+hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1 = 0.0f, float sw2 = 0.0f);
 hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s);

@@ -23,10 +23,15 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
+// H2 instances ("f16x3", FfnArgs::h2_x > 0): every operand - the LayerNorm-ed rows, W1, the hidden activations, W2 - times a
+// plan-time power of two is split into TWO binary16 terms (split_h2.h) and each product is three v_mfma_f32_32x32x16_f16:
+// half the matrix instructions of the six-product form, which runs at the package's sustained matrix rate.
 #include "layers.h"
 #include "ffn_x3.h"
+#include "split_h2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -65,12 +70,30 @@ __device__ __forceinline__ void mfma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3]
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
 }
 
+// one MFMA of the split products: bf16 terms or binary16 terms (fragments are carried as 128-bit bags typed bf16x8)
+template <bool H2>
+__device__ __forceinline__ f32x16 ffn_mma(const bf16x8& w, const bf16x8& x, const f32x16& acc) {
+    if (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+// eight float32 (already scaled) -> two binary16 fragments
+__device__ __forceinline__ void split_frag2(const float (&v)[8], bf16x8& fh, bf16x8& fl) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nww_split2h(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    union { uint4 u; bf16x8 b; } ch, cl;
+    ch.u = make_uint4(h[0], h[1], h[2], h[3]);
+    cl.u = make_uint4(l[0], l[1], l[2], l[3]);
+    fh = ch.b; fl = cl.b;
+}
+
 // ---- plan-time packing: one thread per (hidden block, fragment, lane)
 __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, unsigned char* __restrict__ out, int D) {
+                                                       const float* __restrict__ W2, unsigned char* __restrict__ out, int D, float sw1, float sw2) {
     const int D16 = D / 16, NOB = (D + 31) / 32, NHB = D / 8, H4 = 4 * D;
     const int frags = D16 + 2 * NOB;
-    const size_t blk = ffn_x3_block_bytes(D);
+    const int NT = sw1 > 0.0f ? 2 : 3;
+    const size_t blk = ffn_x3_block_bytes(D, NT);
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)NHB * frags * 64) return;
     const int lane = (int)(idx & 63), f = (int)((idx >> 6) % frags), hb = (int)((idx >> 6) / frags);
@@ -82,29 +105,41 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
         const int kb = f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = W1[(size_t)(32 * hb + i) * D + 16 * kb + 8 * h + e];
-        dst = base + ((size_t)(kb * 3) * 64 + lane) * 16;
+        dst = base + ((size_t)(kb * NT) * 64 + lane) * 16;
     } else {                                                   // W2 fragment (ob, kb2): row = out feature 32ob + i, slot e <-> hidden
         const int ob = (f - D16) >> 1, kb2 = (f - D16) & 1;    //   32hb + 8 (2 kb2 + (e >> 2)) + 4h + (e & 3)
         const int m = 32 * ob + i;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = m < D ? W2[(size_t)m * H4 + 32 * hb + 8 * (2 * kb2 + (e >> 2)) + 4 * h + (e & 3)] : 0.0f;
-        dst = base + ffn_x3_w1_bytes(D) + ((size_t)((ob * 2 + kb2) * 3) * 64 + lane) * 16;
+        dst = base + ffn_x3_w1_bytes(D, NT) + ((size_t)((ob * 2 + kb2) * NT) * 64 + lane) * 16;
     }
-    uint32_t hh[8], mm[8], ll[8];
+    if (NT == 2) {
+        const float sc = f < D16 ? sw1 : sw2;
+        uint32_t hh[4], ll[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3f(v[e], hh[e], mm[e], ll[e]);
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack16(hh[0], hh[1]), pack16(hh[2], hh[3]), pack16(hh[4], hh[5]), pack16(hh[6], hh[7]));
-    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16(mm[0], mm[1]), pack16(mm[2], mm[3]), pack16(mm[4], mm[5]), pack16(mm[6], mm[7]));
-    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16(ll[0], ll[1]), pack16(ll[2], ll[3]), pack16(ll[4], ll[5]), pack16(ll[6], ll[7]));
-    if (f == 0 && lane < 32) reinterpret_cast<float*>(base + ffn_x3_w1_bytes(D) + (size_t)NOB * 6144)[lane] = b1[32 * hb + lane];
+        for (int j = 0; j < 4; ++j) nww_split2h(v[2 * j] * sc, v[2 * j + 1] * sc, hh[j], ll[j]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    } else {
+        uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3f(v[e], hh[e], mm[e], ll[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack16(hh[0], hh[1]), pack16(hh[2], hh[3]), pack16(hh[4], hh[5]), pack16(hh[6], hh[7]));
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16(mm[0], mm[1]), pack16(mm[2], mm[3]), pack16(mm[4], mm[5]), pack16(mm[6], mm[7]));
+        *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16(ll[0], ll[1]), pack16(ll[2], ll[3]), pack16(ll[4], ll[5]), pack16(ll[6], ll[7]));
+    }
+    if (f == 0 && lane < 32) reinterpret_cast<float*>(base + ffn_x3_w1_bytes(D, NT) + (size_t)NOB * 2 * NT * 1024)[lane] = b1[32 * hb + lane];
 }
 
-template <int D16>
+template <int D16, bool H2>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;
-    constexpr int W1_PART = (D16 * 3072 + 4095) & ~4095, W2_PART = (NOB * 6144 + 128 + 4095) & ~4095, BLK = W1_PART + W2_PART;
-    constexpr int B1_OFF = NOB * 6144;                         // the block's 32 biases sit behind the W2 fragments
+    constexpr int NT = H2 ? 2 : 3, NP = H2 ? 3 : 6;            // terms per value, partial products per operand pair
+    constexpr int W1_PART = (D16 * NT * 1024 + 4095) & ~4095, W2_PART = (NOB * 2 * NT * 1024 + 128 + 4095) & ~4095, BLK = W1_PART + W2_PART;
+    constexpr int B1_OFF = NOB * 2 * NT * 1024;                // the block's 32 biases sit behind the W2 fragments
+    // two-term form: accumulators of the first product are h2_x h2_w1 times the true sums, of the second h2_h h2_w2 times
+    const float s_x = H2 ? a.h2_x : 1.0f, ik1 = H2 ? 1.0f / (a.h2_x * a.h2_w1) : 1.0f, s_h = H2 ? a.h2_h : 1.0f, ik2 = H2 ? 1.0f / (a.h2_h * a.h2_w2) : 1.0f;
     // Four separate LDS objects, not four quarters of one: hipcc then knows that the reads of one buffer cannot alias
     // the LDS-DMA writes into another and does not wait for the fetches in flight (s_waitcnt vmcnt(0)) in mid-block.
     __shared__ __attribute__((aligned(16))) unsigned char w1b0[W1_PART];
@@ -133,7 +168,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     fetch_w2(0, w2b0);
 
     // ---- LayerNorm of the lane's half row (features 16kb + 8h + e) -> X fragments
-    bf16x8 xf[D16][3];
+    bf16x8 xf[D16][NT];
     {
         float v[D16][8];
         float s = 0.0f;
@@ -163,7 +198,13 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = (v[kb][e] - mu) * rstd * w[e] + c[e];
-            split_frag(y, xf[kb][0], xf[kb][1], xf[kb][2]);
+            if constexpr (H2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] *= s_x;
+                split_frag2(y, xf[kb][0], xf[kb][1]);
+            } else {
+                split_frag(y, xf[kb][0], xf[kb][1], xf[kb][NT - 1]);
+            }
         }
     }
 
@@ -181,10 +222,11 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     //   iteration hb:  fetch W1(hb + 2), W2(hb + 1);   Ht(hb + 1) = W1(hb + 1) . Xt  ||  hf = split(swish(Ht(hb) + b1(hb)));
     //                  Yt += W2(hb) . hf;               barrier
     auto gemm1_epi = [&](auto has_next, const unsigned char* w1buf, const unsigned char* w2buf, const f32x16& cur, f32x16& next,
-                         bf16x8 (&hf)[2][3]) {
+                         bf16x8 (&hf)[2][NT]) {
         constexpr bool NEXT = decltype(has_next)::value;
-        constexpr int NSLOT = NEXT ? 6 * D16 : 1;              // MFMAs of the first product = slots for epilogue pieces
-        constexpr int PER = (48 + NSLOT - 1) / NSLOT;          // epilogue pieces (16 elements x 3 stages) per slot
+        constexpr int NSLOT = NEXT ? NP * D16 : 1;             // MFMAs of the first product = slots for epilogue pieces
+        constexpr int NPIECE = H2 ? 40 : 48;                   // epilogue pieces (below)
+        constexpr int PER = (NPIECE + NSLOT - 1) / NSLOT;      // ... per slot
         const unsigned char* w1p = w1buf + lane * 16;
         const float* b1p = reinterpret_cast<const float*>(w2buf + B1_OFF) + 4 * h;
         float4 bq[4];
@@ -192,98 +234,128 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
         for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(b1p + 8 * g);     // biases of hidden 8g + 4h + 0..3
         const float bias[16] = {bq[0].x, bq[0].y, bq[0].z, bq[0].w, bq[1].x, bq[1].y, bq[1].z, bq[1].w,
                                 bq[2].x, bq[2].y, bq[2].z, bq[2].w, bq[3].x, bq[3].y, bq[3].z, bq[3].w};
-        bf16x8 nw[3], cw[3];
+        bf16x8 nw[NT], cw[NT];
         if (NEXT) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
+            for (int t = 0; t < NT; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
 #pragma unroll
             for (int r = 0; r < 16; ++r) next[r] = 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        // element e of the accumulator in three pieces: (A) v = acc + bias, u = 1 + 2^(-v log2 e);  (B) y = v / u, hi, rest;
-        // (C) mid, lo.  Registers 8 kb2 .. 8 kb2 + 7 are the eight k slots of 16-block kb2 of the second product.
+        // Three-term form, element e of the accumulator in three pieces: (A) v = acc + bias, u = 1 + 2^(-v log2 e);  (B) y = v / u,
+        // hi, rest;  (C) mid, lo.  Two-term form, per PAIR of elements five pieces: (A) (A) as above with the accumulator scaled
+        // back, (B) (B) y = s_h v / u, (C) the pair's two binary16 dwords.  Registers 8 kb2 .. 8 kb2 + 7 are the eight k slots of
+        // 16-block kb2 of the second product.
         float v[16], u[16];
         uint32_t th[16], tm[16], tl[16];
         auto piece = [&](int p) {
-            const int e = p / 3, st = p - 3 * e;
-            if (st == 0) {
-                v[e] = cur[e] + bias[e];
-                u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
-                asm volatile("" : "+v"(v[e]), "+v"(u[e]));     // pins the piece behind its MFMA (pure arithmetic floats freely otherwise)
-            } else if (st == 1) {
-                const float y = v[e] * __builtin_amdgcn_rcpf(u[e]);
-                th[e] = __float_as_uint(y) & 0xffff0000u;
-                u[e] = y - __uint_as_float(th[e]);
-                asm volatile("" : "+v"(th[e]), "+v"(u[e]));
+            if constexpr (H2) {
+                const int j = p / 5, st = p - 5 * j;
+                if (st < 2) {
+                    const int e = 2 * j + st;
+                    v[e] = fmaf(cur[e], ik1, bias[e]);
+                    u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
+                    asm volatile("" : "+v"(v[e]), "+v"(u[e]));
+                } else if (st < 4) {
+                    const int e = 2 * j + st - 2;
+                    v[e] = (v[e] * s_h) * __builtin_amdgcn_rcpf(u[e]);
+                    asm volatile("" : "+v"(v[e]));
+                } else {
+                    nww_split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
+                    asm volatile("" : "+v"(th[j]), "+v"(tl[j]));
+                }
             } else {
-                tm[e] = __float_as_uint(u[e]) & 0xffff0000u;
-                tl[e] = __float_as_uint(u[e] - __uint_as_float(tm[e]));
-                asm volatile("" : "+v"(tm[e]), "+v"(tl[e]));
+                const int e = p / 3, st = p - 3 * e;
+                if (st == 0) {
+                    v[e] = cur[e] + bias[e];
+                    u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
+                    asm volatile("" : "+v"(v[e]), "+v"(u[e]));     // pins the piece behind its MFMA (pure arithmetic floats freely otherwise)
+                } else if (st == 1) {
+                    const float y = v[e] * __builtin_amdgcn_rcpf(u[e]);
+                    th[e] = __float_as_uint(y) & 0xffff0000u;
+                    u[e] = y - __uint_as_float(th[e]);
+                    asm volatile("" : "+v"(th[e]), "+v"(u[e]));
+                } else {
+                    tm[e] = __float_as_uint(u[e]) & 0xffff0000u;
+                    tl[e] = __float_as_uint(u[e] - __uint_as_float(tm[e]));
+                    asm volatile("" : "+v"(tm[e]), "+v"(tl[e]));
+                }
             }
         };
-        constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PX[6] = {1, 0, 2, 0, 1, 0};       // the six products, small terms first (mfma6)
+        // the partial products, small terms first (mfma6; two-term form: lo hi, hi lo, hi hi)
+        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             if (NEXT) {
-                const int kb = q / 6, m = q - 6 * kb;
+                const int kb = q / NP, m = q - NP * kb;
                 if (m == 0) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) cw[t] = nw[t];
+                    for (int t = 0; t < NT; ++t) cw[t] = nw[t];
                 }
-                if (m < 3 && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * 3 + m) * 1024);
-                next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw[PW[m]], xf[kb][PX[m]], next, 0, 0, 0);
+                if (m < NT && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * NT + m) * 1024);
+                next = ffn_mma<H2>(cw[PW[m]], xf[kb][PX[m]], next);
                 asm volatile("" : "+a"(next));
             }
 #pragma unroll
-            for (int p = q * PER; p < (q + 1) * PER && p < 48; ++p) piece(p);
+            for (int p = q * PER; p < (q + 1) * PER && p < NPIECE; ++p) piece(p);
             __builtin_amdgcn_sched_barrier(0);                 // each MFMA keeps its pieces: a lone wave issues in order, and the
         }                                                      // next MFMA of the chain waits 32 clocks for this one anyway
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2) {
-            union { uint4 q; bf16x8 b; } ch, cm, cl;
-            const int o = 8 * kb2;
-            ch.q = make_uint4(pack16(th[o], th[o + 1]), pack16(th[o + 2], th[o + 3]), pack16(th[o + 4], th[o + 5]), pack16(th[o + 6], th[o + 7]));
-            cm.q = make_uint4(pack16(tm[o], tm[o + 1]), pack16(tm[o + 2], tm[o + 3]), pack16(tm[o + 4], tm[o + 5]), pack16(tm[o + 6], tm[o + 7]));
-            cl.q = make_uint4(pack16(tl[o], tl[o + 1]), pack16(tl[o + 2], tl[o + 3]), pack16(tl[o + 4], tl[o + 5]), pack16(tl[o + 6], tl[o + 7]));
-            hf[kb2][0] = ch.b; hf[kb2][1] = cm.b; hf[kb2][2] = cl.b;
+            if constexpr (H2) {
+                union { uint4 q; bf16x8 b; } ch, cl;
+                const int o = 4 * kb2;
+                ch.q = make_uint4(th[o], th[o + 1], th[o + 2], th[o + 3]);
+                cl.q = make_uint4(tl[o], tl[o + 1], tl[o + 2], tl[o + 3]);
+                hf[kb2][0] = ch.b; hf[kb2][1] = cl.b;
+            } else {
+                union { uint4 q; bf16x8 b; } ch, cm, cl;
+                const int o = 8 * kb2;
+                ch.q = make_uint4(pack16(th[o], th[o + 1]), pack16(th[o + 2], th[o + 3]), pack16(th[o + 4], th[o + 5]), pack16(th[o + 6], th[o + 7]));
+                cm.q = make_uint4(pack16(tm[o], tm[o + 1]), pack16(tm[o + 2], tm[o + 3]), pack16(tm[o + 4], tm[o + 5]), pack16(tm[o + 6], tm[o + 7]));
+                cl.q = make_uint4(pack16(tl[o], tl[o + 1]), pack16(tl[o + 2], tl[o + 3]), pack16(tl[o + 4], tl[o + 5]), pack16(tl[o + 6], tl[o + 7]));
+                hf[kb2][0] = ch.b; hf[kb2][1] = cm.b; hf[kb2][NT - 1] = cl.b;
+            }
         }
     };
     // second product: two output blocks at a time, their MFMAs alternating (a chain on one accumulator issues every 36
     // clocks, two interleaved chains every 32: tools/ubench/mfma_valu_samewave.hip)
-    auto gemm2 = [&](const unsigned char* w2buf, const bf16x8 (&hf)[2][3]) {
+    auto gemm2 = [&](const unsigned char* w2buf, const bf16x8 (&hf)[2][NT]) {
         const unsigned char* w2p = w2buf + lane * 16;
-        constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PX[6] = {1, 0, 2, 0, 1, 0};       // the six products, small terms first (mfma6)
+        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};   // as in gemm1_epi
         constexpr int NG = 2 * ((NOB + 1) / 2);                // groups: (pair of output blocks, kb2)
         auto frag = [&](int g, int which, int t) {             // group g = 2 * pair + kb2; which = 0 / 1: block 2 pair + which
             const int ob = 2 * (g >> 1) + which, kb2 = g & 1;
-            return *reinterpret_cast<const bf16x8*>(w2p + ((ob * 2 + kb2) * 3 + t) * 1024);
+            return *reinterpret_cast<const bf16x8*>(w2p + ((ob * 2 + kb2) * NT + t) * 1024);
         };
-        bf16x8 na[3], nb[3];
+        bf16x8 na[NT], nb[NT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { na[t] = frag(0, 0, t); if (NOB > 1) nb[t] = frag(0, 1, t); }
+        for (int t = 0; t < NT; ++t) { na[t] = frag(0, 0, t); if (NOB > 1) nb[t] = frag(0, 1, t); }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int ob = 2 * (g >> 1), kb2 = g & 1;
             const bool two = ob + 1 < NOB;
-            bf16x8 ca[3] = {na[0], na[1], na[2]}, cb[3] = {nb[0], nb[1], nb[2]};
+            bf16x8 ca[NT], cb[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
             if (g + 1 < NG) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     na[t] = frag(g + 1, 0, t);
                     if (2 * ((g + 1) >> 1) + 1 < NOB) nb[t] = frag(g + 1, 1, t);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[PW[m]], hf[kb2][PX[m]], yacc[ob], 0, 0, 0);
-                if (two) yacc[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[PW[m]], hf[kb2][PX[m]], yacc[ob + 1], 0, 0, 0);
+            for (int m = 0; m < NP; ++m) {
+                yacc[ob] = ffn_mma<H2>(ca[PW[m]], hf[kb2][PX[m]], yacc[ob]);
+                if (two) yacc[ob + 1] = ffn_mma<H2>(cb[PW[m]], hf[kb2][PX[m]], yacc[ob + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     f32x16 accA, accB;
-    bf16x8 hf[2][3];
+    bf16x8 hf[2][NT];
     float4 res[NOB][4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -294,10 +366,17 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
         for (int r = 0; r < 16; ++r) accA[r] = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < D16; ++kb) {
-            bf16x8 cw[3];
+            bf16x8 cw[NT];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) cw[t] = *reinterpret_cast<const bf16x8*>(w1p + (kb * 3 + t) * 1024);
-            mfma6(cw, xf[kb], accA);
+            for (int t = 0; t < NT; ++t) cw[t] = *reinterpret_cast<const bf16x8*>(w1p + (kb * NT + t) * 1024);
+            if constexpr (H2) {
+                accA = ffn_mma<true>(cw[1], xf[kb][0], accA);
+                accA = ffn_mma<true>(cw[0], xf[kb][1], accA);
+                accA = ffn_mma<true>(cw[0], xf[kb][0], accA);
+            } else {
+                const bf16x8 c3[3] = {cw[0], cw[1], cw[NT - 1]}, x3[3] = {xf[kb][0], xf[kb][1], xf[kb][NT - 1]};
+                mfma6(c3, x3, accA);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,6 +431,9 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             if (m < D) {                                       // D % 16 == 0, so the four features are in or out together
                 const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + m);
                 float4 r = res[ob][g];
+                if (H2) {                                      // the accumulators back to the true scale (a power of two: exact)
+                    yacc[ob][4 * g + 0] *= ik2; yacc[ob][4 * g + 1] *= ik2; yacc[ob][4 * g + 2] *= ik2; yacc[ob][4 * g + 3] *= ik2;
+                }
                 r.x += a.rscale * (yacc[ob][4 * g + 0] + b2.x);
                 r.y += a.rscale * (yacc[ob][4 * g + 1] + b2.y);
                 r.z += a.rscale * (yacc[ob][4 * g + 2] + b2.z);
@@ -367,10 +449,10 @@ size_t ffn_x3_packed_bytes(int D) { return (size_t)(D / 8) * ffn_x3_block_bytes(
 
 bool ffn_x3_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 144; }
 
-hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s) {
+hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1, float sw2) {
     const size_t total = (size_t)(D / 8) * (D / 16 + 2 * ((D + 31) / 32)) * 64;
     hipLaunchKernelGGL(ffn_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W1, b1, W2,
-                       reinterpret_cast<unsigned char*>(out), D);
+                       reinterpret_cast<unsigned char*>(out), D, sw1, sw2);
     return hipGetLastError();
 }
 
@@ -379,7 +461,8 @@ hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s) {
     const dim3 grid((a.M + 127) / 128);
 #define FFN_GO(D16V)                                                                                               \
     {                                                                                                              \
-                hipLaunchKernelGGL((ffn_x3_kernel<D16V>), grid, dim3(256), 0, s, a);                                       \
+        if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);              \
+        else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false>), grid, dim3(256), 0, s, a);                           \
     }
     switch (D) {
         case 32: FFN_GO(2) break;

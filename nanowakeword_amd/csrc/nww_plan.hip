@@ -939,13 +939,27 @@ extern "C" int nww_finalize(nww_handle* h) {
                     static const int fused = [] { const char* e = getenv("NWW_FFN_FUSED"); return e ? atoi(e) : 1; }();
                     if (fused && p.h->conv_products == 6 && ffn_x3_supported(D)) {
                         void* packed = nullptr;
+                        // NWW_ARITH_F16X3: both operands of both products are bounded whatever the residual stream holds -
+                        // |LayerNorm(h)_i| <= sqrt(D) |w_i| + |b_i|, |swish(v)| <= |v| - so the scales need nothing but the weights
+                        float fx = 0.0f, fw1 = 0.0f, fh = 0.0f, fw2 = 0.0f;
+                        if (p.h->f16) {
+                            const auto hlw = f16_fetch(p.h, lw, D), hlb = f16_fetch(p.h, lb, D);
+                            double bx = 0.0;
+                            for (int i = 0; i < D; ++i) bx = std::fmax(bx, std::sqrt((double)D) * std::fabs((double)hlw[i]) + std::fabs((double)hlb[i]));
+                            const auto w1 = f16_fetch(p.h, p.W(q + ff + ".linear1.weight"), (size_t)4 * D * D), w2 = f16_fetch(p.h, p.W(q + ff + ".linear2.weight"), (size_t)4 * D * D);
+                            const auto b1 = f16_fetch(p.h, p.W(q + ff + ".linear1.bias"), (size_t)4 * D);
+                            const double bh = f16_layer_bound(w1, 4 * D, D, b1, true, b1, b1, false, bx);
+                            fx = f16_scale(bx); fw1 = f16_wscale(w1); fh = f16_scale(bh); fw2 = f16_wscale(w2);
+                        }
+                        const bool h2 = fx > 0.0f && fw1 > 0.0f && fh > 0.0f && fw2 > 0.0f;
                         if (hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
                             launch_ffn_x3_pack(p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"),
-                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream) == hipSuccess) {
+                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream, h2 ? fw1 : 0.0f, h2 ? fw2 : 0.0f) == hipSuccess) {
                             p.h->packed_weights.push_back(packed);
                             const float* b2 = p.W(q + ff + ".linear2.bias");
-                            p.add("ffn_x3:" + q + ff + " (ln+linear1+swish+linear2+0.5res)", [=](Run& r) {
+                            p.add("ffn_x3:" + q + ff + " (ln+linear1+swish+linear2+0.5res)" + (h2 ? " [f16x3]" : ""), [=](Run& r) {
                                 FfnArgs a{r.buf[hb], lw, lb, static_cast<const unsigned char*>(packed), b2, r.B * T, 0.5f};
+                                if (h2) { a.h2_x = fx; a.h2_w1 = fw1; a.h2_h = fh; a.h2_w2 = fw2; }
                                 return launch_ffn_x3(a, D, r.stream);
                             });
                             return;

@@ -114,6 +114,10 @@ bool mha_mfma_supported(int T, int D, int n_head);
 // head_major != 0: qkv is [q|k|v][B][n_head][T][D / n_head] (lin_x3's qkv store) instead of [B][T][3 D]
 hipError_t launch_mha_mfma(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s, int head_major = 0);
 bool mha_head_dim_supported(int head_dim);
+// the same from two binary16 terms per operand on v_mfma_f32_32x32x16_f16 (mha_h2.hip; NWW_ARITH_F16X3): K, V scaled by the
+// unit's own maxima, every query row by its own
+bool mha_h2_supported(int T, int D, int n_head);
+hipError_t launch_mha_h2(const float* qkv, float* out, int B, int T, int D, int n_head, hipStream_t s, int head_major = 0);
 // [B][C][H][W] -> [B][W][C*H]  (CRNN: sequence over W, features C*H; architectures.py:272-276)
 hipError_t launch_crnn_seq(const float* in, float* out, int B, int C, int H, int W, hipStream_t s);
 // GRU recurrence for one direction. xg [B][T][3H] = x W_ih^T + b_ih (precomputed by GEMM).

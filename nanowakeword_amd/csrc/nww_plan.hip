@@ -982,7 +982,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                 else
                     add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
                 static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
-                if (mha_mfma && mha_mfma_supported(T, D, NH))
+                static const int mha_h2 = [] { const char* e = getenv("NWW_MHA_H2"); return e ? atoi(e) : 1; }();
+                if (mha_mfma && mha_h2 && p.h->f16 && mha_h2_supported(T, D, NH))
+                    p.add("mha_h2:" + q + " [f16x3]", [=](Run& r) { return launch_mha_h2(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream, head_major ? 1 : 0); });
+                else if (mha_mfma && mha_mfma_supported(T, D, NH))
                     p.add("mha_mfma:" + q, [=](Run& r) { return launch_mha_mfma(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream, head_major ? 1 : 0); });
                 else
                     p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });

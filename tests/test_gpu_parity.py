@@ -244,14 +244,14 @@ def test_conformer_attention_head_dims(hip, d_model, n_head):
                                                     (128, 4, (33, 64), 6), (144, 4, (101, 64), 3), (144, 4, (130, 64), 2)])
 def test_conformer_fused_kernels_every_width(hip, d_model, n_head, shape, B):
     """Every compiled width of the round-2 Conformer kernels (ffn_x3 / lin_x3: d_model 32, 64, 96, 128, 144; input_proj
-    K = 32 / 64; mha_mfma head dims 16, 24, 32, 36 and its 1..4 key tiles; T = 130 > 128 falls back to the VALU attention
+    K = 32 / 64; mha_h2 (mha_mfma under the other arithmetics) head dims 16, 24, 32, 36 and 1..4 key tiles; T = 130 > 128 falls back to the VALU attention
     core) must be IN the plan and agree with the oracle; row counts that are not multiples of the 128-row tile."""
     HipModel, _ = hip
     cfg = HeadConfig("conformer", shape, embedding_dim=16, conformer_d_model=d_model, conformer_n_head=n_head)
     sd = synth_state_dict(cfg)
     m = HipModel(cfg, FrontendConfig(), state_dict=sd)
     plan = m.describe_plan()
-    assert "ffn_x3:" in plan and "lin_x3:" in plan and ("mha_mfma:" in plan) == (shape[0] <= 128), plan
+    assert "ffn_x3:" in plan and "lin_x3:" in plan and ("mha_h2:" in plan) == (shape[0] <= 128), plan       # (default arithmetic: the two-term attention core)
     feats = synth_features(B, cfg.input_shape, seed=d_model + B)
     logits, _ = m.forward_features(feats)
     ref = oracle.model_forward(feats, sd, cfg).ravel()

@@ -130,7 +130,9 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"TEST_CONV_ARITH": "bf16x6"}, [dict(model_type="dnn", input_shape=(98, 40))], ["gemm:layer1"], ["[f16x3]"], False),   # ... DNN layer1
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
-    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "head-major"], False),  # one-lane-per-query attention core
+    ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "mha_h2", "head-major"], False),  # one-lane-per-query attention core
+    ({"NWW_MHA_H2": "0"}, [_CONF], ["mha_mfma"], ["mha_h2"], False),                    # float32-MFMA attention core under the default arithmetic
+    ({"TEST_CONV_ARITH": "bf16x6"}, [_CONF], ["mha_mfma", "ffn_x3"], ["[f16x3]"], False),   # Conformer on three bf16 terms
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM
     ({"NWW_BC_FRONT": "0"}, [_BC], ["conv1_mfma:init_conv", "dwconv3x3_nhwc:model.block1"], ["conv1_dw_mfma", "conv1_dw_x3"], False),   # init conv and block1 depthwise apart
     ({"NWW_BC_FRONT": "2"}, [_BC], ["conv1_dw_mfma"], ["conv1_dw_x3"], False),          # fused front kernel on the float32 MFMA

@@ -66,16 +66,19 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
     const size_t hm_which = (size_t)units * T * DH;            // floats per q / k / v plane (head-major)
     const int pieces = T * (DH / 4);
 
-    for (int unit = (int)blockIdx.x; unit < units; unit += (int)gridDim.x) {
-        const int b = unit / n_head, head = unit - b * n_head;
+    // K, V rows of a unit -> registers (4-byte aligned 16-byte pieces); requested one unit ahead, under the previous unit's products
+    float4 kr[NPC], vr[NPC];
+    auto unit_ptrs = [&](int u, const float*& qb, const float*& kb, const float*& vb) {
+        const int b = u / n_head, head = u - b * n_head;
         // head_major: qkv = [q|k|v][unit][T][DH] (lin_x3's qkv store); else the rows of nn.Linear's [clip][T][3 D] output
-        const float* qb = head_major ? qkv + (size_t)unit * T * DH : qkv + (size_t)b * T * 3 * D + head * DH;
-        const float* kb = head_major ? qb + hm_which : qb + D;
-        const float* vb = head_major ? kb + hm_which : kb + D;
-        const int rstride = head_major ? DH : 3 * D;
-        // ---- K, V rows -> registers (one pass), the unit's maxima, then scaled, split and stored
-        float4 kr[NPC], vr[NPC];
-        float mk = 0.0f, mv = 0.0f;
+        qb = head_major ? qkv + (size_t)u * T * DH : qkv + (size_t)b * T * 3 * D + head * DH;
+        kb = head_major ? qb + hm_which : qb + D;
+        vb = head_major ? kb + hm_which : kb + D;
+    };
+    const int rstride = head_major ? DH : 3 * D;
+    auto fetch_kv = [&](int u) {
+        const float *qb, *kb, *vb;
+        unit_ptrs(u, qb, kb, vb);
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int i = tid + 256 * j;
@@ -84,10 +87,42 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
                 const int t = i / (DH / 4), c = 4 * (i - t * (DH / 4));
                 kr[j] = *reinterpret_cast<const float4*>(kb + (size_t)t * rstride + c);
                 vr[j] = *reinterpret_cast<const float4*>(vb + (size_t)t * rstride + c);
-                mk = fmaxf(mk, fmaxf(fmaxf(fabsf(kr[j].x), fabsf(kr[j].y)), fmaxf(fabsf(kr[j].z), fabsf(kr[j].w))));
-                mv = fmaxf(mv, fmaxf(fmaxf(fabsf(vr[j].x), fabsf(vr[j].y)), fmaxf(fabsf(vr[j].z), fabsf(vr[j].w))));
             }
         }
+    };
+    // the thread's share of max |K|, max |V| of the rows in its registers.  Taken (= the loads waited for) BEFORE the previous
+    // unit's output stores are issued: hipcc waits for loop-carried loads with s_waitcnt vmcnt(0), which on gfx9 covers stores too
+    float mk = 0.0f, mv = 0.0f;
+    auto local_max = [&]() {
+        mk = 0.0f; mv = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
+            mk = fmaxf(mk, fmaxf(fmaxf(fabsf(kr[j].x), fabsf(kr[j].y)), fmaxf(fabsf(kr[j].z), fabsf(kr[j].w))));
+            mv = fmaxf(mv, fmaxf(fmaxf(fabsf(vr[j].x), fabsf(vr[j].y)), fmaxf(fabsf(vr[j].z), fabsf(vr[j].w))));
+        }
+    };
+    if ((int)blockIdx.x < units) { fetch_kv((int)blockIdx.x); local_max(); }
+    for (int unit = (int)blockIdx.x; unit < units; unit += (int)gridDim.x) {
+        const int b = unit / n_head, head = unit - b * n_head;
+        const float *qb, *kb, *vb;
+        unit_ptrs(unit, qb, kb, vb);
+        // the lane's query row (dims 16 kb + 8 h + e) is requested first: it lands while K and V are staged
+        const int qt = wave;                                   // T <= 128: at most four query tiles
+        const int query = 32 * qt + n;
+        float qv[NKB][8];
+        if (qt < NTq) {
+            const float* qrow = qb + (size_t)min(query, T - 1) * rstride;
+#pragma unroll
+            for (int k2 = 0; k2 < NKB; ++k2)
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const int c = 16 * k2 + 8 * h + 4 * e4;
+                    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < DH) q4 = *reinterpret_cast<const float4*>(qrow + c);      // DH % 4 == 0: all four in or out
+                    qv[k2][4 * e4] = q4.x; qv[k2][4 * e4 + 1] = q4.y; qv[k2][4 * e4 + 2] = q4.z; qv[k2][4 * e4 + 3] = q4.w;
+                }
+        }
+        // ---- the unit's maxima, then K, V scaled, split and stored
         mk = wave_max(mk); mv = wave_max(mv);
         __syncthreads();                                       // everyone has left the previous unit's rows (and `red`)
         if (lane == 0) { red[wave] = mk; red[4 + wave] = mv; }
@@ -121,24 +156,18 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
             }
         }
         __syncthreads();
-        const int qt = wave;                                   // T <= 128: at most four query tiles
+        const bool has_next = unit + (int)gridDim.x < units;
+        if (qt >= NTq && has_next) { fetch_kv(unit + (int)gridDim.x); local_max(); }
         if (qt < NTq) {
-            // ---- the lane's query row: dims 16 kb + 8 h + e, scaled by 1/sqrt(dh) and by the row's own power of two, split
-            const int query = 32 * qt + n;
-            const float* qrow = qb + (size_t)min(query, T - 1) * rstride;
-            float qv[NKB][8];
+            // ---- the query row scaled by 1/sqrt(dh) and by the row's own power of two, split (waits for the row: the only loads
+            // in flight), THEN the next unit's K, V rows are requested
             float mq = 0.0f;
 #pragma unroll
             for (int k2 = 0; k2 < NKB; ++k2)
 #pragma unroll
-                for (int e4 = 0; e4 < 2; ++e4) {
-                    const int c = 16 * k2 + 8 * h + 4 * e4;
-                    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c < DH) q4 = *reinterpret_cast<const float4*>(qrow + c);      // DH % 4 == 0: all four in or out
-                    qv[k2][4 * e4] = q4.x * scale; qv[k2][4 * e4 + 1] = q4.y * scale; qv[k2][4 * e4 + 2] = q4.z * scale; qv[k2][4 * e4 + 3] = q4.w * scale;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mq = fmaxf(mq, fabsf(qv[k2][4 * e4 + e]));
-                }
+                for (int e = 0; e < 8; ++e) { qv[k2][e] *= scale; mq = fmaxf(mq, fabsf(qv[k2][e])); }
+            asm volatile("" ::: "memory");
+            if (has_next) fetch_kv(unit + (int)gridDim.x);
             mq = fmaxf(mq, __shfl_xor(mq, 32, 64));
             const float sQ = pow2_scale_to_2p14(mq);
             u32x4 qh[NKB], ql[NKB];
@@ -219,6 +248,8 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
                         }
                     }
                 }
+            if (has_next) local_max();
+            asm volatile("" ::: "memory");
             // ---- out[query][head dims 32 mt + 8 g + 4 half + 0..3]
             if (query < T) {
                 const float inv = 1.0f / (den * 16384.0f * sV);

@@ -132,6 +132,10 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
     if (f == 0 && lane < 32) reinterpret_cast<float*>(base + ffn_x3_w1_bytes(D, NT) + (size_t)NOB * 2 * NT * 1024)[lane] = b1[32 * hb + lane];
 }
 
+// (Measured and not kept for the two-term form: 256 rows per workgroup on eight waves, two per SIMD, each running product -
+// epilogue - product in turn so that they cover each other's issue stalls - the lone in-order wave here spends a third of its
+// cycles in them, SQ_WAIT_INST_ANY 50 M of 146 M.  At D = 144 the 80 output accumulators + 72 X-fragment registers + the
+// epilogue's temporaries do not fit 256 registers: 59 spilled, 0.315 ms against 0.320.)
 template <int D16, bool H2>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;

@@ -197,25 +197,32 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
                     }
                 }
             }
-            // ---- softmax over the keys (register 4g + q of tile kt = key 32 kt + 8 g + 4 half + q), in the exp2 domain; the
-            // scores come back to the true scale with one factor per lane (its query's) folded into log2 e
+            // ---- softmax over the keys (register 4g + q of tile kt = key 32 kt + 8 g + 4 half + q), in the exp2 domain.  The raw
+            // accumulators are sK sQ times the scores: the maximum is taken on them (the factor is positive), and one fma per score
+            // brings it to the true scale, subtracts the maximum and adds 14 - the probabilities leave exp2 already times 2^14, the
+            // scale of their binary16 split (the denominator carries the same factor: exact, undone at the end).
             const float unS = 1.4426950408889634f / (sK * sQ);
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (32 * kt + 32 > T) {                          // (uniform) only the tile that straddles T has keys to mask
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3);
-                    st[kt][r] = key < T ? st[kt][r] * unS : -INFINITY;
-                    mx = fmaxf(mx, st[kt][r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3);
+                        st[kt][r] = key < T ? st[kt][r] : -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float off = 14.0f - mx * unS;
             float den = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+                    st[kt][r] = __builtin_amdgcn_exp2f(fmaf(st[kt][r], unS, off));
                     den += st[kt][r];
                 }
             den += __shfl_xor(den, 32, 64);
@@ -234,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
 #pragma unroll
                         for (int e2 = 0; e2 < 4; ++e2) {
                             uint32_t hh, ll;
-                            nww_split2h(st[kt][8 * j + 2 * e2] * 16384.0f, st[kt][8 * j + 2 * e2 + 1] * 16384.0f, hh, ll);
+                            nww_split2h(st[kt][8 * j + 2 * e2], st[kt][8 * j + 2 * e2 + 1], hh, ll);
                             ph[e2] = hh; pl[e2] = ll;
                         }
                         const f16x8 bh = __builtin_bit_cast(f16x8, ph), bl = __builtin_bit_cast(f16x8, pl);
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
             asm volatile("" ::: "memory");
             // ---- out[query][head dims 32 mt + 8 g + 4 half + 0..3]
             if (query < T) {
-                const float inv = 1.0f / (den * 16384.0f * sV);
+                const float inv = 1.0f / (den * sV);             // (den and the products both carry the probabilities' 2^14)
                 float* op = out + ((size_t)b * T + query) * D + head * DH;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)

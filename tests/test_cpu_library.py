@@ -180,3 +180,49 @@ def test_spec_and_macs():
     with pytest.raises(ValueError):
         HeadConfig("lstm", (16, 96))
     assert FrontendConfig().n_frames(16000) == 101 and FrontendConfig(center=False).n_frames(16000) == 98
+
+
+def test_f16x3_split_arithmetic_claims():
+    """The claims csrc/split_h2.h and DESIGN 4.2c make about the two-term binary16 split, checked in numpy (no GPU): for v inside
+    the binary16 range, hi = RN16(v), lo = RN16(v - hi): (i) v - hi is exact in float32; (ii) |v - (hi + lo)| <= 2^-23 |v| as long as
+    lo keeps all its bits (|v| >= 2^-2; below that the error is an absolute 2^-25), and exactly 0 for at least a third of the values; (iii) every partial product of two terms is
+    exact in float32 (11 x 11 significant bits); (iv) the dropped lo*lo is < 2^-22 of the product; (v) scaling by a power of two
+    commutes with the split; (vi) a dot product from the three partial products is as close to exact as the float32 one."""
+    rng = np.random.default_rng(7)
+    v = (rng.standard_normal(200000) * np.exp(rng.uniform(-2.0, 9.0, 200000))).astype(np.float32)
+    small = v[np.abs(v) < 0.25]
+    hs0 = small.astype(np.float16); ls0 = (small - hs0.astype(np.float32)).astype(np.float16)
+    assert (np.abs(small.astype(np.float64) - hs0.astype(np.float64) - ls0.astype(np.float64)) <= 2.0 ** -25).all()
+    v = v[(np.abs(v) < 60000.0) & (np.abs(v) >= 0.25)]
+    hi = v.astype(np.float16)
+    r = v - hi.astype(np.float32)
+    assert np.array_equal(r.astype(np.float64), v.astype(np.float64) - hi.astype(np.float64))          # (i)
+    lo = r.astype(np.float16)
+    err = np.abs(v.astype(np.float64) - (hi.astype(np.float64) + lo.astype(np.float64)))
+    assert (err <= 2.0 ** -23 * np.abs(v.astype(np.float64))).all()                                     # (ii)
+    assert (err == 0).mean() > 1 / 3
+    w = (rng.standard_normal(v.size) * 100).astype(np.float32)
+    wh = w.astype(np.float16); wl = (w - wh.astype(np.float32)).astype(np.float16)
+    for a, b in ((hi, wh), (hi, wl), (lo, wh)):
+        p32 = a.astype(np.float32) * b.astype(np.float32)
+        assert np.array_equal(p32.astype(np.float64), a.astype(np.float64) * b.astype(np.float64))      # (iii)
+    prod = np.abs(v.astype(np.float64) * w.astype(np.float64))
+    ok = prod > 0
+    assert (np.abs(lo.astype(np.float64) * wl.astype(np.float64))[ok] < 2.0 ** -22 * prod[ok]).all()   # (iv)
+    s = np.float32(2.0 ** -5)
+    vs = v * s
+    hs = vs.astype(np.float16)
+    keep = np.abs(vs) >= 0.25
+    assert np.array_equal(hs[keep].astype(np.float32), (hi.astype(np.float32) * s)[keep])               # (v)
+    K = 4096
+    a = rng.standard_normal((64, K)).astype(np.float32) * 37.0
+    b = rng.standard_normal((K,)).astype(np.float32) * 0.03
+    exact = a.astype(np.float64) @ b.astype(np.float64)
+    sa, sb = np.float32(2.0 ** 6), np.float32(2.0 ** 17)
+    ah = (a * sa).astype(np.float16); al = (a * sa - ah.astype(np.float32)).astype(np.float16)
+    bh = (b * sb).astype(np.float16); bl = (b * sb - bh.astype(np.float32)).astype(np.float16)
+    f = lambda x: x.astype(np.float32)
+    acc = (f(al) @ f(bh) + f(ah) @ f(bl) + f(ah) @ f(bh)) * np.float32(1.0 / (sa * sb))
+    e3 = np.abs(acc.astype(np.float64) - exact).max()
+    e32 = np.abs((a @ b).astype(np.float64) - exact).max()
+    assert e3 <= 2.0 * e32 + 1e-6, (e3, e32)                                                            # (vi)

@@ -429,6 +429,9 @@ __global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __res
 // (pooling, splitting: ~110 instructions per 6 MFMAs), conv2's MFMA-bound, and one after the other the matrix pipe is busy 45 % of
 // an item - but beside a wave that issues MFMAs back to back the VALU wave ran 2.4 k clocks per group instead of 1.2 k and set the
 // pace: 12.5 k clocks per third of a clip against 2 x 16.3 k per clip here (0.247 ms against 0.233; tools/ubench/trunk_trace.hip).
+// With the roles swapped - conv1 on waves 0-3, the OLDER half that the SIMD's issue arbitration favours - 0.230 against 0.223, and
+// s_setprio 2 on the conv1 waves changes nothing: one after the other or side by side, the launch takes about the SUM of its matrix
+// time (0.10 ms at the clock it runs at) and its VALU time (0.09 ms).
 template <int ACT, int PRODUCTS, bool BN>
 __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
     using AR = TbA<PRODUCTS>;

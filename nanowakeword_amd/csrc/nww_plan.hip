@@ -185,6 +185,27 @@ double f16_layer_bound(const std::vector<float>& w, int Cout, int K, const std::
     return worst;
 }
 
+// A tensor's plan-time range: a BOUND on its magnitude (what the scale is derived from) and a rough TYPICAL magnitude.  Two binary16
+// terms hold 22-23 bits of a value down to 2^-17 of the scaled bound; a bound that is more pessimistic than that against the values
+// that matter would cost precision silently - so a layer takes the two-term form only when bound <= 2^16 typ (typ-sized values then
+// sit at >= 2^-1 after scaling, one bit above where `lo` starts to lose bits), and otherwise stays on
+// the three-term bf16 form (which has float32's range and needs no bound).  typ: the head's features ~ 32 (dB values), a layer's
+// output ~ sqrt(sum_k w^2) typ_in (uncorrelated terms; |folded-BN alpha| applied) - order-of-magnitude, which is all the guard needs.
+struct F16Range {
+    double bound = 0.0, typ = 0.0;
+    bool ok() const { return bound > 0.0 && typ > 0.0 && bound <= typ * 65536.0; }
+};
+const F16Range F16_FEATURES{NWW_F16_FEATURE_BOUND, 32.0};
+double f16_layer_typ(const std::vector<float>& w, int Cout, int K, const std::vector<float>& al, bool has_bn, double typ_in) {
+    double acc = 0;
+    for (int c = 0; c < Cout; ++c) {
+        double q = 0;
+        for (int k = 0; k < K; ++k) q += (double)w[(size_t)c * K + k] * (double)w[(size_t)c * K + k];
+        acc += std::sqrt(q) * (has_bn ? std::fabs((double)al[c]) : 1.0);
+    }
+    return acc / (Cout > 0 ? Cout : 1) * typ_in;
+}
+
 // source selector for a step input: -1 = head input x, -2 = emb, -3 = hid, >=0 workspace buffer
 inline const float* src(Run& r, int id) { return id == -1 ? r.x : id == -2 ? r.emb : id == -3 ? r.hid : r.buf[id]; }
 inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid : id == -4 ? r.logits : r.buf[id]; }
@@ -193,7 +214,8 @@ inline float* dst(Run& r, int id) { return id == -2 ? r.emb : id == -3 ? r.hid :
 void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int rows_per_clip, int N, int K,
               const float* W, const float* bias, int act, const float* alpha = nullptr, const float* beta = nullptr,
               int res_id = 99, float rscale = 1.f, bool* a_blocked_inout = nullptr, bool feeds_tail = false, bool feeds_ln = false,
-              double a_bound = 0.0, bool a_bound_assumed = false) {
+              F16Range a_range = F16Range{}, bool a_bound_assumed = false) {
+    const double a_bound = a_range.ok() ? a_range.bound : 0.0;
     if (out_id >= 0) p.need(out_id, (size_t)rows_per_clip * N);
     // Contractions run on the bf16 matrix cores by exact operand splitting (gemm_x3.hip) where that kernel wins -
     // measured per shape on the Conformer / GRU / CNN heads at full batch (ms, split-operand vs float32 MFMA):
@@ -312,8 +334,9 @@ static int trunk_fits(int C1, int H, int W) { int per_cu = 0; return trunk_pick_
 bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C1, int C2, int H, int W,
                const float* w1, const float* b1, const float* al1, const float* be1, const float* w2,
                const float* b2, const float* al2, const float* be2, int act, const bool* out_blocked = nullptr,
-               double in_bound = 0.0, double* out_bound = nullptr) {
-    if (out_bound) *out_bound = 0.0;
+               F16Range in_range = F16Range{}, F16Range* out_range = nullptr) {
+    if (out_range) *out_range = F16Range{};
+    const double in_bound = in_range.ok() ? in_range.bound : 0.0;
     static const int enabled = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
     if (!enabled || C1 != 16 || C2 != 32 || H < 4 || W < 4 || trunk_fits(C1, H, W) == 0) return false;
     p.need(out_id, (size_t)C2 * (H / 4) * (W / 4));
@@ -326,20 +349,22 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
         if (hipMalloc(&packed, trunk_b_packed_bytes()) != hipSuccess) return false;
         // NWW_ARITH_F16X3: two binary16 terms per operand when the input is bounded; the scales from bounds on conv1's / conv2's outputs
         float f_in = 0.0f, f_s1 = 0.0f, f_w1 = 0.0f, f_w2 = 0.0f;
-        double bound2 = 0.0;
+        double bound2 = 0.0, typ2 = 0.0;
         if (p.h->f16 && x3 == 6 && in_bound > 0.0 && (act == ACT_RELU || act == ACT_GELU || act == ACT_SILU)) {
             const auto hw1 = f16_fetch(p.h, w1, (size_t)C1 * 9), hw2 = f16_fetch(p.h, w2, (size_t)C2 * C1 * 9);
             const auto hb1 = f16_fetch(p.h, b1, C1), hb2 = f16_fetch(p.h, b2, C2);
             const auto ha1 = f16_fetch(p.h, al1, C1), he1 = f16_fetch(p.h, be1, C1), ha2 = f16_fetch(p.h, al2, C2), he2 = f16_fetch(p.h, be2, C2);
             const double bound1 = f16_layer_bound(hw1, C1, 9, hb1, b1 != nullptr, ha1, he1, al1 != nullptr, in_bound);
             bound2 = f16_layer_bound(hw2, C2, C1 * 9, hb2, b2 != nullptr, ha2, he2, al2 != nullptr, bound1);
-            f_in = f16_scale(in_bound); f_s1 = f16_scale(bound1); f_w1 = f16_wscale(hw1); f_w2 = f16_wscale(hw2);
+            const F16Range r1{bound1, f16_layer_typ(hw1, C1, 9, ha1, al1 != nullptr, in_range.typ)};
+            typ2 = f16_layer_typ(hw2, C2, C1 * 9, ha2, al2 != nullptr, r1.typ);
+            if (r1.ok()) { f_in = f16_scale(in_bound); f_s1 = f16_scale(bound1); f_w1 = f16_wscale(hw1); f_w2 = f16_wscale(hw2); }
         }
         const bool f16 = f_in > 0.0f && f_s1 > 0.0f && f_w1 > 0.0f && f_w2 > 0.0f;
         if ((f16 ? launch_trunk_b_pack_f16(w1, w2, static_cast<unsigned char*>(packed), f_w1, f_w2, p.h->own_stream)
                  : launch_trunk_b_pack(w1, w2, static_cast<unsigned char*>(packed), p.h->own_stream)) != hipSuccess) { (void)hipFree(packed); return false; }
         p.h->packed_weights.push_back(packed);
-        if (f16 && out_bound) *out_bound = bound2;
+        if (f16 && out_range) *out_range = F16Range{bound2, typ2};
         const int products = f16 ? 3 : x3;
         if (in_id == -1 && !p.h->e2e_transposed) p.h->x_stride_ok = true;                   // this step reads the head input with any clip stride
         p.add("trunk_x3:" + name + (f16 ? " [f16x3]" : ""), [=](Run& r) {
@@ -369,8 +394,9 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
                    int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0, bool* ring_in = nullptr,
-                   double in_bound = 0.0, double* out_bound = nullptr) {
-    if (out_bound) *out_bound = 0.0;
+                   F16Range in_range = F16Range{}, F16Range* out_range = nullptr) {
+    if (out_range) *out_range = F16Range{};
+    const double in_bound = in_range.ok() ? in_range.bound : 0.0;
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
         conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
@@ -391,9 +417,11 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
         if (p.h->f16 && in_bound > 0.0) {
             const auto hw = f16_fetch(p.h, w, (size_t)Cout * Cin * 9);
             h2_in = f16_scale(in_bound); h2_w = f16_wscale(hw);
-            if (out_bound && h2_in > 0.0f && h2_w > 0.0f)
-                *out_bound = f16_layer_bound(hw, Cout, Cin * 9, f16_fetch(p.h, bias, Cout), bias != nullptr, f16_fetch(p.h, alpha, Cout),
-                                             f16_fetch(p.h, beta, Cout), alpha != nullptr, in_bound);
+            if (out_range && h2_in > 0.0f && h2_w > 0.0f) {
+                const auto hal = f16_fetch(p.h, alpha, Cout);
+                *out_range = F16Range{f16_layer_bound(hw, Cout, Cin * 9, f16_fetch(p.h, bias, Cout), bias != nullptr, hal, f16_fetch(p.h, beta, Cout), alpha != nullptr, in_bound),
+                                      f16_layer_typ(hw, Cout, Cin * 9, hal, alpha != nullptr, in_range.typ)};
+            }
         }
         const bool h2 = h2_in > 0.0f && h2_w > 0.0f;
         p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name + (h2 ? " [f16x3]" : ""), [=](Run& r) {
@@ -605,7 +633,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
             static const int body_on = [] { const char* e = getenv("NWW_DNN_BODY"); return e ? atoi(e) : 1; }();
             if (tail_on && body_on && L <= 256 && nb <= 4 && tail_supported(L, E)) {
-                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND, true);
+                add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, F16_FEATURES, true);
                 p.dnn_body = true;
                 p.dnn_ln0_w = p.W("model.layernorm1.weight"); p.dnn_ln0_b = p.W("model.layernorm1.bias");
                 p.dnn_n_mid = nb;
@@ -617,7 +645,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 set_tail(p, "layernorm1+blocks+last_layer", 0, L, p.W("model.last_layer.weight"), p.W("model.last_layer.bias"));
                 break;
             }
-            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, NWW_F16_FEATURE_BOUND, true);
+            add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, F16_FEATURES, true);
             {
                 const float *lw1 = p.W("model.layernorm1.weight"), *lb1 = p.W("model.layernorm1.bias");
                 p.add("layernorm:layernorm1", [=](Run& r) {
@@ -646,10 +674,10 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int H2 = T / 4, W2 = F / 4;
             h->trunk_blocked = (h->conv_products == 6 || h->conv_products == 9) && trunk_b_pick_strips(T, F) > 0 &&
                                (W2 % 4) == 0 && ((H2 * W2) % 4) == 0 && ((32 * H2 * W2) % 32) == 0;
-            double a2_bound = 0.0;                // NWW_ARITH_F16X3: a bound on the trunk's output, fc1's operand
+            F16Range a2_bound;                    // NWW_ARITH_F16X3: the range of the trunk's output, fc1's operand
             const bool fused = add_trunk(p, "conv1+pool+conv2+pool", -1, 1, 16, 32, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr,
                                          p.W("model.conv2.weight"), p.W("model.conv2.bias"), nullptr, nullptr, act, &h->trunk_blocked,
-                                         NWW_F16_FEATURE_BOUND, &a2_bound);
+                                         F16_FEATURES, &a2_bound);
             if (!fused) {
                 h->trunk_blocked = false;
                 add_conv(p, "conv1", -1, 0, 1, 16, T, F, p.W("model.conv1.weight"), p.W("model.conv1.bias"), nullptr, nullptr, act, 1);
@@ -689,10 +717,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                 });
                 const int h3 = Ht / 4, w3 = Wt / 4;           // (25, 16): AdaptiveAvgPool2d((1,4))'s windows run along the FRAMES, here y
                 const int sw4 = h3 / 4, kw4 = h3 - 3 * sw4;
-                double tbound = 0.0;                          // NWW_ARITH_F16X3: a bound on the trunk's output, the third conv's operand
+                F16Range tbound;                              // NWW_ARITH_F16X3: the range of the trunk's output, the third conv's operand
                 const bool ok = add_trunk(p, "conv_block.0-7 (transposed plane)", -1, 1, 16, 32, Ht, Wt, wts[0], p.W("model.conv_block.0.bias"),
                                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), wts[1], p.W("model.conv_block.4.bias"),
-                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &tbound) &&
+                                          p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, F16_FEATURES, &tbound) &&
                                 h->plan.back().name.rfind("trunk_x3:", 0) == 0 && h3 >= 4 &&
                                 add_conv_mfma(p, "model.conv_block.8 (transposed plane)", 1, 0, 32, 64, h3, w3, wts[2], p.W("model.conv_block.8.bias"),
                                               p.W("model.conv_block.9.alpha"), p.W("model.conv_block.9.beta"), act, 0, kw4, sw4, 4, nullptr, 1, nullptr, tbound);
@@ -709,10 +737,10 @@ extern "C" int nww_finalize(nww_handle* h) {
             int cin = 1, hh = Hh, ww = Ww, cur = -1;
             int first = 0;
             bool fused_pool = false;
-            double cbound = 0.0;                              // NWW_ARITH_F16X3: bound on the current stage's input (0: unknown)
+            F16Range cbound;                                  // NWW_ARITH_F16X3: range of the current stage's input (empty: unknown)
             if (add_trunk(p, "conv_block.0-7", -1, 1, 16, 32, Hh, Ww, p.W("model.conv_block.0.weight"), p.W("model.conv_block.0.bias"),
                           p.W("model.conv_block.1.alpha"), p.W("model.conv_block.1.beta"), p.W("model.conv_block.4.weight"),
-                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &cbound)) {
+                          p.W("model.conv_block.4.bias"), p.W("model.conv_block.5.alpha"), p.W("model.conv_block.5.beta"), act, nullptr, F16_FEATURES, &cbound)) {
                 first = 2; cin = 32; hh = Hh / 4; ww = Ww / 4; cur = 1;
             }
             for (int i = first; i < 3; ++i) {
@@ -728,7 +756,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     }
                 }
                 {
-                    double nb = 0.0;
+                    F16Range nb;
                     if (!add_conv_mfma(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2,
                                        0, 0, 0, nullptr, 0, nullptr, cbound, &nb))
                         add_conv(p, cw, cur, out, cin, ch[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, i < 2);
@@ -756,12 +784,12 @@ extern "C" int nww_finalize(nww_handle* h) {
             int cin = 1, hh = T, ww = F, cur = -1;
             int first = 0;
             bool seq_written = false;
-            double cbound = 0.0;                              // NWW_ARITH_F16X3: bound on the current stage's input (0: unknown)
+            F16Range cbound;                                  // NWW_ARITH_F16X3: range of the current stage's input (empty: unknown)
             const size_t steps_before = h->plan.size();
             if (c.n_crnn_channels >= 2 && c.crnn_channels[0] == 16 && c.crnn_channels[1] == 32 &&
                 add_trunk(p, "cnn.0-7", -1, 1, 16, 32, T, F, p.W("model.cnn.0.weight"), p.W("model.cnn.0.bias"), p.W("model.cnn.1.alpha"),
                           p.W("model.cnn.1.beta"), p.W("model.cnn.4.weight"), p.W("model.cnn.4.bias"), p.W("model.cnn.5.alpha"),
-                          p.W("model.cnn.5.beta"), act, nullptr, NWW_F16_FEATURE_BOUND, &cbound)) {
+                          p.W("model.cnn.5.beta"), act, nullptr, F16_FEATURES, &cbound)) {
                 first = 2; cin = 32; hh = T / 4; ww = F / 4; cur = 1;
             }
             for (int i = first; i < c.n_crnn_channels; ++i) {
@@ -771,7 +799,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 bool seq = i == c.n_crnn_channels - 1;
                 // the stage right behind a fused split-operand trunk may take its input from the streaming rings (nww_stream.hip)
                 bool ring = i == 2 && first == 2 && h->plan.size() == steps_before + 1 && h->plan.back().name.rfind("trunk_x3:", 0) == 0 && ((F / 4) % 4) == 0;
-                double nb = 0.0;
+                F16Range nb;
                 const bool mf = add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring, cbound, &nb);
                 cbound = nb;
                 if (!mf) {

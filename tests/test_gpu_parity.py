@@ -389,6 +389,16 @@ def test_f16x3_scales_clamp_and_activations(hip):
         ref = oracle.model_forward(feats, sd, cfg).ravel()
         assert np.abs(lg - ref).max() <= FEAT_LOGIT_ATOL, ((e1, e2, e3), float(np.abs(lg - ref).max()))
         m.close()
+    # (iv) a layer whose plan-time bound is out of all proportion to its typical magnitude (here: a bias of 1e7 on conv1) is not
+    # given to the two-term form - the bound would push the values that matter below binary16's precision - and runs on three bf16 terms
+    sd = {k: v.copy() for k, v in base.items()}
+    sd["model.conv1.bias"] = (sd["model.conv1.bias"] + np.float32(1e7)).astype(np.float32)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith="f16x3")
+    assert "trunk_x3:" in m.describe_plan() and "[f16x3]" not in m.describe_plan().split("gemm:")[0], m.describe_plan()
+    lg, _ = m.forward_features(feats)
+    ref = oracle.model_forward(feats, sd, cfg, dtype=np.float64).ravel()
+    assert np.abs(lg - ref).max() <= 1e-5 * np.abs(ref).max(), float(np.abs(lg - ref).max() / np.abs(ref).max())
+    m.close()
     m = HipModel(cfg, FrontendConfig(), state_dict=base, conv_arith="f16x3")
     wild = feats.copy()
     wild[0] *= 1e6; wild[1, 3, 5] = 3e38; wild[2, :, 0] = -1e9

@@ -531,6 +531,19 @@ def main():
             # back-to-back bf16 MFMAs with toggling operands on all 256 CUs sustain 5.63e10 wave-instructions per second of the
             # nominal 7.68e10 (1.85 GHz at the package's power limit; tools/ubench/power_mix.hip mode 4)
             roofline["frac_of_sustained_matrix_rate"] = round(achieved / peak / (5.63 / 7.68), 4)
+            # how busy the two pipes the kernel is limited by actually are, from the committed PMC pass of this kernel at this batch
+            # (profiles/traffic.json) and the live launch time: with the two-term arithmetic the matrix pipe is no longer the only
+            # limiter - the launch takes about the SUM of its matrix time and its VALU time
+            try:
+                ent = json.load(open(tp)).get(name) or {}
+                if ent.get("batch") == B and ent.get("sq_insts_mfma"):
+                    cyc = 1024 * dom[1] * 1e-3 * 2.4e9
+                    roofline["mfma_busy_frac_at_2.4GHz"] = round(ent["sq_insts_mfma"] * 32 / cyc, 4)
+                    roofline["valu_issue_frac_at_2.4GHz"] = round(ent["sq_insts_valu"] * 4 / cyc, 4)
+                    roofline["pipe_counters_source"] = "SQ_INSTS_MFMA x 32 clocks, SQ_INSTS_VALU x 4 clocks (profiles/traffic.json) / (1024 SIMDs x avg_launch_ms x 2.4 GHz)"
+            except Exception:
+                pass
+            roofline["vs_f32_mfma_peak"] = round(achieved / PEAK_F32_TFLOPS, 3)      # the float32 products per second against the chip's float32 matrix peak
         fe_row = [r for r in per if r[0].startswith("frontend")]
         extra = {}
         if fe_row:

@@ -129,7 +129,9 @@ struct GruArgs {
     const float* xg; const float* w_hh; const float* b_hh;
     float* seq_out; int ld_seq; float* last_out; int ld_last; int col_off;
     int B, T, H, reverse, steps;
-    int products = 0;      // 6 / 9: recurrent product from split operands on the bf16 matrix cores (rnn_x3.hip), 0: float32 MFMA
+    int products = 0;      // 6 / 9: recurrent product from split operands on the bf16 matrix cores (rnn_x3.hip), 0: float32 MFMA;
+                           // 3: two binary16 terms per operand (h times 2^14 - |h| <= 1 - and W_hh times w_scale, a power of two)
+    float w_scale = 1.0f;
     // rnn_x3 only: the FIRST step of the opposite direction (all that rnn_out[:, -1] needs of it; h = 0, so no recurrent product)
     // computed in the same launch from its gate pre-activations xg2 [B][xg2_bstride] and recurrent bias -> last_out[:, col_off2 + j]
     const float* xg2 = nullptr; size_t xg2_bstride = 0; const float* b_hh2 = nullptr; int col_off2 = 0;

@@ -471,7 +471,10 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                     int seqA, int seqB, int last_id, int G = 3) {
     p.need(xg_id, (size_t)(T + 1) * G * H);                  // + one row per clip: the reverse direction's last-frame projection
     p.need(last_id, (size_t)2 * H);
-    const int products = p.h->conv_products;                 // the recurrent product follows the handle's arithmetic switch
+    // the recurrent product follows the handle's arithmetic switch; NWW_ARITH_F16X3: two binary16 terms (|h| <= 1 bounds the one
+    // operand, W_hh's scale comes from the weights)
+    static const int rnn_h2 = [] { const char* e = getenv("NWW_RNN_H2"); return e ? atoi(e) : 1; }();
+    const int products = (p.h->f16 && rnn_h2) ? 3 : p.h->conv_products;
     GruArgs probe; probe.H = H; probe.products = products;
     probe.w_hh = p.W(prefix + ".weight_hh_l" + std::to_string(layers - 1));       // the pointer the fused launch will really get (alignment test)
     const bool x3 = probe.w_hh != nullptr && rnn_x3_enabled(probe);
@@ -521,9 +524,11 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
             const float* bhh_f = fold ? p.W(prefix + ".bias_hh_l" + std::to_string(l)) : bhh;
             const std::string nm = fold ? (G == 4 ? "lstm:" : "gru:") + prefix + "_l" + std::to_string(l) + " + first reverse step"
                                         : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
-            p.add(nm, [=](Run& r) {
+            const float w_scale = products == 3 ? f16_wscale(f16_fetch(p.h, whh_f, (size_t)G * H * H)) : 1.0f;
+            const int products_l = (products == 3 && !(w_scale > 0.0f)) ? p.h->conv_products : products;
+            p.add(nm + (products_l == 3 && x3 && ldw == 0 ? " [f16x3]" : ""), [=](Run& r) {
                 GruArgs a;
-                a.products = products;
+                a.products = products_l; a.w_scale = w_scale;
                 a.xg = r.buf[xg_id]; a.w_hh = whh_f; a.b_hh = bhh_f;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
                 a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H;

@@ -15,10 +15,15 @@
 // Clips are independent rows of every product: results do not depend on batch size or position.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// NP = 3 ("f16x3"): W_hh times a plan-time power of two and h times 2^14 (|h| <= 1: the recurrent operand needs no bound from the
+// plan) as TWO binary16 terms each (split_h2.h), three partial products per k-block on v_mfma_f32_16x16x32_f16 - 72 instead of
+// 144 MFMAs per step at H = 128, two term planes of h instead of three, and the scaling back is the fma that adds b_hh.
 #include "layers.h"
+#include "split_h2.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 __device__ __forceinline__ void split3r(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
@@ -37,16 +42,19 @@ template <int G, int H, int NP, int NB>
 __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a) {
     constexpr int KS = H / 32;                                // MFMA k-blocks
     constexpr int LDP = H + 8;                                // bf16 per LDS row: +16 bytes keeps the 16-byte fragment reads conflict-free
+    constexpr bool H2 = NP == 3;
+    constexpr int NTM = H2 ? 2 : 3;                           // terms per value
+    const float s_h = 16384.0f, s_w = H2 ? a.w_scale : 1.0f, un = H2 ? 1.0f / (16384.0f * a.w_scale) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_r);       // [3 terms][16 clips][LDP]
+    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_r);       // [terms][16 clips][LDP]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * 16;
     const int j0 = 16 * NB * wave + n;                        // this lane's hidden units j0 + 16 bl (B-operand column, C-layout column)
-    for (int idx = threadIdx.x; idx < 3 * 16 * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
+    for (int idx = threadIdx.x; idx < NTM * 16 * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
 
     // W_hh rows q*H + j, k = 32 ks + 8 g .. + 7 -> B fragments, split once
-    uint4 wf[G][NB][KS][3];
+    uint4 wf[G][NB][KS][NTM];
     float bh[G][NB];
 #pragma unroll
     for (int q = 0; q < G; ++q)
@@ -57,12 +65,20 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
             for (int ks = 0; ks < KS; ++ks) {
                 const float4 v0 = *reinterpret_cast<const float4*>(src + 32 * ks), v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
                 const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                uint32_t hi[8], mid[8], lo[8];
+                if (H2) {
+                    uint32_t hh[4], ll[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split3r(x[e], hi[e], mid[e], lo[e]);
-                wf[q][bl][ks][0] = make_uint4(pack_hi16r(hi[0], hi[1]), pack_hi16r(hi[2], hi[3]), pack_hi16r(hi[4], hi[5]), pack_hi16r(hi[6], hi[7]));
-                wf[q][bl][ks][1] = make_uint4(pack_hi16r(mid[0], mid[1]), pack_hi16r(mid[2], mid[3]), pack_hi16r(mid[4], mid[5]), pack_hi16r(mid[6], mid[7]));
-                wf[q][bl][ks][2] = make_uint4(pack_hi16r(lo[0], lo[1]), pack_hi16r(lo[2], lo[3]), pack_hi16r(lo[4], lo[5]), pack_hi16r(lo[6], lo[7]));
+                    for (int e = 0; e < 4; ++e) nww_split2h(x[2 * e] * s_w, x[2 * e + 1] * s_w, hh[e], ll[e]);
+                    wf[q][bl][ks][0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                    wf[q][bl][ks][NTM - 1] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                } else {
+                    uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split3r(x[e], hi[e], mid[e], lo[e]);
+                    wf[q][bl][ks][0] = make_uint4(pack_hi16r(hi[0], hi[1]), pack_hi16r(hi[2], hi[3]), pack_hi16r(hi[4], hi[5]), pack_hi16r(hi[6], hi[7]));
+                    wf[q][bl][ks][1] = make_uint4(pack_hi16r(mid[0], mid[1]), pack_hi16r(mid[2], mid[3]), pack_hi16r(mid[4], mid[5]), pack_hi16r(mid[6], mid[7]));
+                    wf[q][bl][ks][NTM - 1] = make_uint4(pack_hi16r(lo[0], lo[1]), pack_hi16r(lo[2], lo[3]), pack_hi16r(lo[4], lo[5]), pack_hi16r(lo[6], lo[7]));
+                }
             }
             bh[q][bl] = a.b_hh[q * H + j0 + 16 * bl];
             __builtin_amdgcn_sched_barrier(0);                // one row at a time: all rows' raw loads in flight at once would not fit beside the fragments
@@ -106,14 +122,22 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + 64 * ks), am = *reinterpret_cast<const bf16x8*>(arow + PLANE + 64 * ks),
-                             al = *reinterpret_cast<const bf16x8*>(arow + 2 * PLANE + 64 * ks);
+                             al = *reinterpret_cast<const bf16x8*>(arow + (NTM - 1) * PLANE + 64 * ks);
                 // small terms first, the dominant hi*hi last (gemm_x3.hip's order); every product feeds all of the wave's accumulators
 #define RNN_PROD(AF, WT)                                                                                              \
     _Pragma("unroll") for (int q = 0; q < G; ++q)                                                                     \
         _Pragma("unroll") for (int bl = 0; bl < NB; ++bl)                                                             \
             acc[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF, __builtin_bit_cast(bf16x8, wf[q][bl][ks][WT]), acc[q][bl], 0, 0, 0);
-                if (NP == 9) { RNN_PROD(al, 2) RNN_PROD(al, 1) RNN_PROD(am, 2) }
-                RNN_PROD(am, 1) RNN_PROD(ah, 2) RNN_PROD(al, 0) RNN_PROD(ah, 1) RNN_PROD(am, 0) RNN_PROD(ah, 0)
+#define RNN_PROD_H(AF, WT)                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < G; ++q)                                                                     \
+        _Pragma("unroll") for (int bl = 0; bl < NB; ++bl)                                                             \
+            acc[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, AF), __builtin_bit_cast(f16x8, wf[q][bl][ks][WT]), acc[q][bl], 0, 0, 0);
+                if (H2) { RNN_PROD_H(al, 0) RNN_PROD_H(ah, 1) RNN_PROD_H(ah, 0) }       // lo hi, hi lo, hi hi (al = the second plane here)
+                else {
+                    if (NP == 9) { RNN_PROD(al, 2) RNN_PROD(al, 1) RNN_PROD(am, 2) }
+                    RNN_PROD(am, 1) RNN_PROD(ah, 2) RNN_PROD(al, 0) RNN_PROD(ah, 1) RNN_PROD(am, 0) RNN_PROD(ah, 0)
+                }
+#undef RNN_PROD_H
 #undef RNN_PROD
             }
         }
@@ -127,15 +151,19 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 // rows beyond B repeat the last clip (clamped xg row): straight-line gate arithmetic, only the stores are predicated
                 float hn, cn = 0.0f;
                 if (G == 3) {
-                    const float rg = sigmoid_r(xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
-                    const float zg = sigmoid_r(xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
-                    const float ng = tanh_r(xpf[0][2][bl][r] + rg * (acc[2][bl][r] + bh[2][bl]));
+                    // (two-term form: the accumulators come back to the true scale inside the fma that adds b_hh)
+                    const float a0 = H2 ? fmaf(acc[0][bl][r], un, bh[0][bl]) : acc[0][bl][r] + bh[0][bl];
+                    const float a1 = H2 ? fmaf(acc[1][bl][r], un, bh[1][bl]) : acc[1][bl][r] + bh[1][bl];
+                    const float a2 = H2 ? fmaf(acc[2][bl][r], un, bh[2][bl]) : acc[2][bl][r] + bh[2][bl];
+                    const float rg = sigmoid_r(H2 ? xpf[0][0][bl][r] + a0 : xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
+                    const float zg = sigmoid_r(H2 ? xpf[0][1][bl][r] + a1 : xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
+                    const float ng = tanh_r(xpf[0][2][bl][r] + rg * a2);
                     hn = (1.0f - zg) * ng + zg * hprev[bl][r];
                 } else {
-                    const float ig = sigmoid_r(xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
-                    const float fg = sigmoid_r(xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
-                    const float gg = tanh_r(xpf[0][2][bl][r] + acc[2][bl][r] + bh[2][bl]);
-                    const float og = sigmoid_r(xpf[0][G - 1][bl][r] + acc[G - 1][bl][r] + bh[G - 1][bl]);
+                    const float ig = sigmoid_r(H2 ? xpf[0][0][bl][r] + fmaf(acc[0][bl][r], un, bh[0][bl]) : xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
+                    const float fg = sigmoid_r(H2 ? xpf[0][1][bl][r] + fmaf(acc[1][bl][r], un, bh[1][bl]) : xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
+                    const float gg = tanh_r(H2 ? xpf[0][2][bl][r] + fmaf(acc[2][bl][r], un, bh[2][bl]) : xpf[0][2][bl][r] + acc[2][bl][r] + bh[2][bl]);
+                    const float og = sigmoid_r(H2 ? xpf[0][G - 1][bl][r] + fmaf(acc[G - 1][bl][r], un, bh[G - 1][bl]) : xpf[0][G - 1][bl][r] + acc[G - 1][bl][r] + bh[G - 1][bl]);
                     cn = fg * cprev[bl][r] + ig * gg;
                     hn = og * tanh_r(cn);
                 }
@@ -162,10 +190,16 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                     }
                 }
                 hprev[bl][r] = hn; cprev[bl][r] = cn;
-                uint32_t hi, mid, lo;
-                split3r(hn, hi, mid, lo);
                 uint16_t* d = hp + c * LDP + j;
-                d[0] = (uint16_t)(hi >> 16); d[16 * LDP] = (uint16_t)(mid >> 16); d[2 * 16 * LDP] = (uint16_t)(lo >> 16);
+                if (H2) {
+                    uint32_t hh, ll;
+                    nww_split2h(hn * s_h, 0.0f, hh, ll);
+                    d[0] = (uint16_t)hh; d[16 * LDP] = (uint16_t)ll;
+                } else {
+                    uint32_t hi, mid, lo;
+                    split3r(hn, hi, mid, lo);
+                    d[0] = (uint16_t)(hi >> 16); d[16 * LDP] = (uint16_t)(mid >> 16); d[(NTM - 1) * 16 * LDP] = (uint16_t)(lo >> 16);
+                }
             }
         }
 #pragma unroll
@@ -182,15 +216,16 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 }  // namespace
 
 bool rnn_x3_usable(const GruArgs& a) {
-    return (a.products == 6 || a.products == 9) && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0;
+    return (a.products == 3 || a.products == 6 || a.products == 9) && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0;
 }
 
 hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
     if (!rnn_x3_usable(a) || (gates != 3 && gates != 4)) return hipErrorInvalidValue;
     const dim3 grid((a.B + 15) / 16), block(a.H == 128 ? 256 : 64 * (a.H / 16));
-    const size_t lds = (size_t)3 * 16 * (a.H + 8) * sizeof(uint16_t);
+    const size_t lds = (size_t)(a.products == 3 ? 2 : 3) * 16 * (a.H + 8) * sizeof(uint16_t);
 #define RNN_GO(GV, HV)                                                                                                \
     if (a.products == 9) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 9, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a);  \
+    else if (a.products == 3) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 3, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a); \
     else hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 6, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a);
 #define RNN_H(GV)                                                                                                     \
     switch (a.H) {                                                                                                    \

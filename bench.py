@@ -172,6 +172,8 @@ def config_legs(torch, dev):
             ("C3", "bcresnet head, (101,64), batch 8192 (= 65536 / 8 GPUs), fp32", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, None),
             ("C3_bf16", "bcresnet head, (101,64), batch 8192, bf16 activations between kernels (opt-in act_dtype; tolerance 2e-2)",
              HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, "bf16"),
+            ("C3_f16", "bcresnet head, (101,64), batch 8192, scaled binary16 activations between kernels (opt-in act_dtype; same bytes as bf16, 11 significant bits: 1e-2 on every test clip)",
+             HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, "f16"),
             ("C5", "conformer head, (101,64), batch 2048 (= 16384 / 8 GPUs), MFMA attention", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048, None)):
         sd = synth_state_dict(cfg)
         window, fb = torchaudio_tables(fe)

@@ -92,14 +92,18 @@ typedef struct nww_config {
     /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
        CRNNModel, modules/architectures.py:238-254)                                                               */
     int32_t crnn_rnn_lstm;
-    /* storage type of the activation tensors BETWEEN the head's kernels: NWW_ACT_DTYPE_F32 (default) or NWW_ACT_DTYPE_BF16 (round to
-       nearest even on store; products and accumulation stay float32).  bf16 is an opt-in for the BcResNet head
-       (BASELINE.json config 3 "bf16 activations"): logits then agree with the float32 reference to ~1e-2, not 1e-4.      */
+    /* storage type of the activation tensors BETWEEN the head's kernels: NWW_ACT_DTYPE_F32 (default), NWW_ACT_DTYPE_BF16 (round to
+       nearest even on store; products and accumulation stay float32) or NWW_ACT_DTYPE_F16 (binary16 of value x a power of two
+       fixed per tensor at plan time from a bound on it, round to nearest even, saturating; same bytes and speed as bf16, 11
+       significant bits instead of 8).  Both are opt-ins for the BcResNet head (BASELINE.json config 3 "bf16 activations"):
+       bf16 logits agree with the float32 reference to ~2e-2 on the test clips except all-zero PCM (0.2); f16 logits to ~5e-3 on
+       every clip.  f16 assumes features within +-NWW_F16_FEATURE_BOUND, like NWW_ARITH_F16X3.                               */
     int32_t act_dtype;
     int32_t reserved[4];
 } nww_config;
 #define NWW_ACT_DTYPE_F32 0
 #define NWW_ACT_DTYPE_BF16 1
+#define NWW_ACT_DTYPE_F16 2
 #define NWW_ARITH_DEFAULT 0
 #define NWW_ARITH_F32 1
 #define NWW_ARITH_F16X3 3

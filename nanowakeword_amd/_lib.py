@@ -113,7 +113,7 @@ def load_library():
 
 
 ARITH_CODE = {None: 0, "default": 0, "f32": 1, "f16x3": 3, "bf16x6": 6, "bf16x9": 9}
-ACT_DTYPE_CODE = {None: 0, "f32": 0, "bf16": 1}          # nww_config.act_dtype: storage of the activations between kernels
+ACT_DTYPE_CODE = {None: 0, "f32": 0, "bf16": 1, "f16": 2}          # nww_config.act_dtype: storage of the activations between kernels
 
 
 def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major_features: bool | None = None,
@@ -144,6 +144,6 @@ def make_config(head: HeadConfig, fe: FrontendConfig, device: int = 0, mel_major
         raise ValueError(f"conv_arith must be one of {sorted(k for k in ARITH_CODE if k)}")
     c.conv_arith = ARITH_CODE[conv_arith]
     if act_dtype not in ACT_DTYPE_CODE:
-        raise ValueError("act_dtype must be 'f32' or 'bf16'")
+        raise ValueError("act_dtype must be 'f32', 'bf16' or 'f16'")
     c.act_dtype = ACT_DTYPE_CODE[act_dtype]
     return c

@@ -13,9 +13,13 @@ struct DualArgs {
     // x != nullptr: xs is not read; the shortcut's rows are gathered from the block input x [B][H][W][K] (channels last) at
     // (oy * sh, ox * sw) of pixel m = (b, oy, ox), M = B * Ho * Wo
     const float* x = nullptr; int H = 0, W = 0, Ho = 0, Wo = 0, sh = 1, sw = 1;
-    // bf16 activations (nww_config.act_dtype): d, xs / x and out are bf16 arrays; an activation is then ONE bf16 term, so a
-    // float32 weight needs three products (hi, mid, lo) instead of six
-    int bf16 = 0;
+    // 16-bit activations (nww_config.act_dtype; ACT16_* of split_h2.h).  1 = bf16: d, xs / x and out are bf16 arrays; an activation is
+    // then ONE bf16 term, so a float32 weight needs three products (hi, mid, lo) instead of six.  2 = binary16: the arrays hold
+    // value x the tensor's plan-time power-of-two scale; the weights are packed as TWO binary16 terms of weight x scale
+    // (launch_dual_x3_pack with terms = 2, which also folds 1 / (weight scale x input scale) into the BN factors): two products on
+    // v_mfma_f32_32x32x16_f16; the result times out_mul (= out's scale) is rounded to binary16, saturating.
+    int act16 = 0;
+    float out_mul = 1.0f;
     // mean_out != nullptr (the last block): out is NOT written; the block's output is averaged over the mean_P = Ho * Wo pixels of
     // every clip instead -> mean_out [M / mean_P][N] float32 (BcResNetModel's global average pool, architectures.py:677-678).  The
     // pixel tiling is then clip-aligned (a wave = 32 pixels of ONE clip), so a clip's sums do not depend on its slot in the batch.
@@ -23,11 +27,14 @@ struct DualArgs {
 };
 bool dual_x3_mean_supported(int pixels_per_clip);
 
-// one packed 32-output block: 2 x K/16 x 3 fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps
-__host__ __device__ inline size_t dual_x3_block_bytes(int K) { return ((size_t)2 * (K / 16) * 3072 + 512 + 4095) & ~(size_t)4095; }
+// one packed 32-output block: 2 x K/16 x terms fragments of 1 KB + four 32-float folded-BN vectors, padded to whole 4 KB copy steps
+__host__ __device__ inline size_t dual_x3_block_bytes(int K, int terms = 3) { return ((size_t)2 * (K / 16) * terms * 1024 + 512 + 4095) & ~(size_t)4095; }
 bool dual_x3_supported(int K, int N);
-size_t dual_x3_packed_bytes(int K, int N);
+size_t dual_x3_packed_bytes(int K, int N, int terms = 3);
 // Wpw, Wsc [N][K]; (a1, b1) folded BN of the pointwise branch, (as, bs) of the shortcut (null = 1 / 0)
+// terms = 3: three bf16 terms per weight.  terms = 2 (binary16 activations): two binary16 terms of Wpw x pw_ws / Wsc x sc_ws, and the
+// packed BN factors are a1 x pw_un / as x sc_un (pw_un = 1 / (pw_ws x d's scale), sc_un = 1 / (sc_ws x xs's scale))
+struct DualPackScales { float pw_ws = 1.0f, sc_ws = 1.0f, pw_un = 1.0f, sc_un = 1.0f; };
 hipError_t launch_dual_x3_pack(const float* Wpw, const float* Wsc, const float* a1, const float* b1, const float* as,
-                               const float* bs, void* out, int K, int N, hipStream_t s);
+                               const float* bs, void* out, int K, int N, hipStream_t s, int terms = 3, DualPackScales sc = DualPackScales{});
 hipError_t launch_dual_x3(const DualArgs& a, int K, int act, hipStream_t s);

@@ -19,9 +19,11 @@
 #include <stdlib.h>
 #include "layers.h"
 #include "dual_x3.h"
+#include "split_h2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -66,9 +68,9 @@ __device__ __forceinline__ void mfma6d(const bf16x8 (&w)[3], const bf16x8 (&x)[3
 __global__ void __launch_bounds__(256) dual_pack_kernel(const float* __restrict__ Wpw, const float* __restrict__ Wsc,
                                                         const float* __restrict__ a1, const float* __restrict__ b1,
                                                         const float* __restrict__ as, const float* __restrict__ bs,
-                                                        unsigned char* __restrict__ out, int K, int N) {
+                                                        unsigned char* __restrict__ out, int K, int N, int terms, DualPackScales sc) {
     const int K16 = K / 16, nblk = (N + 31) / 32;
-    const size_t blk_bytes = dual_x3_block_bytes(K);
+    const size_t blk_bytes = dual_x3_block_bytes(K, terms);
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)nblk * 2 * K16 * 64) return;
     const int lane = (int)(idx & 63);
@@ -82,19 +84,28 @@ __global__ void __launch_bounds__(256) dual_pack_kernel(const float* __restrict_
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = col < N ? W[(size_t)col * K + 16 * kb + 8 * h + e] : 0.0f;
-    uint32_t hh[8], mm[8], ll[8];
+    unsigned char* dst = base + ((size_t)((part * K16 + kb) * terms) * 64 + lane) * 16;
+    if (terms == 2) {                                          // two binary16 terms of weight x scale (split_h2.h)
+        const float ws = part ? sc.sc_ws : sc.pw_ws;
+        uint32_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3d(v[e], hh[e], mm[e], ll[e]);
-    unsigned char* dst = base + ((size_t)((part * K16 + kb) * 3) * 64 + lane) * 16;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack16d(hh[0], hh[1]), pack16d(hh[2], hh[3]), pack16d(hh[4], hh[5]), pack16d(hh[6], hh[7]));
-    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16d(mm[0], mm[1]), pack16d(mm[2], mm[3]), pack16d(mm[4], mm[5]), pack16d(mm[6], mm[7]));
-    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16d(ll[0], ll[1]), pack16d(ll[2], ll[3]), pack16d(ll[4], ll[5]), pack16d(ll[6], ll[7]));
+        for (int e = 0; e < 4; ++e) nww_split2h(v[2 * e] * ws, v[2 * e + 1] * ws, hi[e], lo[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    } else {
+        uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3d(v[e], hh[e], mm[e], ll[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack16d(hh[0], hh[1]), pack16d(hh[2], hh[3]), pack16d(hh[4], hh[5]), pack16d(hh[6], hh[7]));
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16d(mm[0], mm[1]), pack16d(mm[2], mm[3]), pack16d(mm[4], mm[5]), pack16d(mm[6], mm[7]));
+        *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16d(ll[0], ll[1]), pack16d(ll[2], ll[3]), pack16d(ll[4], ll[5]), pack16d(ll[6], ll[7]));
+    }
     if (kb == 0 && part == 0 && lane < 32) {
-        float* aff = reinterpret_cast<float*>(base + (size_t)2 * K16 * 3072);
+        float* aff = reinterpret_cast<float*>(base + (size_t)2 * K16 * terms * 1024);
         const bool ok = col < N;
-        aff[lane] = ok ? (a1 ? a1[col] : 1.0f) : 0.0f;
+        aff[lane] = ok ? (a1 ? a1[col] : 1.0f) * sc.pw_un : 0.0f;
         aff[32 + lane] = ok && b1 ? b1[col] : 0.0f;
-        aff[64 + lane] = ok ? (as ? as[col] : 1.0f) : 0.0f;
+        aff[64 + lane] = ok ? (as ? as[col] : 1.0f) * sc.sc_un : 0.0f;
         aff[96 + lane] = ok && bs ? bs[col] : 0.0f;
     }
 }
@@ -105,22 +116,25 @@ __device__ __forceinline__ void mfma3d(const bf16x8 (&w)[3], const bf16x8& x, f3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x, acc, 0, 0, 0);
 }
-__device__ __forceinline__ uint32_t pk_bf16d(float a, float b) {      // round to nearest even
-    union { __bf16 h[2]; uint32_t u; } c;
-    c.h[0] = (__bf16)a; c.h[1] = (__bf16)b;
-    return c.u;
+// two products of a scaled float32 weight (two binary16 terms) with a binary16 activation, small term first
+__device__ __forceinline__ void mfma2h(const bf16x8 (&w)[3], const bf16x8& x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 
-// BF: bf16 activations in and out (DualArgs::bf16).  NWV waves per workgroup (32 pixels each) share every weight block: a
+// AT = DualArgs::act16: 0 float32 activations, 1 bf16 in and out, 2 scaled binary16 in and out (fragments are carried as 128-bit
+// bags typed bf16x8 either way).  NWV waves per workgroup (32 pixels each) share every weight block: a
 // workgroup streams ALL packed weights (K = 128: 8 x 52 KB) through LDS once per 32 NWV pixels, which at four waves was the
 // kernel's bound for the wide blocks (1.4 GB of L2 -> LDS traffic for block 3 at 8192 clips) - eight waves halve it.
 // MEAN: the global average pool fused behind the last block (DualArgs::mean_out): waves are (clip, 32-pixel group) pairs, the
 // activated outputs of a wave go through a [32 pixels][32 channels] LDS tile (rows 144 bytes apart: conflict-free 16-byte stores) to
 // be summed per channel in pixel order, the groups of a clip are added in group order by the clip's first wave.
-template <int K16, int ACT, bool BF, int NWV, bool MEAN = false>
+template <int K16, int ACT, int AT, int NWV, bool MEAN = false>
 __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
-    constexpr int FRAG_BYTES = 2 * K16 * 3072, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
+    constexpr bool BF = AT != 0;
+    constexpr int NTM = AT == 2 ? 2 : 3;                                 // terms per weight
+    constexpr int FRAG_BYTES = 2 * K16 * NTM * 1024, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
     __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
@@ -203,22 +217,25 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * 3 + t) * 1024);
+            for (int t = 0; t < NTM; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * NTM + t) * 1024);
 #pragma unroll
         for (int kb = 0; kb < K16; ++kb) {
             bf16x8 cw[2][3];
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) cw[p][t] = nw[p][t];
+                for (int t = 0; t < NTM; ++t) cw[p][t] = nw[p][t];
             if (kb + 1 < K16) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * 3 + t) * 1024);
+                    for (int t = 0; t < NTM; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * NTM + t) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (BF) {
+            if constexpr (AT == 2) {
+                mfma2h(cw[0], xf[0][kb][0], acc[0]);
+                mfma2h(cw[1], xf[1][kb][0], acc[1]);
+            } else if constexpr (AT == 1) {
                 mfma3d(cw[0], xf[0][kb][0], acc[0]);
                 mfma3d(cw[1], xf[1][kb][0], acc[1]);
             } else {
@@ -247,7 +264,8 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
                 if constexpr (MEAN) {
                     if (!row_ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(mtile + (wave * 32 + n) * MT_LD + 8 * g + 4 * h) = o;
-                } else if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) = make_uint2(pk_bf16d(o.x, o.y), pk_bf16d(o.z, o.w));
+                } else if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) =
+                        make_uint2(nww_pk_act16(AT, o.x, o.y, a.out_mul), nww_pk_act16(AT, o.z, o.w, a.out_mul));
                 else *reinterpret_cast<float4*>(orow + col) = o;
             }
         }
@@ -299,13 +317,14 @@ bool dual_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 128) &
 // the fused mean needs every clip's 32-pixel groups inside one four-wave workgroup
 bool dual_x3_mean_supported(int pixels_per_clip) { return pixels_per_clip >= 1 && pixels_per_clip <= 128 && 4 % ((pixels_per_clip + 31) / 32) == 0; }
 
-size_t dual_x3_packed_bytes(int K, int N) { return (size_t)((N + 31) / 32) * dual_x3_block_bytes(K); }
+size_t dual_x3_packed_bytes(int K, int N, int terms) { return (size_t)((N + 31) / 32) * dual_x3_block_bytes(K, terms); }
 
 hipError_t launch_dual_x3_pack(const float* Wpw, const float* Wsc, const float* a1, const float* b1, const float* as,
-                               const float* bs, void* out, int K, int N, hipStream_t s) {
+                               const float* bs, void* out, int K, int N, hipStream_t s, int terms, DualPackScales sc) {
+    if (terms != 2 && terms != 3) return hipErrorInvalidValue;
     const size_t total = (size_t)((N + 31) / 32) * 2 * (K / 16) * 64;
     hipLaunchKernelGGL(dual_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Wpw, Wsc, a1, b1, as, bs,
-                       reinterpret_cast<unsigned char*>(out), K, N);
+                       reinterpret_cast<unsigned char*>(out), K, N, terms, sc);
     return hipGetLastError();
 }
 
@@ -321,12 +340,15 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
         if (!dual_x3_mean_supported(a.mean_P) || a.M % a.mean_P != 0 || K != 128) return hipErrorInvalidValue;      // (the last block: K = 128)
         const int gpc = (a.mean_P + 31) / 32, clips = a.M / a.mean_P;
         // bf16 activations: eight waves per workgroup as in the unfused launch (half the weight traffic through LDS; 8 % gpc == 0 too)
-        const bool w8m = a.bf16 && a.M >= 256 * 256;
+        const bool w8m = a.act16 && a.M >= 256 * 256;
         const dim3 gridm((unsigned)(((size_t)clips * gpc + (w8m ? 7 : 3)) / (w8m ? 8 : 4)));
 #define DUAL_MEAN(ACTV)                                                                                            \
-        if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, true, 8, true>), gridm, dim3(512), 0, s, a);          \
-        else if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, true, 4, true>), gridm, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, false, 4, true>), gridm, dim3(256), 0, s, a);
+        if (a.act16 == 2) {                                                                                        \
+            if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 2, 8, true>), gridm, dim3(512), 0, s, a);         \
+            else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 2, 4, true>), gridm, dim3(256), 0, s, a);             \
+        } else if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 8, true>), gridm, dim3(512), 0, s, a);      \
+        else if (a.act16) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 4, true>), gridm, dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 0, 4, true>), gridm, dim3(256), 0, s, a);
         switch (act) {
             case ACT_RELU: DUAL_MEAN(ACT_RELU) break;
             case ACT_GELU: DUAL_MEAN(ACT_GELU) break;
@@ -339,14 +361,17 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
     // eight waves per workgroup where it measured faster at 8192 clips: bf16 activations at K = 32 (0.255 -> 0.211 ms) and
     // K = 128 (0.293 -> 0.229); K = 64 (0.161 -> 0.172) and every float32 shape (0.363 -> 0.395, 0.235 -> 0.248; K = 128
     // needs 284 registers) stay at four
-    const bool w8 = a.M >= 256 * 256 && a.bf16 && K != 64;
+    const bool w8 = a.M >= 256 * 256 && a.act16 && K != 64;
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define DUAL_GO(K16V, ACTV)                                                                                        \
-    if (w8) {                                                                                                      \
-        hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 8>), grid, dim3(512), 0, s, a);                       \
+    if (a.act16 == 2) {                                                                                            \
+        if (w8) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 2, 8>), grid, dim3(512), 0, s, a);                  \
+        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 2, 4>), grid, dim3(256), 0, s, a);                     \
+    } else if (w8) {                                                                                               \
+        hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 1, 8>), grid, dim3(512), 0, s, a);                          \
     } else {                                                                                                       \
-        if (a.bf16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, true, 4>), grid, dim3(256), 0, s, a);           \
-        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, false, 4>), grid, dim3(256), 0, s, a);                 \
+        if (a.act16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 1, 4>), grid, dim3(256), 0, s, a);             \
+        else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 0, 4>), grid, dim3(256), 0, s, a);                     \
     }
 #define DUAL_ACT(K16V)                                                                                             \
     switch (act) {                                                                                                 \

@@ -84,9 +84,10 @@ hipError_t launch_conv3x3(const Conv3Args& a, hipStream_t s);
 
 // depthwise 3x3, pad 1, stride (sh, sw) on channels-last data: in [B][H][W][C], wt [9][C] (tap-major weights)
 // -> d_out [B][Ho][Wo][C]; xs_out (may be null) receives in[b][oy*sh][ox*sw][c], the input of a strided 1x1 conv.
-// bf16 = true: `in` and `d_out` are bf16 arrays (nww_config.act_dtype), xs_out must be null
+// act16 = 1 / 2 (nww_config.act_dtype): `in` and `d_out` are bf16 / scaled binary16 arrays, xs_out must be null; binary16: the sums
+// are multiplied by out_mul = d_out's scale / in's scale before rounding
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
-                                 int W, int sh, int sw, hipStream_t s, bool bf16 = false);
+                                 int W, int sh, int sw, hipStream_t s, int act16 = 0, float out_mul = 1.0f);
 // rows [R][D]: y = act(LayerNorm(x)*w + b), eps 1e-5, biased variance; in place allowed (y == x)
 // LayerNorm over x[row][i] = sum_z parts[z][row][i] + in_bias[i] (the split-K partials of the producing GEMM; D <= 256)
 hipError_t launch_layernorm_parts(const float* parts, int nparts, size_t part_stride, const float* in_bias, float* y, const float* w,

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "layers.h"
+#include "split_h2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -447,12 +448,6 @@ dwconv3x3_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ wt
 // (stride 1: 18 loads for 4 outputs instead of 36 four-byte ones per channel; stride 2: 27), the nine weights of the four
 // channels stay in registers.  Same tap order and fmaf chain as dwconv3x3_nhwc_kernel.  xs_out is not supported (the
 // split-operand block kernel gathers the shortcut rows itself).
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // round to nearest even
-    union { __bf16 h[2]; uint32_t u; } c;
-    c.h[0] = (__bf16)a; c.h[1] = (__bf16)b;
-    return c.u;
-}
-
 template <int SW>
 __global__ void __launch_bounds__(256)
 dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__ wt, float* __restrict__ d_out, int C, int H, int W,
@@ -501,12 +496,14 @@ dwconv3x3_nhwc_x4_kernel(const float* __restrict__ in, const float* __restrict__
     }
 }
 
-// bf16 activations (nww_config.act_dtype): a thread owns EIGHT channels (one 16-byte load per input pixel) of two outputs
-// along x - 7.5 sixteen-byte loads per output where the float32 kernel above needs 13.5 per eight channels
-template <int SW>
+// 16-bit activations (nww_config.act_dtype; KIND = ACT16_BF16 / ACT16_F16 of split_h2.h): a thread owns EIGHT channels (one
+// 16-byte load per input pixel) of two outputs along x - 7.5 sixteen-byte loads per output where the float32 kernel above needs
+// 13.5 per eight channels.  binary16: the input carries its tensor's scale, the sums are multiplied by out_mul = output scale /
+// input scale (a power of two) before they are rounded.
+template <int SW, int KIND>
 __global__ void __launch_bounds__(256)
-dwconv3x3_nhwc_bf16_kernel(const __bf16* __restrict__ in, const float* __restrict__ wt, __bf16* __restrict__ d_out, int C, int H, int W,
-                           int Ho, int Wo, int sh, size_t total) {
+dwconv3x3_nhwc_bf16_kernel(const uint16_t* __restrict__ in, const float* __restrict__ wt, uint16_t* __restrict__ d_out, int C, int H, int W,
+                           int Ho, int Wo, int sh, size_t total, float out_mul) {
     constexpr int NX = 2, COLS = (NX - 1) * SW + 3;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // ((b*Ho + oy)*Wg + xg)*C8 + c8
     if (idx >= total) return;
@@ -517,7 +514,7 @@ dwconv3x3_nhwc_bf16_kernel(const __bf16* __restrict__ in, const float* __restric
     t /= Wg;
     const int oy = (int)(t % Ho);
     const size_t b = t / Ho;
-    const __bf16* ip = in + b * (size_t)H * W * C + 8 * c8;
+    const uint16_t* ip = in + b * (size_t)H * W * C + 8 * c8;
     float acc[NX][8];
 #pragma unroll
     for (int j = 0; j < NX; ++j)
@@ -545,8 +542,10 @@ dwconv3x3_nhwc_bf16_kernel(const __bf16* __restrict__ in, const float* __restric
                 const uint32_t u[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[j][2 * e] = fmaf(__uint_as_float(u[e] << 16), w[2 * e], acc[j][2 * e]);
-                    acc[j][2 * e + 1] = fmaf(__uint_as_float(u[e] & 0xffff0000u), w[2 * e + 1], acc[j][2 * e + 1]);
+                    float lo, hi;
+                    nww_unpk_act16(KIND, u[e], lo, hi);
+                    acc[j][2 * e] = fmaf(lo, w[2 * e], acc[j][2 * e]);
+                    acc[j][2 * e + 1] = fmaf(hi, w[2 * e + 1], acc[j][2 * e + 1]);
                 }
             }
         }
@@ -556,21 +555,28 @@ dwconv3x3_nhwc_bf16_kernel(const __bf16* __restrict__ in, const float* __restric
         const int ox = xg * NX + j;
         if (ox < Wo)
             *reinterpret_cast<uint4*>(d_out + ((b * Ho + oy) * (size_t)Wo + ox) * C + 8 * c8) =
-                make_uint4(pk_bf16(acc[j][0], acc[j][1]), pk_bf16(acc[j][2], acc[j][3]), pk_bf16(acc[j][4], acc[j][5]), pk_bf16(acc[j][6], acc[j][7]));
+                make_uint4(nww_pk_act16(KIND, acc[j][0], acc[j][1], out_mul), nww_pk_act16(KIND, acc[j][2], acc[j][3], out_mul),
+                           nww_pk_act16(KIND, acc[j][4], acc[j][5], out_mul), nww_pk_act16(KIND, acc[j][6], acc[j][7], out_mul));
     }
 }
 
 hipError_t launch_dwconv3x3_nhwc(const float* in, const float* wt, float* d_out, float* xs_out, int B, int C, int H,
-                                 int W, int sh, int sw, hipStream_t s, bool bf16) {
+                                 int W, int sh, int sw, hipStream_t s, int act16, float out_mul) {
     const int Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
-    if (bf16) {                                                // bf16 activations: their own kernel, eight channels per thread
+    if (act16) {                                               // 16-bit activations: their own kernel, eight channels per thread
         if (xs_out || C % 8 != 0 || (sw != 1 && sw != 2) || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(wt)) & 15) != 0)
             return hipErrorInvalidValue;
         const size_t total8 = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 8);
-        const __bf16* ib = reinterpret_cast<const __bf16*>(in);
-        __bf16* ob = reinterpret_cast<__bf16*>(d_out);
-        if (sw == 1) hipLaunchKernelGGL(dwconv3x3_nhwc_bf16_kernel<1>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8);
-        else hipLaunchKernelGGL(dwconv3x3_nhwc_bf16_kernel<2>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8);
+        const uint16_t* ib = reinterpret_cast<const uint16_t*>(in);
+        uint16_t* ob = reinterpret_cast<uint16_t*>(d_out);
+        const dim3 grid((unsigned)((total8 + 255) / 256));
+        if (act16 == ACT16_F16) {
+            if (sw == 1) hipLaunchKernelGGL((dwconv3x3_nhwc_bf16_kernel<1, ACT16_F16>), grid, dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8, out_mul);
+            else hipLaunchKernelGGL((dwconv3x3_nhwc_bf16_kernel<2, ACT16_F16>), grid, dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8, out_mul);
+        } else {
+            if (sw == 1) hipLaunchKernelGGL((dwconv3x3_nhwc_bf16_kernel<1, ACT16_BF16>), grid, dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8, 1.0f);
+            else hipLaunchKernelGGL((dwconv3x3_nhwc_bf16_kernel<2, ACT16_BF16>), grid, dim3(256), 0, s, ib, wt, ob, C, H, W, Ho, Wo, sh, total8, 1.0f);
+        }
         return hipGetLastError();
     }
     if (!xs_out && C % 4 == 0 && (sw == 1 || sw == 2) &&

@@ -88,9 +88,10 @@ extern "C" int nww_create(const nww_config* cfg, nww_handle** out) {
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "recurrent hidden size (layer_dim = %d) must be <= 512", c.layer_dim);
     if (c.head_type == NWW_HEAD_CONFORMER && (c.conformer_n_head <= 0 || c.conformer_d_model % c.conformer_n_head))
         return fail(nullptr, NWW_ERR_INVALID, "conformer_d_model must be divisible by conformer_n_head");
-    if (c.act_dtype != NWW_ACT_DTYPE_F32 && c.act_dtype != NWW_ACT_DTYPE_BF16) return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_DTYPE_F32 or NWW_ACT_DTYPE_BF16");
-    if (c.act_dtype == NWW_ACT_DTYPE_BF16 && c.head_type != NWW_HEAD_BCRESNET)
-        return fail(nullptr, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 is implemented for the BcResNet head only (BASELINE config 3)");
+    if (c.act_dtype != NWW_ACT_DTYPE_F32 && c.act_dtype != NWW_ACT_DTYPE_BF16 && c.act_dtype != NWW_ACT_DTYPE_F16)
+        return fail(nullptr, NWW_ERR_INVALID, "act_dtype must be NWW_ACT_DTYPE_F32, NWW_ACT_DTYPE_BF16 or NWW_ACT_DTYPE_F16");
+    if (c.act_dtype != NWW_ACT_DTYPE_F32 && c.head_type != NWW_HEAD_BCRESNET)
+        return fail(nullptr, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 / f16 is implemented for the BcResNet head only (BASELINE config 3)");
     if (c.head_type == NWW_HEAD_CONFORMER && !mha_head_dim_supported(c.conformer_d_model / c.conformer_n_head))
         return fail(nullptr, NWW_ERR_UNSUPPORTED, "attention head_dim %d is wider than the widest compiled kernel (128)",
                     c.conformer_d_model / c.conformer_n_head);

@@ -843,11 +843,56 @@ extern "C" int nww_finalize(nww_handle* h) {
             // init conv fused with block1's depthwise (trunk.hip: the 32-channel planes never reach HBM)
             static const int bc_front = [] { const char* e = getenv("NWW_BC_FRONT"); return e ? atoi(e) : 1; }();
             const bool front_fused = ic_mfma && bc_front && conv1_pool_nhwc_mfma_fits(T, F) && conv1_pool_dw_rows(T, F, 2) > 0;
-            // nww_config.act_dtype = NWW_ACT_DTYPE_BF16: every activation tensor between the kernels of this head is stored as bf16
-            // (arithmetic and accumulation stay float32); implemented on the fused front + split-operand block path only
-            const bool act_bf16 = c.act_dtype == NWW_ACT_DTYPE_BF16;
+            // nww_config.act_dtype = NWW_ACT_DTYPE_BF16 / _F16: every activation tensor between the kernels of this head is stored in 16
+            // bits (arithmetic and accumulation stay float32); implemented on the fused front + split-operand block path only.
+            // binary16 (11 significant bits against bf16's 8) stores value x a power of two fixed here from a bound on the tensor
+            // (features within +-NWW_F16_FEATURE_BOUND as in the f16x3 arithmetic; the bound is not allowed to sit more than 2^16 above
+            // the tensor's typical magnitude, and the stores saturate), and a block's weights are two binary16 terms of weight x scale.
+            const int act16 = c.act_dtype;                       // NWW_ACT_DTYPE_* == ACT16_* (split_h2.h)
+            const bool act_bf16 = act16 != NWW_ACT_DTYPE_F32;    // any 16-bit storage
+            const bool act_f16 = act16 == NWW_ACT_DTYPE_F16;
             if (act_bf16 && !(front_fused && p.h->conv_products == 6))
-                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 needs the fused BcResNet front kernel and conv_arith bf16x6 for this input shape");
+                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 / f16 needs the fused BcResNet front kernel and a split-operand conv_arith for this input shape");
+            float s_h[4] = {1.f, 1.f, 1.f, 1.f}, s_d[4] = {1.f, 1.f, 1.f, 1.f};     // scales of h_i (block i's output, h_0 = init conv) and d_i
+            DualPackScales dps[4];
+            if (act_f16) {
+                auto cap = [](F16Range r) { return f16_scale(std::fmin(r.bound, r.typ * 65536.0)); };
+                auto dw_range = [&](const float* wt, int C, F16Range in) {      // wt [9][C] tap-major
+                    const auto w = f16_fetch(p.h, wt, (size_t)9 * C);
+                    double worst = 0, typ = 0;
+                    for (int ch = 0; ch < C; ++ch) {
+                        double l1 = 0, l2 = 0;
+                        for (int k = 0; k < 9; ++k) { const double v = w[(size_t)k * C + ch]; l1 += std::fabs(v); l2 += v * v; }
+                        worst = std::fmax(worst, l1); typ += std::sqrt(l2);
+                    }
+                    return F16Range{worst * in.bound, typ / C * in.typ};
+                };
+                const auto hw0 = f16_fetch(p.h, p.W("model.init_conv.0.weight"), 32 * 9);
+                const float *pa0 = p.W("model.init_conv.1.alpha"), *pb0 = p.W("model.init_conv.1.beta");
+                const auto ha0 = f16_fetch(p.h, pa0, 32), hb0 = f16_fetch(p.h, pb0, 32);
+                F16Range rh{f16_layer_bound(hw0, 32, 9, hb0, false, ha0, hb0, pa0 != nullptr, F16_FEATURES.bound),
+                            f16_layer_typ(hw0, 32, 9, ha0, pa0 != nullptr, F16_FEATURES.typ)};
+                s_h[0] = cap(rh);
+                const int chs[4] = {32, 64, 128, 256};
+                for (int i = 1; i <= 3; ++i) {
+                    const std::string q = "model.block" + std::to_string(i);
+                    const int ci = chs[i - 1], co = chs[i];
+                    const F16Range rd = dw_range(p.W(q + ".depthwise.weight_t"), ci, rh);
+                    s_d[i] = cap(rd);
+                    const float *pa1 = p.W(q + ".bn1.alpha"), *pas = p.W(q + ".shortcut.1.alpha");
+                    const auto wpw = f16_fetch(p.h, p.W(q + ".pointwise.weight"), (size_t)co * ci), wsc = f16_fetch(p.h, p.W(q + ".shortcut.0.weight"), (size_t)co * ci);
+                    const auto ha1 = f16_fetch(p.h, pa1, co), hb1 = f16_fetch(p.h, p.W(q + ".bn1.beta"), co);
+                    const auto has = f16_fetch(p.h, pas, co), hbs = f16_fetch(p.h, p.W(q + ".shortcut.1.beta"), co);
+                    dps[i].pw_ws = f16_wscale(wpw); dps[i].sc_ws = f16_wscale(wsc);
+                    if (!(s_d[i] > 0.f && s_h[i - 1] > 0.f && dps[i].pw_ws > 0.f && dps[i].sc_ws > 0.f))
+                        return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = f16: no finite bound on the tensors of block %d", i);
+                    dps[i].pw_un = 1.0f / (dps[i].pw_ws * s_d[i]); dps[i].sc_un = 1.0f / (dps[i].sc_ws * s_h[i - 1]);
+                    const F16Range rpw{f16_layer_bound(wpw, co, ci, hb1, false, ha1, hb1, pa1 != nullptr, rd.bound), f16_layer_typ(wpw, co, ci, ha1, pa1 != nullptr, rd.typ)};
+                    const F16Range rsc{f16_layer_bound(wsc, co, ci, hbs, false, has, hbs, pas != nullptr, rh.bound), f16_layer_typ(wsc, co, ci, has, pas != nullptr, rh.typ)};
+                    rh = F16Range{rpw.bound + rsc.bound, std::hypot(rpw.typ, rsc.typ)};
+                    s_h[i] = cap(rh);
+                }
+            }
             if (front_fused) {
                 const float *w0 = p.W("model.init_conv.0.weight"), *a0 = p.W("model.init_conv.1.alpha"), *b0 = p.W("model.init_conv.1.beta");
                 const float* dwt1 = p.W("model.block1.depthwise.weight_t");
@@ -863,9 +908,9 @@ extern "C" int nww_finalize(nww_handle* h) {
                     if (launch_bc_front_b_pack(w0, static_cast<unsigned char*>(fpack), p.h->own_stream) == hipSuccess) p.h->packed_weights.push_back(fpack);
                     else { (void)hipFree(fpack); fpack = nullptr; }
                 }
-                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
+                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_f16 ? ", f16 out)" : act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
-                    a.bf16_out = act_bf16 ? 1 : 0;
+                    a.bf16_out = act16; a.d_scale = s_d[1]; a.xs_scale = s_h[0];
                     if (fpack) {
                         a.wpack = static_cast<const unsigned char*>(fpack);
                         return launch_bc_front_b(a, fprod, max_grid, r.stream);
@@ -906,25 +951,30 @@ extern "C" int nww_finalize(nww_handle* h) {
                     // both products from split operands on the bf16 matrix cores (dual_x3.hip) under the same arithmetic switch
                     static const int dual_x3 = [] { const char* e = getenv("NWW_BC_DUAL_X3"); return e ? atoi(e) : 1; }();
                     void* packed = nullptr;
+                    const int terms = act_f16 ? 2 : 3;
                     if (dual_x3 && p.h->conv_products == 6 && dual_x3_supported(ci, co) &&
-                        hipMalloc(&packed, dual_x3_packed_bytes(ci, co)) == hipSuccess) {
-                        if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream) == hipSuccess) {
+                        hipMalloc(&packed, dual_x3_packed_bytes(ci, co, terms)) == hipSuccess) {
+                        if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream, terms, dps[i]) == hipSuccess) {
                             p.h->packed_weights.push_back(packed);
                             // when the block input is in HBM (every block but the one whose depthwise ran inside the fused front kernel) the
                             // shortcut rows are gathered from it and the depthwise kernel planned just above writes no copy of them
                             const bool gather = !(front_fused && i == 1);
                             if (gather) {
+                                const float dw_mul = s_d[i] / s_h[i - 1];
                                 p.pop_last();
-                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act_bf16); });
+                                p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act16, dw_mul); });
                             }
                             // the last block feeds only the global average pool: averaged in the same launch, its output never reaches HBM
                             static const int mean_fused_on = [] { const char* e = getenv("NWW_BC_MEAN_FUSED"); return e ? atoi(e) : 1; }();
                             const bool fuse_mean = mean_fused_on && i == 3 && ci == 128 && dual_x3_mean_supported(rows);
                             if (fuse_mean) { mean_fused = true; p.need(5, 256); }
-                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
+                            if (act_f16 && i == 3 && !fuse_mean)
+                                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = f16 needs the global average pool fused into the last block (%d pixels per clip)", rows);
+                            const float out_mul = fuse_mean ? 1.0f : s_h[i];
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
                                 if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
-                                a.bf16 = act_bf16 ? 1 : 0;
+                                a.act16 = act16; a.out_mul = out_mul;
                                 if (fuse_mean) { a.mean_out = r.buf[5]; a.mean_P = rows; }
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });
@@ -933,7 +983,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                         }
                         (void)hipFree(packed);
                     }
-                    if (act_bf16) return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16: block %d has no split-operand kernel (channels %d -> %d)", i, ci, co);
+                    if (act_bf16) return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = bf16 / f16: block %d has no split-operand kernel (channels %d -> %d)", i, ci, co);
                     p.add("gemm2:" + q + ".pointwise+bn+act + shortcut+bn", [=](Run& r) {
                         GemmArgs g;
                         g.A = r.buf[dwb]; g.lda = ci; g.W = wpw; g.K = ci; g.alpha = a1; g.beta = b1; g.bias = nullptr; g.act = act;

@@ -20,3 +20,29 @@ __device__ __forceinline__ void nww_split2h(float a, float b, uint32_t& hi, uint
     const nww_f32x2 r = {ra, rb};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, nww_f16x2));
 }
+
+// ---- 16-bit storage of activation tensors (nww_config.act_dtype): ACT16_BF16 = bf16 (round to nearest even, no scale),
+// ACT16_F16 = binary16 of value x a plan-time power-of-two scale (round to nearest even, saturating at +-65504)
+enum { ACT16_F32 = 0, ACT16_BF16 = 1, ACT16_F16 = 2 };
+__device__ __forceinline__ uint32_t nww_pk_bf16(float a, float b) {
+    union { __bf16 h[2]; uint32_t u; } c;
+    c.h[0] = (__bf16)a; c.h[1] = (__bf16)b;
+    return c.u;
+}
+__device__ __forceinline__ uint32_t nww_pk_f16_sat(float a, float b) {
+    const nww_f32x2 v = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nww_f16x2));
+}
+// kind is wave-uniform; f16: (a, b) times mul
+__device__ __forceinline__ uint32_t nww_pk_act16(int kind, float a, float b, float mul) {
+    return kind == ACT16_F16 ? nww_pk_f16_sat(a * mul, b * mul) : nww_pk_bf16(a, b);
+}
+// the two values of a packed dword back to float32 (f16: still times the tensor's scale)
+__device__ __forceinline__ void nww_unpk_act16(int kind, uint32_t u, float& a, float& b) {
+    if (kind == ACT16_F16) {
+        const nww_f16x2 h = __builtin_bit_cast(nww_f16x2, u);
+        a = (float)h[0]; b = (float)h[1];
+    } else {
+        a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+    }
+}

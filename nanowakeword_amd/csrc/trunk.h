@@ -104,7 +104,8 @@ struct Conv1DwArgs {
     float* d_out; float* xs_out;
     int B, H, W, act, sh, sw;
     int Ho = 0, Wo = 0, rows_dw = 0; // filled by the launcher
-    int bf16_out = 0;                // d_out / xs_out are bf16 arrays (nww_config.act_dtype = NWW_ACT_DTYPE_BF16)
+    int bf16_out = 0;                // nww_config.act_dtype: 1 = d_out / xs_out are bf16 arrays, 2 = binary16 arrays of value x scale
+    float d_scale = 1.0f, xs_scale = 1.0f;   // bf16_out == 2: the tensors' plan-time power-of-two scales
     const unsigned char* wpack = nullptr;   // launch_bc_front_b only: conv weight fragments (launch_bc_front_b_pack)
 };
 // the same stage with the convolution from split operands on the bf16 matrix cores (trunk_b.hip); products = 6 / 9

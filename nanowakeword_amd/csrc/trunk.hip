@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include "layers.h"
 #include "trunk.h"
+#include "split_h2.h"
 
 #include "conv_tile_epilogue.h"
 
@@ -727,12 +728,12 @@ __global__ void __launch_bounds__(64 * NW) conv1_pool_dw_nhwc_kernel(Conv1DwArgs
                     }
                 }
                 const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cq;
-                if (a.bf16_out) {                         // wave-uniform: bf16 activations (round to nearest even)
-                    union { __bf16 h[4]; uint2 u; } pd, px;
-                    pd.h[0] = (__bf16)acc.x; pd.h[1] = (__bf16)acc.y; pd.h[2] = (__bf16)acc.z; pd.h[3] = (__bf16)acc.w;
-                    px.h[0] = (__bf16)centre.x; px.h[1] = (__bf16)centre.y; px.h[2] = (__bf16)centre.z; px.h[3] = (__bf16)centre.w;
-                    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.d_out) + oi) = pd.u;
-                    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.xs_out) + oi) = px.u;
+                if (a.bf16_out) {                             // wave-uniform: 16-bit activations (split_h2.h)
+                    const int k16 = a.bf16_out;
+                    const uint2 pd = make_uint2(nww_pk_act16(k16, acc.x, acc.y, a.d_scale), nww_pk_act16(k16, acc.z, acc.w, a.d_scale));
+                    const uint2 px = make_uint2(nww_pk_act16(k16, centre.x, centre.y, a.xs_scale), nww_pk_act16(k16, centre.z, centre.w, a.xs_scale));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_out) + oi) = pd;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.xs_out) + oi) = px;
                 } else {
                     *reinterpret_cast<float4*>(a.d_out + oi) = acc;
                     *reinterpret_cast<float4*>(a.xs_out + oi) = centre;

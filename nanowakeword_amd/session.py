@@ -64,7 +64,8 @@ class HipModel:
                  state_dict: Optional[Mapping] = None, window=None, mel_fb=None, tables: str = "torchaudio",
                  conv_arith: Optional[str] = None, act_dtype: Optional[str] = None):
         """act_dtype="bf16": the BcResNet head stores the activations between its kernels as bf16 (BASELINE config 3 as written;
-        float32 products and accumulation; logits then agree with the float32 reference to ~1e-2 instead of 1e-4)."""
+        float32 products and accumulation; logits then agree with the float32 reference to ~1e-2 instead of 1e-4 - 0.2 on all-zero
+        PCM).  act_dtype="f16": the same tensors as scaled binary16 (same bytes, 11 significant bits: ~5e-3 on every test clip)."""
         self.lib = _lib.load_library()      # ImportError if the HIP extension is missing - no fallback
         self.head = head
         self.fe = frontend or FrontendConfig()

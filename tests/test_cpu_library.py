@@ -44,6 +44,8 @@ def test_config_struct_mirrors_header():
     assert ctypes.sizeof(_lib.NwwConfig) == 4 * (len(names) + 3 + 3) == 132   # crnn_channels[4] and reserved[4] arrays; size fixed across versions
     assert int(re.search(r"#define NWW_ACT_DTYPE_BF16 (\d+)", hdr).group(1)) == _lib.ACT_DTYPE_CODE["bf16"] and _lib.ACT_DTYPE_CODE["f32"] == 0
     assert _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="bf16").act_dtype == 1
+    assert int(re.search(r"#define NWW_ACT_DTYPE_F16 (\d+)", hdr).group(1)) == _lib.ACT_DTYPE_CODE["f16"]
+    assert _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="f16").act_dtype == 2
     with pytest.raises(ValueError):
         _lib.make_config(HeadConfig("bcresnet", (101, 64)), FrontendConfig(), act_dtype="fp8")
     for key, code in (("f32", "NWW_ARITH_F32"), ("bf16x6", "NWW_ARITH_BF16X6"), ("bf16x9", "NWW_ARITH_BF16X9")):

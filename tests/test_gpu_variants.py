@@ -387,6 +387,68 @@ def test_bcresnet_bf16_activations(HipModel, golden_frontend):
         HipModel(HeadConfig("cnn", (101, 64)), FrontendConfig(), act_dtype="bf16")
 
 
+def test_bcresnet_f16_activations(HipModel, golden_frontend):
+    """nww_config.act_dtype = f16: the tensors between the BcResNet head's kernels as binary16 of value x a plan-time power of two
+    (same bytes as bf16, 11 significant bits instead of 8; block weights as two binary16 terms, float32 accumulation).  Unlike bf16
+    the mode needs no carve-outs: 1e-2 against the float32 oracle on ALL 16 golden clips - tones, chirp and digital silence
+    included (CPU emulation of the storage rounding alone: <= 4.2e-3) - and on synthetic features; batch-invariant; out-of-range
+    features saturate instead of producing infinities; the float32 path is untouched."""
+    g = golden_frontend
+    cfg = HeadConfig("bcresnet", (101, 64))
+    sd = synth_state_dict(cfg)
+    m32 = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    l32, _ = m32.forward_pcm(g["pcm"])
+    mh = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"], act_dtype="f16")
+    plan = mh.describe_plan()
+    assert "f16 out" in plan and plan.count("(f16 activations)") == 3 and "global_avg_pool" in plan, plan
+    lh, ph = mh.forward_pcm(g["pcm"])
+    lm = np.ascontiguousarray(oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"]).transpose(0, 2, 1))
+    ref = oracle.model_forward(lm, sd, cfg).ravel()
+    e = np.abs(lh - ref)
+    print("bcresnet f16 activations, |dlogit| per clip:", {str(n): float(f"{v:.2e}") for n, v in zip(g["names"], e)},
+          f"(float32 path: {np.abs(l32 - ref).max():.2e})")
+    assert e.max() <= 1e-2, e
+    assert np.abs(ph - 1.0 / (1.0 + np.exp(-lh.astype(np.float64)))).max() <= 1e-6
+    for B in (3, 40):
+        x = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = mh.forward_features(x)
+        d = np.abs(lg - oracle.model_forward(x, sd, cfg).ravel()).max()
+        assert d <= 5e-3, d
+    lb1, _ = mh.forward_pcm(g["pcm"][:1])
+    assert np.array_equal(lb1, lh[:1])
+    # features far outside the assumed +-8192: finite (saturated) logits, no infinities / NaNs
+    big = synth_features(4, cfg.input_shape, seed=1) * 1e6
+    lg, _ = mh.forward_features(big)
+    assert np.isfinite(lg).all()
+    l32b, _ = m32.forward_pcm(g["pcm"])
+    assert np.array_equal(l32, l32b)
+    mh.close(); m32.close()
+    with pytest.raises(Exception, match="BcResNet"):
+        HipModel(HeadConfig("cnn", (101, 64)), FrontendConfig(), act_dtype="f16")
+
+
+def test_bcresnet_f16_batch_invariance_at_baseline_size(HipModel, golden_frontend):
+    """act_dtype = f16 at BASELINE config 3's per-GPU batch of 8192 (the eight-wave kernels): slot- and batch-independent logits,
+    within 5e-3 of the float32 path."""
+    g = golden_frontend
+    cfg = HeadConfig("bcresnet", (101, 64))
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"], act_dtype="f16")
+    B = 8192
+    x = synth_pcm("noise", B, 16000, seed=7)
+    lg, _ = m.forward_pcm(x)
+    assert np.isfinite(lg).all()
+    l16, _ = m.forward_pcm(x[:16])
+    assert np.array_equal(lg[:16], l16)
+    perm = np.random.default_rng(0).permutation(B)
+    lp, _ = m.forward_pcm(np.ascontiguousarray(x[perm]))
+    assert np.array_equal(lp, lg[perm])
+    m32 = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    l32, _ = m32.forward_pcm(x[:64])
+    assert np.abs(lg[:64] - l32).max() <= 5e-3, float(np.abs(lg[:64] - l32).max())
+    m.close(); m32.close()
+
+
 R04_REFUSED = set()          # every shape of heads_r04.npz runs (round 4: any recurrent width <= 512, any attention head dim <= 128)
 
 

@@ -27,6 +27,7 @@ def main():
         ("C2 cnn 64-mel B=4096", HeadConfig("cnn", (101, 64)), FrontendConfig(), 4096, 30),
         ("C3 bcresnet 64-mel B=8192/GPU (fp32)", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, 10),
         ("C3b bcresnet 64-mel B=8192/GPU (bf16 activations)", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, 10),
+        ("C3c bcresnet 64-mel B=8192/GPU (f16 activations)", HeadConfig("bcresnet", (101, 64)), FrontendConfig(), 8192, 10),
         ("C4 crnn-gru 64-mel streaming S=1024 x 125 hops", HeadConfig("crnn", (101, 64)), FrontendConfig(), 1024, 0),
         ("C5 conformer 64-mel B=2048/GPU", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048, 10),
         ("e2e_dnn 64-mel B=4096", HeadConfig("e2e_dnn", (64, 101)), FrontendConfig(), 4096, 20),
@@ -37,7 +38,7 @@ def main():
             continue
         sd = synth_state_dict(cfg)
         window, fb = torchaudio_tables(fe)
-        m = HipModel(cfg, fe, device=0, state_dict=sd, window=window, mel_fb=fb, act_dtype="bf16" if "bf16 activations" in name else None)
+        m = HipModel(cfg, fe, device=0, state_dict=sd, window=window, mel_fb=fb, act_dtype="bf16" if "bf16 activations" in name else "f16" if "f16 activations" in name else None)
         stream = torch.cuda.current_stream(dev).cuda_stream
         out = {"config": name, "head": cfg.model_type, "batch": B, "mmac_per_clip": round(head_macs(cfg) / 1e6, 2)}
         if "streaming" in name:

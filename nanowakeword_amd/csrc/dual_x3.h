@@ -20,6 +20,11 @@ struct DualArgs {
     // v_mfma_f32_32x32x16_f16; the result times out_mul (= out's scale) is rounded to binary16, saturating.
     int act16 = 0;
     float out_mul = 1.0f;
+    // h2 = 1 (float32 activations only; NWW_ARITH_F16X3): the products on TWO binary16 terms per operand, three per float32 product on
+    // v_mfma_f32_32x32x16_f16.  The weights are packed with terms = 2 (scale = f16_wscale, un = 1 / scale); an activation row is
+    // scaled by ITS OWN power of two (largest element into [2^14, 2^15), found in registers - no plan-time bound on the tensor is
+    // needed) and the accumulators are multiplied back per pixel.
+    int h2 = 0;
     // mean_out != nullptr (the last block): out is NOT written; the block's output is averaged over the mean_P = Ho * Wo pixels of
     // every clip instead -> mean_out [M / mean_P][N] float32 (BcResNetModel's global average pool, architectures.py:677-678).  The
     // pixel tiling is then clip-aligned (a wave = 32 pixels of ONE clip), so a clip's sums do not depend on its slot in the batch.

@@ -122,8 +122,16 @@ __device__ __forceinline__ void mfma2h(const bf16x8 (&w)[3], const bf16x8& x, f3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 
-// AT = DualArgs::act16: 0 float32 activations, 1 bf16 in and out, 2 scaled binary16 in and out (fragments are carried as 128-bit
-// bags typed bf16x8 either way).  NWV waves per workgroup (32 pixels each) share every weight block: a
+// three products of two-term operands (binary16), small terms first: lo*hi, hi*lo, hi*hi
+__device__ __forceinline__ void mfma3h(const bf16x8 (&w)[3], const bf16x8* x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
+}
+
+// AT: 0 float32 activations on three bf16 terms (six products), 1 bf16 in and out, 2 scaled binary16 in and out (DualArgs::act16),
+// 3 float32 activations on two binary16 terms with a per-pixel scale (DualArgs::h2; three products).  Fragments are carried as
+// 128-bit bags typed bf16x8 either way.  NWV waves per workgroup (32 pixels each) share every weight block: a
 // workgroup streams ALL packed weights (K = 128: 8 x 52 KB) through LDS once per 32 NWV pixels, which at four waves was the
 // kernel's bound for the wide blocks (1.4 GB of L2 -> LDS traffic for block 3 at 8192 clips) - eight waves halve it.
 // MEAN: the global average pool fused behind the last block (DualArgs::mean_out): waves are (clip, 32-pixel group) pairs, the
@@ -132,8 +140,9 @@ __device__ __forceinline__ void mfma2h(const bf16x8 (&w)[3], const bf16x8& x, f3
 template <int K16, int ACT, int AT, int NWV, bool MEAN = false>
 __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
-    constexpr bool BF = AT != 0;
-    constexpr int NTM = AT == 2 ? 2 : 3;                                 // terms per weight
+    constexpr bool BF = AT == 1 || AT == 2;                              // 16-bit activations in HBM
+    constexpr int NTM = AT >= 2 ? 2 : 3;                                 // terms per weight
+    constexpr int NXT = BF ? 1 : AT == 3 ? 2 : 3;                        // terms per activation
     constexpr int FRAG_BYTES = 2 * K16 * NTM * 1024, BLK = (FRAG_BYTES + 512 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
     __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
@@ -171,7 +180,8 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     fetch(0, wb0);
 
     // ---- the lane's half rows (features 16kb + 8h + e) of d and xs -> fragments
-    bf16x8 xf[2][K16][BF ? 1 : 3];
+    bf16x8 xf[2][K16][NXT];
+    float pin[2] = {1.0f, 1.0f};                               // AT == 3: 1 / the pixel's scale, per input
     const float* xs_row = nullptr;
     size_t xs_off = 0;                                         // element offset of the pixel's row in x (BF: 2-byte elements)
     if (a.x) {
@@ -188,6 +198,35 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
                                    : reinterpret_cast<const __bf16*>(a.d) + rr * K;
 #pragma unroll
             for (int kb = 0; kb < K16; ++kb) xf[p][kb][0] = *reinterpret_cast<const bf16x8*>(xrow + 16 * kb + 8 * h);
+        }
+    } else if constexpr (AT == 3) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* xrow = (p ? (a.x ? xs_row : a.xs + rr * K) : a.d + rr * K);
+            float v[K16][8];
+            float m = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb) {
+                const float4 p0 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h);
+                const float4 p1 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h + 4);
+                v[kb][0] = p0.x; v[kb][1] = p0.y; v[kb][2] = p0.z; v[kb][3] = p0.w;
+                v[kb][4] = p1.x; v[kb][5] = p1.y; v[kb][6] = p1.z; v[kb][7] = p1.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[kb][e]));
+            }
+            // the row's largest magnitude (both half rows) -> its power-of-two scale: max * s in [2^14, 2^15)
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const uint32_t eb = min(max(__float_as_uint(m) >> 23, 16u), 254u);
+            const float sc = __uint_as_float((268u - eb) << 23);
+            pin[p] = __uint_as_float((eb - 14u) << 23);
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb) {
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nww_split2h(v[kb][2 * e] * sc, v[kb][2 * e + 1] * sc, hi[e], lo[e]);
+                xf[p][kb][0] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+                xf[p][kb][1] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+            }
         }
     } else {
 #pragma unroll
@@ -232,7 +271,10 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
                     for (int t = 0; t < NTM; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * NTM + t) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (AT == 2) {
+            if constexpr (AT == 3) {
+                mfma3h(cw[0], xf[0][kb], acc[0]);
+                mfma3h(cw[1], xf[1][kb], acc[1]);
+            } else if constexpr (AT == 2) {
                 mfma2h(cw[0], xf[0][kb][0], acc[0]);
                 mfma2h(cw[1], xf[1][kb][0], acc[1]);
             } else if constexpr (AT == 1) {
@@ -247,6 +289,10 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
         // the next weight block's LDS-DMA must have landed before the barrier behind this block: waited for here, BEFORE the
         // stores (vmcnt counts them too - waiting after them made every block sit out the write latency of its own outputs)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (AT == 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] *= pin[0]; acc[1][r] *= pin[1]; }
+        }
         // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
         if (!MEAN && !row_ok) return;
         const float* aff = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
@@ -335,6 +381,7 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
         return hipErrorInvalidValue;
     if (a0.x && (a0.Ho <= 0 || a0.Wo <= 0 || a0.M % (a0.Ho * a0.Wo) != 0)) return hipErrorInvalidValue;
     DualArgs a = a0;
+    if (a.act16) a.h2 = 0;
     a.nblk = (a.N + 31) / 32;
     if (a.mean_out) {
         if (!dual_x3_mean_supported(a.mean_P) || a.M % a.mean_P != 0 || K != 128) return hipErrorInvalidValue;      // (the last block: K = 128)
@@ -348,6 +395,7 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
             else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 2, 4, true>), gridm, dim3(256), 0, s, a);             \
         } else if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 8, true>), gridm, dim3(512), 0, s, a);      \
         else if (a.act16) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 4, true>), gridm, dim3(256), 0, s, a);    \
+        else if (a.h2) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 3, 4, true>), gridm, dim3(256), 0, s, a);       \
         else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 0, 4, true>), gridm, dim3(256), 0, s, a);
         switch (act) {
             case ACT_RELU: DUAL_MEAN(ACT_RELU) break;
@@ -371,6 +419,7 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
         hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 1, 8>), grid, dim3(512), 0, s, a);                          \
     } else {                                                                                                       \
         if (a.act16) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 1, 4>), grid, dim3(256), 0, s, a);             \
+        else if (a.h2) hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 3, 4>), grid, dim3(256), 0, s, a);           \
         else hipLaunchKernelGGL((dual_x3_kernel<K16V, ACTV, 0, 4>), grid, dim3(256), 0, s, a);                     \
     }
 #define DUAL_ACT(K16V)                                                                                             \

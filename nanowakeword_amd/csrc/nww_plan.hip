@@ -951,7 +951,16 @@ extern "C" int nww_finalize(nww_handle* h) {
                     // both products from split operands on the bf16 matrix cores (dual_x3.hip) under the same arithmetic switch
                     static const int dual_x3 = [] { const char* e = getenv("NWW_BC_DUAL_X3"); return e ? atoi(e) : 1; }();
                     void* packed = nullptr;
-                    const int terms = act_f16 ? 2 : 3;
+                    // float32 activations under NWW_ARITH_F16X3: two binary16 terms per operand, the activation rows scaled per pixel in
+                    // the kernel (DualArgs::h2) - no tensor bound needed; NWW_BC_DUAL_H2 = 0 keeps the three-term bf16 form
+                    static const int dual_h2_on = [] { const char* e = getenv("NWW_BC_DUAL_H2"); return e ? atoi(e) : 1; }();
+                    const bool dual_h2 = dual_h2_on && p.h->f16 && !act_bf16;
+                    if (dual_h2) {
+                        dps[i].pw_ws = f16_wscale(f16_fetch(p.h, wpw, (size_t)co * ci)); dps[i].sc_ws = f16_wscale(f16_fetch(p.h, wsc, (size_t)co * ci));
+                        if (!(dps[i].pw_ws > 0.f && dps[i].sc_ws > 0.f)) return fail(h, NWW_ERR_INVALID, "block %d: non-finite weights", i);
+                        dps[i].pw_un = 1.0f / dps[i].pw_ws; dps[i].sc_un = 1.0f / dps[i].sc_ws;
+                    }
+                    const int terms = act_f16 || dual_h2 ? 2 : 3;
                     if (dual_x3 && p.h->conv_products == 6 && dual_x3_supported(ci, co) &&
                         hipMalloc(&packed, dual_x3_packed_bytes(ci, co, terms)) == hipSuccess) {
                         if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream, terms, dps[i]) == hipSuccess) {
@@ -971,10 +980,10 @@ extern "C" int nww_finalize(nww_handle* h) {
                             if (act_f16 && i == 3 && !fuse_mean)
                                 return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = f16 needs the global average pool fused into the last block (%d pixels per clip)", rows);
                             const float out_mul = fuse_mean ? 1.0f : s_h[i];
-                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : ""), [=](Run& r) {
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : dual_h2 ? " [f16x3]" : ""), [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
                                 if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
-                                a.act16 = act16; a.out_mul = out_mul;
+                                a.act16 = act16; a.out_mul = out_mul; a.h2 = dual_h2 ? 1 : 0;
                                 if (fuse_mean) { a.mean_out = r.buf[5]; a.mean_P = rows; }
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });

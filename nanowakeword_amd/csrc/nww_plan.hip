@@ -1,5 +1,6 @@
 // nww_plan.hip - Model.state_dict() spec per head and the launch plans nww_finalize builds from the loaded weights.
 #include "nww_internal.h"
+#include "bc_chain.h"
 #define prof_mark nww_prof_mark
 #define prof_begin nww_prof_begin
 #define ensure_ws nww_ensure_ws
@@ -932,15 +933,23 @@ extern "C" int nww_finalize(nww_handle* h) {
             bool mean_fused = false;
             const int ch[4] = {32, 64, 128, 256};
             const int st[3][2] = {{2, 2}, {2, 2}, {2, 1}};
+            // d_i / xs_i (depthwise output and strided block input) of the coming block live in buffers dwb / xsb; have_dx: they are
+            // already there - written by the fused front kernel or by the previous block's chained kernel (bc_chain.hip)
+            int dwb = 2, xsb = 3;
+            bool have_dx = front_fused;
+            static const int chain_on = [] { const char* e = getenv("NWW_BC_CHAIN"); return e ? atoi(e) : 1; }();
             for (int i = 1; i <= 3; ++i) {
                 const std::string q = "model.block" + std::to_string(i);
                 const int ci = ch[i - 1], co = ch[i], sh = st[i - 1][0], sw = st[i - 1][1];
                 const int ho = (hh - 1) / sh + 1, wo = (ww - 1) / sw + 1;
-                const int dwb = 2, xsb = 3, resb = 4, outb = cur ^ 1;
+                int outb = 4;
+                for (int cand : {0, 1, 4})
+                    if (cand != cur && cand != dwb && cand != xsb) { outb = cand; break; }
+                const int resb = 4;
                 p.need(dwb, (size_t)ci * ho * wo); p.need(xsb, (size_t)ci * ho * wo);
                 const float* dwt = p.W(q + ".depthwise.weight_t");
                 const int hin = hh, win = ww;
-                if (!(front_fused && i == 1))
+                if (!have_dx)
                     p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], r.buf[xsb], r.B, ci, hin, win, sh, sw, r.stream); });
                 // one dual GEMM per block: shortcut and pointwise products in the same workgroup, no residual round trip
                 {
@@ -967,11 +976,31 @@ extern "C" int nww_finalize(nww_handle* h) {
                             p.h->packed_weights.push_back(packed);
                             // when the block input is in HBM (every block but the one whose depthwise ran inside the fused front kernel) the
                             // shortcut rows are gathered from it and the depthwise kernel planned just above writes no copy of them
-                            const bool gather = !(front_fused && i == 1);
+                            const bool gather = !have_dx;
                             if (gather) {
                                 const float dw_mul = s_d[i] / s_h[i - 1];
                                 p.pop_last();
                                 p.add("dwconv3x3_nhwc:" + q, [=](Run& r) { return launch_dwconv3x3_nhwc(r.buf[cur], dwt, r.buf[dwb], nullptr, r.B, ci, hin, win, sh, sw, r.stream, act16, dw_mul); });
+                            }
+                            // blocks 1 and 2 chained with the next block's depthwise (bc_chain.hip): the block's output stays in LDS, the
+                            // next block finds its d / xs rows in the other buffer pair
+                            const char* suffix = act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : dual_h2 ? " [f16x3]" : "";
+                            if (chain_on && i < 3 && have_dx && terms == 2 && bc_chain_supported(ci, ho, wo)) {
+                                const std::string qn = "model.block" + std::to_string(i + 1);
+                                const float* dwn = p.W(qn + ".depthwise.weight_t");
+                                const int sh2 = st[i][0], sw2 = st[i][1], ho2 = (ho - 1) / sh2 + 1, wo2 = (wo - 1) / sw2 + 1;
+                                const int odb = dwb == 2 ? 0 : 2, oxb = odb + 1, idb = dwb, ixb = xsb;
+                                p.need(odb, (size_t)co * ho2 * wo2); p.need(oxb, (size_t)co * ho2 * wo2);
+                                const float d_mul = s_d[i + 1], xs_mul = s_h[i];
+                                const int max_grid = p.h->cu_count;
+                                p.add("bc_chain:" + q + ".pointwise+bn+act + shortcut+bn -> " + qn + ".depthwise" + suffix, [=](Run& r) {
+                                    ChainArgs a{r.buf[idb], r.buf[ixb], r.buf[odb], r.buf[oxb], static_cast<const unsigned char*>(packed), dwn,
+                                                r.B, ho, wo, sh2, sw2, ho2, wo2};
+                                    a.act16 = act_f16 ? 2 : 0; a.d_mul = d_mul; a.xs_mul = xs_mul;
+                                    return launch_bc_chain(a, ci, act, max_grid, r.stream);
+                                });
+                                hh = ho; ww = wo; dwb = odb; xsb = oxb; have_dx = true;
+                                continue;
                             }
                             // the last block feeds only the global average pool: averaged in the same launch, its output never reaches HBM
                             static const int mean_fused_on = [] { const char* e = getenv("NWW_BC_MEAN_FUSED"); return e ? atoi(e) : 1; }();
@@ -980,14 +1009,14 @@ extern "C" int nww_finalize(nww_handle* h) {
                             if (act_f16 && i == 3 && !fuse_mean)
                                 return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = f16 needs the global average pool fused into the last block (%d pixels per clip)", rows);
                             const float out_mul = fuse_mean ? 1.0f : s_h[i];
-                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + (act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : dual_h2 ? " [f16x3]" : ""), [=](Run& r) {
+                            p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + suffix, [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
                                 if (gather) { a.x = r.buf[cur]; a.H = hin; a.W = win; a.Ho = ho; a.Wo = wo; a.sh = sh; a.sw = sw; }
                                 a.act16 = act16; a.out_mul = out_mul; a.h2 = dual_h2 ? 1 : 0;
                                 if (fuse_mean) { a.mean_out = r.buf[5]; a.mean_P = rows; }
                                 return launch_dual_x3(a, ci, act, r.stream);
                             });
-                            hh = ho; ww = wo; cur = outb;
+                            hh = ho; ww = wo; cur = outb; have_dx = false; dwb = 2; xsb = 3;
                             continue;
                         }
                         (void)hipFree(packed);
@@ -1003,7 +1032,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     });
                     (void)resb;
                 }
-                hh = ho; ww = wo; cur = outb;
+                hh = ho; ww = wo; cur = outb; have_dx = false; dwb = 2; xsb = 3;
             }
             const int hw = hh * ww;
             if (mean_fused) {

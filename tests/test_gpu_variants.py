@@ -138,6 +138,7 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_BC_FRONT": "2"}, [_BC], ["conv1_dw_mfma"], ["conv1_dw_x3"], False),          # fused front kernel on the float32 MFMA
     ({"NWW_E2E_TRANSPOSED": "0"}, [_E2E], ["trunk_x3", "conv3_x3"], ["transposed"], False),   # E2E head on the (n_mels, frames) plane
     ({"TEST_CONV_ARITH": "bf16x9"}, [_BC], ["conv1_dw_x3"], [], False),                 # fused front kernel, all nine partial products
+    ({"NWW_BC_CHAIN": "0"}, [_BC], ["dwconv3x3_nhwc:model.block2", "dwconv3x3_nhwc:model.block3", "[f16x3]"], ["bc_chain"], False),   # blocks unchained
     ({"NWW_BC_DUAL_H2": "0"}, [_BC], ["dual_x3"], ["+ shortcut+bn [f16x3]"], False),   # BcResNet block products on three bf16 terms under the default arithmetic
     ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                   # BcResNet block products on the float32-MFMA dual GEMM
     ({"NWW_GEMM_X3": "0"}, [_CNN], [], [], False),                                      # fc1 on the float32-MFMA GEMM
@@ -386,6 +387,50 @@ def test_bcresnet_bf16_activations(HipModel, golden_frontend):
     mbf.close(); m32.close()
     with pytest.raises(Exception, match="BcResNet"):
         HipModel(HeadConfig("cnn", (101, 64)), FrontendConfig(), act_dtype="bf16")
+
+
+_CHAIN_SCRIPT = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["NWW_ROOT"])
+from nanowakeword_amd.config import FrontendConfig, HeadConfig
+from nanowakeword_amd.session import HipModel
+from nanowakeword_amd.synth import synth_pcm, synth_state_dict
+out = {}
+for shape, n in (((101, 64), 16000), ((32, 40), None)):
+    for act_dtype in (None, "f16"):
+        cfg = HeadConfig("bcresnet", shape)
+        m = HipModel(cfg, FrontendConfig(n_mels=shape[1]), state_dict=synth_state_dict(cfg), act_dtype=act_dtype)
+        plan = m.describe_plan()
+        assert ("bc_chain" in plan) == (os.environ.get("NWW_BC_CHAIN", "1") != "0"), plan
+        if n:
+            lg, _ = m.forward_pcm(synth_pcm("speechlike", 300, n, seed=3))
+        else:
+            from nanowakeword_amd.synth import synth_features
+            lg, _ = m.forward_features(synth_features(37, shape, seed=2))
+        out[f"{shape[0]}_{act_dtype}"] = lg
+        m.close()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_bcresnet_chained_blocks_equal_unchained(tmp_path):
+    """bc_chain.hip keeps a block's output in LDS and runs the next block's depthwise on it; the same arithmetic in the same order as
+    dual_x3 + dwconv3x3_nhwc, so the float32 logits are bit-identical with the chain switched off (NWW_BC_CHAIN = 0), at the
+    BASELINE shape (13 / 8 work items per clip, ragged last pixel group) and at a small one; the f16-activation logits (whose unchained
+    path rounds the block output to binary16 before the depthwise, the chained one after) agree to 1e-2 (observed 6e-3 on N(0,1)-scale
+    features, whose first-layer activations are far from the log-mel statistics the scales assume)."""
+    res = {}
+    for chain in ("1", "0"):
+        out = str(tmp_path / f"chain{chain}.npz")
+        e = dict(os.environ, NWW_ROOT=ROOT, PYTHONPATH=os.pathsep.join([ROOT] + sys.path), NWW_BC_CHAIN=chain)
+        r = subprocess.run([sys.executable, "-c", _CHAIN_SCRIPT, out], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[chain] = dict(np.load(out))
+    for k in res["1"]:
+        if k.endswith("None"):
+            assert np.array_equal(res["1"][k], res["0"][k]), (k, float(np.abs(res["1"][k] - res["0"][k]).max()))
+        else:
+            assert np.abs(res["1"][k] - res["0"][k]).max() <= 1e-2, (k, float(np.abs(res["1"][k] - res["0"][k]).max()))
 
 
 def test_bcresnet_f16_activations(HipModel, golden_frontend):

@@ -903,17 +903,29 @@ extern "C" int nww_finalize(nww_handle* h) {
                 // the convolution from split operands on the bf16 matrix cores (trunk_b.hip) under the handle's arithmetic switch;
                 // NWW_BC_FRONT = 2 keeps the float32-MFMA kernel
                 void* fpack = nullptr;
-                const int fprod = p.h->conv_products;
-                if ((fprod == 6 || fprod == 9) && bc_front != 2 && bc_front_b_rows(T, F, 2) > 0 &&
+                int fprod = p.h->conv_products;
+                // under NWW_ARITH_F16X3 (BN present): two binary16 terms per operand, features clamped to +-NWW_F16_FEATURE_BOUND as in the
+                // CNN trunk; NWW_BC_FRONT_H2 = 0 keeps the three-term bf16 form
+                static const int front_h2_on = [] { const char* e = getenv("NWW_BC_FRONT_H2"); return e ? atoi(e) : 1; }();
+                float fin = 0.0f, fws = 1.0f;
+                if (front_h2_on && p.h->f16 && fprod == 6 && a0 && bc_front != 2) {
+                    fin = f16_scale(F16_FEATURES.bound); fws = f16_wscale(f16_fetch(p.h, w0, 32 * 9));
+                    if (fin > 0.0f && fws > 0.0f) fprod = 3;
+                }
+                if ((fprod == 6 || fprod == 9 || fprod == 3) && bc_front != 2 && bc_front_b_rows(T, F, 2) > 0 &&
                     hipMalloc(&fpack, bc_front_b_packed_bytes()) == hipSuccess) {
-                    if (launch_bc_front_b_pack(w0, static_cast<unsigned char*>(fpack), p.h->own_stream) == hipSuccess) p.h->packed_weights.push_back(fpack);
+                    const hipError_t pe = fprod == 3 ? launch_bc_front_b_pack_f16(w0, static_cast<unsigned char*>(fpack), fws, p.h->own_stream)
+                                                     : launch_bc_front_b_pack(w0, static_cast<unsigned char*>(fpack), p.h->own_stream);
+                    if (pe == hipSuccess) p.h->packed_weights.push_back(fpack);
                     else { (void)hipFree(fpack); fpack = nullptr; }
                 }
-                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_f16 ? ", f16 out)" : act_bf16 ? ", bf16 out)" : ")"), [=](Run& r) {
+                const float f_un = 1.0f / (fin > 0.0f ? fin * fws : 1.0f);
+                p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_f16 ? ", f16 out)" : act_bf16 ? ", bf16 out)" : ")") + (fpack && fprod == 3 ? " [f16x3]" : ""), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
                     a.bf16_out = act16; a.d_scale = s_d[1]; a.xs_scale = s_h[0];
                     if (fpack) {
                         a.wpack = static_cast<const unsigned char*>(fpack);
+                        a.f16_in = fin; a.f16_clamp = NWW_F16_FEATURE_BOUND; a.f16_unscale = f_un;
                         return launch_bc_front_b(a, fprod, max_grid, r.stream);
                     }
                     return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);

@@ -107,10 +107,14 @@ struct Conv1DwArgs {
     int bf16_out = 0;                // nww_config.act_dtype: 1 = d_out / xs_out are bf16 arrays, 2 = binary16 arrays of value x scale
     float d_scale = 1.0f, xs_scale = 1.0f;   // bf16_out == 2: the tensors' plan-time power-of-two scales
     const unsigned char* wpack = nullptr;   // launch_bc_front_b only: conv weight fragments (launch_bc_front_b_pack)
+    // launch_bc_front_b with products = 3 (two binary16 terms; weights from launch_bc_front_b_pack_f16 with scale sw): the input is
+    // clamped to +-f16_clamp and multiplied by f16_in; f16_unscale = 1 / (f16_in * sw)
+    float f16_in = 0.0f, f16_clamp = 0.0f, f16_unscale = 1.0f;
 };
 // the same stage with the convolution from split operands on the bf16 matrix cores (trunk_b.hip); products = 6 / 9
 size_t bc_front_b_packed_bytes();
 hipError_t launch_bc_front_b_pack(const float* w1, unsigned char* packed, hipStream_t s);
+hipError_t launch_bc_front_b_pack_f16(const float* w1, unsigned char* packed, float sw, hipStream_t s);
 int bc_front_b_rows(int H, int W, int sh);         // depthwise rows per LDS strip, 0 = does not fit
 hipError_t launch_bc_front_b(const Conv1DwArgs& a, int products, int max_grid, hipStream_t s);
 int conv1_pool_dw_rows(int H, int W, int sh);      // depthwise rows per LDS strip, 0 = does not fit

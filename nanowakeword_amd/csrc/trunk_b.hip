@@ -816,8 +816,34 @@ __global__ void __launch_bounds__(64) bc_front_pack_kernel(const float* __restri
         }
 }
 
+// two binary16 terms of weight x sw: fragments [set][dy][term]
+__global__ void __launch_bounds__(64) bc_front_pack_f16_kernel(const float* __restrict__ w1, unsigned char* __restrict__ out, float sw) {
+    const int lane = threadIdx.x, m = lane & 31, hi = lane >> 5;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out);
+    const int cw = 8 * ((m >> 2) & 1) + 2 * (m >> 3) + ((m >> 1) & 1), dxw = m & 1;
+    for (int set = 0; set < 2; ++set)
+        for (int dy = 0; dy < 2; ++dy) {
+            float v[8];
+            for (int kk = 0; kk < 8; ++kk) {
+                const int ty = 2 * hi + (kk >> 2) - dy, tx = (kk & 3) - dxw;
+                const bool in = ty >= 0 && ty < 3 && tx >= 0 && tx < 3;
+                v[kk] = in ? w1[(16 * set + cw) * 9 + ty * 3 + tx] * sw : 0.0f;
+            }
+            uint32_t th[4], tl[4];
+            for (int j = 0; j < 4; ++j) nww_split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
+            const int f = (set * 2 + dy) * 2;
+            o[(f + 0) * 64 + lane] = frag4(th[0], th[1], th[2], th[3]);
+            o[(f + 1) * 64 + lane] = frag4(tl[0], tl[1], tl[2], tl[3]);
+        }
+}
+
+// PRODUCTS = 3 (BN only): two binary16 terms per operand - the input times a.f16_in (clamped to +-a.f16_clamp first) in TWO planes, the
+// weights packed by bc_front_pack_f16_kernel; the accumulators are k = f16_in x weight scale times the true sums and a.f16_unscale =
+// 1 / k goes into the folded-BN factor (pool_quad's comment)
 template <int ACT, int PRODUCTS, bool BN>
 __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
+    constexpr bool F16 = PRODUCTS == 3;
+    constexpr int NT = F16 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int H = a.H, W = a.W, H1 = H / 2, W1 = W / 2;
     const int Ho = a.Ho, Wo = a.Wo, sh = a.sh, sw = a.sw;
@@ -826,17 +852,17 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     float* const Wd = reinterpret_cast<float*>(lds_raw);
     float* const BNp = Wd + 288;
     unsigned char* const In3 = lds_raw + BF_HEAD;
-    float* const P = reinterpret_cast<float*>(In3 + 3 * plane_b);
+    float* const P = reinterpret_cast<float*>(In3 + NT * plane_b);
     const int W1p = (W1 + 3) & ~3;                            // pixel slots per P row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hi = lane >> 5;
 
-    for (int k = tid; k < 3 * plane_b / 4; k += NTHR) reinterpret_cast<uint32_t*>(In3)[k] = 0u;       // halo columns stay zero
+    for (int k = tid; k < NT * plane_b / 4; k += NTHR) reinterpret_cast<uint32_t*>(In3)[k] = 0u;      // halo columns stay zero
     for (int k = tid; k < 288; k += NTHR) Wd[k] = a.dw_wt[k];
     if (tid < 32) {
-        BNp[tid] = a.bias ? a.bias[tid] : 0.0f;
-        BNp[32 + tid] = (BN && a.alpha) ? a.alpha[tid] : 1.0f;
+        BNp[tid] = a.bias ? a.bias[tid] * (F16 ? 1.0f / a.f16_unscale : 1.0f) : 0.0f;
+        BNp[32 + tid] = (BN && a.alpha) ? a.alpha[tid] * (F16 ? a.f16_unscale : 1.0f) : 1.0f;
         BNp[64 + tid] = (BN && a.alpha) ? a.beta[tid] : 0.0f;
     }
     __syncthreads();
@@ -844,7 +870,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     const int set = wave & 1;
     bf16x8 wf[2][3];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) wf[q / 3][q % 3] = *reinterpret_cast<const bf16x8*>(a.wpack + (set * 6 + q) * 1024 + lane * 16);      // (straight from the packed image: 12 KB of LDS more for P)
+    for (int q = 0; q < 2 * NT; ++q) wf[q / NT][q % NT] = *reinterpret_cast<const bf16x8*>(a.wpack + (set * 2 * NT + q) * 1024 + lane * 16);      // (straight from the packed image: 12 KB of LDS more for P)
 
     const int nstrips = (Ho + a.rows_dw - 1) / a.rows_dw;
     const int ngx = (W1 + 31) / 32;
@@ -881,15 +907,30 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             if (idx4 < n4) {
                 const int lr = (4 * idx4) / W, x = 4 * idx4 - lr * W;
                 unsigned char* d = In3 + (lr * Wp0 + x + 1) * 2;
-                uint32_t w[3][4];
-                split3(pre[q].x, w[0][0], w[1][0], w[2][0]); split3(pre[q].y, w[0][1], w[1][1], w[2][1]);
-                split3(pre[q].z, w[0][2], w[1][2], w[2][2]); split3(pre[q].w, w[0][3], w[1][3], w[2][3]);
+                if constexpr (F16) {
+                    const float cl = a.f16_clamp, sc = a.f16_in;
+                    uint32_t h01, l01, h23, l23;
+                    nww_split2h(__builtin_amdgcn_fmed3f(pre[q].x, -cl, cl) * sc, __builtin_amdgcn_fmed3f(pre[q].y, -cl, cl) * sc, h01, l01);
+                    nww_split2h(__builtin_amdgcn_fmed3f(pre[q].z, -cl, cl) * sc, __builtin_amdgcn_fmed3f(pre[q].w, -cl, cl) * sc, h23, l23);
+                    const uint32_t hh[2][2] = {{h01, h23}, {l01, l23}};
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    unsigned char* p = d + t * plane_b;
-                    *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
-                    *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
-                    *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+                    for (int t = 0; t < 2; ++t) {
+                        unsigned char* p = d + t * plane_b;
+                        *reinterpret_cast<uint16_t*>(p) = (uint16_t)(hh[t][0] & 0xffffu);
+                        *reinterpret_cast<uint32_t*>(p + 2) = (hh[t][0] >> 16) | (hh[t][1] << 16);
+                        *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(hh[t][1] >> 16);
+                    }
+                } else {
+                    uint32_t w[3][4];
+                    split3(pre[q].x, w[0][0], w[1][0], w[2][0]); split3(pre[q].y, w[0][1], w[1][1], w[2][1]);
+                    split3(pre[q].z, w[0][2], w[1][2], w[2][2]); split3(pre[q].w, w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        unsigned char* p = d + t * plane_b;
+                        *reinterpret_cast<uint16_t*>(p) = (uint16_t)(w[t][0] >> 16);
+                        *reinterpret_cast<uint32_t*>(p + 2) = pack_hi16(w[t][1], w[t][2]);
+                        *reinterpret_cast<uint16_t*>(p + 6) = (uint16_t)(w[t][3] >> 16);
+                    }
                 }
             }
         }
@@ -901,12 +942,20 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         const float* xin = a.in + (size_t)b * H * W;
         for (int idx = tid; idx < n; idx += NTHR) {
             const int lr = idx / W, x = idx - lr * W, y = y0 + lr;
-            uint32_t wh, wm, wlo;
-            split3((y >= 0 && y < H) ? xin[(size_t)y * W + x] : 0.0f, wh, wm, wlo);
+            const float v = (y >= 0 && y < H) ? xin[(size_t)y * W + x] : 0.0f;
             unsigned char* d = In3 + (lr * Wp0 + x + 1) * 2;
-            *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
-            *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
-            *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+            if constexpr (F16) {
+                uint32_t hh, ll;
+                nww_split2h(__builtin_amdgcn_fmed3f(v, -a.f16_clamp, a.f16_clamp) * a.f16_in, 0.0f, hh, ll);
+                *reinterpret_cast<uint16_t*>(d) = (uint16_t)(hh & 0xffffu);
+                *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(ll & 0xffffu);
+            } else {
+                uint32_t wh, wm, wlo;
+                split3(v, wh, wm, wlo);
+                *reinterpret_cast<uint16_t*>(d) = (uint16_t)(wh >> 16);
+                *reinterpret_cast<uint16_t*>(d + plane_b) = (uint16_t)(wm >> 16);
+                *reinterpret_cast<uint16_t*>(d + 2 * plane_b) = (uint16_t)(wlo >> 16);
+            }
         }
     };
     const int cq = tid & 7, dslot = tid >> 3;                  // depthwise: four channels 4 cq .., NTHR / 8 output slots
@@ -933,7 +982,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             const unsigned char* base = In3 + (2 * Rl + 2 * hi) * pitch0 + 4 * xc;
             bf16x8 cf[3];
 #pragma unroll
-            for (int tt = 0; tt < 3; ++tt) {
+            for (int tt = 0; tt < NT; ++tt) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(base + tt * plane_b);
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(base + tt * plane_b + pitch0);
                 cf[tt] = frag4(p[0], p[1], q[0], q[1]);
@@ -1164,6 +1213,11 @@ hipError_t launch_bc_front_b_pack(const float* w1, unsigned char* packed, hipStr
     hipLaunchKernelGGL(bc_front_pack_kernel, dim3(1), dim3(64), 0, s, w1, packed);
     return hipGetLastError();
 }
+hipError_t launch_bc_front_b_pack_f16(const float* w1, unsigned char* packed, float sw, hipStream_t s) {
+    hipLaunchKernelGGL(bc_front_pack_f16_kernel, dim3(1), dim3(64), 0, s, w1, packed, sw);
+    return hipGetLastError();
+}
+// (the strip height follows the three-term form's LDS need in every arithmetic: how a clip is cut does not depend on the switch)
 static size_t bc_front_b_lds(int W, int sh, int rows_dw) {
     const BfGeom g = bf_geom(W, sh, rows_dw);
     return (size_t)BF_HEAD + 3 * (size_t)g.plane_b + (size_t)g.max_conv * ((W / 2 + 3) & ~3) * 32 * sizeof(float) + 16;
@@ -1178,7 +1232,8 @@ int bc_front_b_rows(int H, int W, int sh) {
     return best;
 }
 hipError_t launch_bc_front_b(const Conv1DwArgs& a0, int products, int max_grid, hipStream_t s) {
-    if (!a0.wpack || (products != 6 && products != 9)) return hipErrorInvalidValue;
+    if (!a0.wpack || (products != 6 && products != 9 && products != 3)) return hipErrorInvalidValue;
+    if (products == 3 && !(a0.alpha && a0.f16_in > 0.0f && a0.f16_unscale > 0.0f)) return hipErrorInvalidValue;
     Conv1DwArgs a = a0;
     a.rows_dw = bc_front_b_rows(a.H, a.W, a.sh);
     if (a.rows_dw <= 0) return hipErrorInvalidValue;
@@ -1199,7 +1254,7 @@ hipError_t launch_bc_front_b(const Conv1DwArgs& a0, int products, int max_grid, 
 #define BF_BN(ACTV, PRODV)                                                                                             \
     if (bn) BF_LAUNCH(ACTV, PRODV, true) else BF_LAUNCH(ACTV, PRODV, false)
 #define BF_ACT(ACTV)                                                                                                   \
-    if (products == 6) BF_BN(ACTV, 6) else BF_BN(ACTV, 9)
+    if (products == 3) BF_LAUNCH(ACTV, 3, true) else if (products == 6) BF_BN(ACTV, 6) else BF_BN(ACTV, 9)
     switch (a.act) {
         case ACT_RELU: BF_ACT(ACT_RELU) break;
         case ACT_GELU: BF_ACT(ACT_GELU) break;

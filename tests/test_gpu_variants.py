@@ -138,6 +138,7 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_BC_FRONT": "2"}, [_BC], ["conv1_dw_mfma"], ["conv1_dw_x3"], False),          # fused front kernel on the float32 MFMA
     ({"NWW_E2E_TRANSPOSED": "0"}, [_E2E], ["trunk_x3", "conv3_x3"], ["transposed"], False),   # E2E head on the (n_mels, frames) plane
     ({"TEST_CONV_ARITH": "bf16x9"}, [_BC], ["conv1_dw_x3"], [], False),                 # fused front kernel, all nine partial products
+    ({"NWW_BC_FRONT_H2": "0"}, [_BC], ["conv1_dw_x3"], ["depthwise (nhwc) [f16x3]"], False),   # fused front kernel on three bf16 terms under the default arithmetic
     ({"NWW_BC_CHAIN": "0"}, [_BC], ["dwconv3x3_nhwc:model.block2", "dwconv3x3_nhwc:model.block3", "[f16x3]"], ["bc_chain"], False),   # blocks unchained
     ({"NWW_BC_DUAL_H2": "0"}, [_BC], ["dual_x3"], ["+ shortcut+bn [f16x3]"], False),   # BcResNet block products on three bf16 terms under the default arithmetic
     ({"NWW_BC_DUAL_X3": "0"}, [_BC], ["gemm2:"], ["dual_x3"], False),                   # BcResNet block products on the float32-MFMA dual GEMM

@@ -95,7 +95,8 @@ hipError_t launch_layernorm_parts(const float* parts, int nparts, size_t part_st
 hipError_t launch_layernorm(const float* x, float* y, const float* w, const float* b, int R, int D, int act,
                             hipStream_t s);
 // mean over the middle axis: in [B][L][D] -> out [B][D]   (global average pools / mean over time)
-hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, bool bf16_in = false);
+// act16 = 1 / 2: `in` is a bf16 / scaled binary16 array (nww_config.act_dtype); binary16: the means are multiplied by unscale
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, int act16 = 0, float unscale = 1.0f);
 // LayerNorm over D of every row of [B][L][D], then the mean over L -> out [B][D] (D <= 256)
 hipError_t launch_ln_mean(const float* x, float* out, const float* w, const float* b, int B, int L, int D, hipStream_t s);
 // AvgPool2d(kernel (kh,kw), stride (sh,sw)) on [B*C][H][W] -> [B*C][oh][ow]  (export form of AdaptiveAvgPool2d)

@@ -719,14 +719,19 @@ hipError_t launch_transpose_planes(const float* in, float* out, int B, int R, in
 
 // ------------------------------------------------------------------------------------------ reductions / pools
 __global__ void __launch_bounds__(256)
-mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total, int bf16) {
+mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int D, size_t total, int bf16, float unscale) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*D + d
     if (idx >= total) return;
     const size_t b = idx / D, d = idx - b * D;
     float s = 0.0f;
     if (bf16) {                                                     // bf16 activations in, float32 mean out
         const uint16_t* p = reinterpret_cast<const uint16_t*>(in) + b * (size_t)L * D + d;
-        for (int l = 0; l < L; ++l) s += __uint_as_float((uint32_t)p[(size_t)l * D] << 16);
+        if (bf16 == ACT16_F16) {
+            for (int l = 0; l < L; ++l) s += (float)__builtin_bit_cast(_Float16, p[(size_t)l * D]);
+            s *= unscale;
+        } else {
+            for (int l = 0; l < L; ++l) s += __uint_as_float((uint32_t)p[(size_t)l * D] << 16);
+        }
     } else {
         const float* p = in + b * (size_t)L * D + d;
         for (int l = 0; l < L; ++l) s += p[(size_t)l * D];
@@ -774,19 +779,25 @@ hipError_t launch_ln_mean(const float* x, float* out, const float* w, const floa
     return hipGetLastError();
 }
 
-// bf16 rows: a thread owns eight channels (16-byte loads)
+// 16-bit rows (KIND = ACT16_BF16 / ACT16_F16 of split_h2.h; binary16: times unscale = 1 / the tensor's scale): a thread owns eight
+// channels (16-byte loads)
+template <int KIND>
 __global__ void __launch_bounds__(256)
-mean_mid_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ out, int L, int D, size_t total8) {
+mean_mid_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int L, int D, size_t total8, float unscale) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // idx = b*(D/8) + d8
     if (idx >= total8) return;
     const int D8 = D / 8;
     const size_t b = idx / D8, d8 = idx - b * D8;
-    const __bf16* p = in + b * (size_t)L * D + 8 * d8;
+    const uint16_t* p = in + b * (size_t)L * D + 8 * d8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto add_row = [&](const uint4 v) {
         const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(u[e] << 16); s[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+        for (int e = 0; e < 4; ++e) {
+            float lo, hi;
+            nww_unpk_act16(KIND, u[e], lo, hi);
+            s[2 * e] += lo; s[2 * e + 1] += hi;
+        }
     };
     int l = 0;
     for (; l + 8 <= L; l += 8) {                                    // eight rows in flight, added in ascending l
@@ -799,7 +810,7 @@ mean_mid_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ out, int
     for (; l < L; ++l) add_row(*reinterpret_cast<const uint4*>(p + (size_t)l * D));
     float* o = out + b * D + 8 * d8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = s[e] / (float)L;
+    for (int e = 0; e < 8; ++e) o[e] = (KIND == ACT16_F16 ? s[e] * unscale : s[e]) / (float)L;
 }
 // float32 rows: a thread owns four channels (16-byte loads, eight rows in flight); per channel the same ascending-l sum
 __global__ void __launch_bounds__(256)
@@ -825,10 +836,12 @@ mean_mid_f32x4_kernel(const float* __restrict__ in, float* __restrict__ out, int
     const float fl = (float)L;
     *reinterpret_cast<float4*>(out + b * D + 4 * d4) = make_float4(s.x / fl, s.y / fl, s.z / fl, s.w / fl);
 }
-hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, bool bf16) {
+hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hipStream_t s, int bf16, float unscale) {
     if (bf16 && D % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
         const size_t total8 = (size_t)B * (D / 8);
-        hipLaunchKernelGGL(mean_mid_bf16_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(in), out, L, D, total8);
+        const dim3 grid((unsigned)((total8 + 255) / 256));
+        if (bf16 == ACT16_F16) hipLaunchKernelGGL(mean_mid_bf16_kernel<ACT16_F16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), out, L, D, total8, unscale);
+        else hipLaunchKernelGGL(mean_mid_bf16_kernel<ACT16_BF16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), out, L, D, total8, 1.0f);
         return hipGetLastError();
     }
     if (!bf16 && D % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
@@ -837,7 +850,7 @@ hipError_t launch_mean_mid(const float* in, float* out, int B, int L, int D, hip
         return hipGetLastError();
     }
     const size_t total = (size_t)B * D;
-    hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total, bf16 ? 1 : 0);
+    hipLaunchKernelGGL(mean_mid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, L, D, total, bf16, unscale);
     return hipGetLastError();
 }
 

@@ -1018,8 +1018,6 @@ extern "C" int nww_finalize(nww_handle* h) {
                             static const int mean_fused_on = [] { const char* e = getenv("NWW_BC_MEAN_FUSED"); return e ? atoi(e) : 1; }();
                             const bool fuse_mean = mean_fused_on && i == 3 && ci == 128 && dual_x3_mean_supported(rows);
                             if (fuse_mean) { mean_fused = true; p.need(5, 256); }
-                            if (act_f16 && i == 3 && !fuse_mean)
-                                return fail(h, NWW_ERR_UNSUPPORTED, "act_dtype = f16 needs the global average pool fused into the last block (%d pixels per clip)", rows);
                             const float out_mul = fuse_mean ? 1.0f : s_h[i];
                             p.add(std::string(gather ? "dual_x3(xs gathered):" : "dual_x3:") + q + ".pointwise+bn+act + shortcut+bn" + (fuse_mean ? " + global_avg_pool" : "") + suffix, [=](Run& r) {
                                 DualArgs a{r.buf[dwb], r.buf[xsb], r.buf[outb], static_cast<const unsigned char*>(packed), r.B * rows, co};
@@ -1052,7 +1050,8 @@ extern "C" int nww_finalize(nww_handle* h) {
                 break;
             }
             p.need(2, 256);
-            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream, act_bf16); });
+            const float mean_un = act_f16 ? 1.0f / s_h[3] : 1.0f;
+            p.add("mean:global_avg_pool", [=](Run& r) { return launch_mean_mid(r.buf[cur], r.buf[2], r.B, hw, 256, r.stream, act16, mean_un); });
             set_tail(p, "fc", 2, 256, p.W("model.fc.weight"), p.W("model.fc.bias"));
             break;
         }

@@ -355,6 +355,47 @@ def test_arithmetic_modes_against_float64(hip):
             assert err[mode] <= 2.0 * err["f32"] + 2e-6, (head, mode, err)
 
 
+def test_bcresnet_shapes_activations_and_storage(hip):
+    """The BcResNet head's round-4 kernels (two-term front kernel, blocks chained with the next depthwise in bc_chain.hip, two-term
+    dual_x3 with per-pixel scales) on shapes whose planes are ragged against the 32-pixel work items, with every activation, odd
+    batch sizes (fewer clips than persistent workgroups, and more), against the oracle: float32 storage at the head tolerance,
+    binary16 storage (act_dtype = f16) at 1e-2.  Weight scales 2^-10 .. 2^10 per layer (the plan-time scales move with them) change
+    nothing beyond float32 rounding."""
+    HipModel, _ = hip
+    for shape, kw in (((101, 64), {}), ((48, 40), {"activation": "gelu"}), ((61, 36), {"activation": "silu"}), ((32, 40), {}),
+                      ((200, 64), {}), ((101, 80), {"activation": "gelu"})):
+        cfg = HeadConfig("bcresnet", shape, **kw)
+        sd = synth_state_dict(cfg)
+        for B in (5, 300):
+            feats = synth_features(B, cfg.input_shape, seed=B)
+            ref = oracle.model_forward(feats[:24], sd, cfg).ravel()
+            for act_dtype, tol in ((None, FEAT_LOGIT_ATOL), ("f16", 1e-2)):
+                m = HipModel(cfg, FrontendConfig(n_mels=shape[1]), state_dict=sd, act_dtype=act_dtype)
+                lg, _ = m.forward_features(feats)
+                d = float(np.abs(lg[:24] - ref).max())
+                assert d <= tol, (shape, kw, B, act_dtype, d, m.describe_plan())
+                m.close()
+    cfg = HeadConfig("bcresnet", (101, 64))
+    base = synth_state_dict(cfg)
+    feats = synth_features(6, cfg.input_shape, seed=9)
+    ref = oracle.model_forward(feats, base, cfg).ravel()
+    for e0, e1, e2, e3 in ((10, -10, 0, 0), (-10, 0, 10, 0), (0, 10, 0, -10), (4, 4, -4, -4)):
+        sd = {k: v.copy() for k, v in base.items()}
+        # scaling a conv's weights in front of a BatchNorm is absorbed by scaling the BN statistics: the network's function is unchanged
+        for name, bn, e in (("model.init_conv.0", "model.init_conv.1", e0), ("model.block1.pointwise", "model.block1.bn1", e1),
+                            ("model.block2.shortcut.0", "model.block2.shortcut.1", e2), ("model.block3.pointwise", "model.block3.bn1", e3)):
+            f = np.float32(2.0 ** e)
+            sd[name + ".weight"] = (sd[name + ".weight"] * f).astype(np.float32)
+            sd[bn + ".running_mean"] = (sd[bn + ".running_mean"] * f).astype(np.float32)
+            sd[bn + ".running_var"] = ((sd[bn + ".running_var"] + np.float32(1e-5)) * f * f - np.float32(1e-5)).astype(np.float32)
+        for act_dtype, tol in ((None, 2 * FEAT_LOGIT_ATOL), ("f16", 1e-2)):
+            m = HipModel(cfg, FrontendConfig(), state_dict=sd, act_dtype=act_dtype)
+            lg, _ = m.forward_features(feats)
+            d = float(np.abs(lg - ref).max())
+            assert d <= tol, ((e0, e1, e2, e3), act_dtype, d)
+            m.close()
+
+
 def test_f16x3_scales_clamp_and_activations(hip):
     """The two-term binary16 arithmetic (nww_config.conv_arith = NWW_ARITH_F16X3, the default): power-of-two scales fixed at plan
     time from bounds on the tensors.  (i) every activation / BatchNorm form of the fused trunk (CNN: bias only; CRNN / E2E: folded

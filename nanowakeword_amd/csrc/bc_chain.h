@@ -12,8 +12,9 @@ struct ChainArgs {
     const float* dw_wt;              // [9][N] the next block's depthwise weights, tap-major
     int B, H, W;                     // this block's output plane
     int sh, sw, Ho, Wo;              // the next block's depthwise stride and output plane
-    // 0: float32 tensors, products on two binary16 terms with a per-pixel scale (DualArgs::h2); 2: binary16 tensors times their
-    // plan-time scales (DualArgs::act16 = 2), d_mul / xs_mul = the scales of d_out / xs_out
+    // 0: float32 tensors, products on two binary16 terms with a per-pixel scale (DualArgs::h2); 1: bf16 tensors (one binary16 term after
+    // the per-pixel scale); 2: binary16 tensors times their plan-time scales (DualArgs::act16 = 2), d_mul / xs_mul = the scales of
+    // d_out / xs_out
     int act16 = 0;
     float d_mul = 1.0f, xs_mul = 1.0f;
 };

@@ -40,7 +40,8 @@ __device__ __forceinline__ float chain_act(float v) {
 
 __host__ __device__ constexpr int chain_blk_bytes(int K16) { return (2 * K16 * 2 * 1024 + 512 + 4095) & ~4095; }
 
-// K16 = K / 16; AT = 3 (float32 tensors) / 2 (binary16 tensors); BSPLIT = items per 32-pixel group (each owns NB / BSPLIT output
+// K16 = K / 16; AT = 3 (float32 tensors) / 2 (scaled binary16 tensors) / 1 (bf16 tensors: a bf16 value times its row's power-of-two
+// scale IS a binary16 value - one activation term, per-pixel scale as for float32); BSPLIT = items per 32-pixel group (each owns NB / BSPLIT output
 // blocks); MAXR = items per wave and clip; SW = the next block's depthwise stride along x (1 or 2)
 template <int K16, int ACT, int AT, int BSPLIT, int MAXR, int SW>
 __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
@@ -127,6 +128,34 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
                         xf[p][kb][1] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
                     }
                 }
+            } else if constexpr (AT == 1) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    uint32_t mb = 0;                           // largest |bf16| of the row as bits (integer order = magnitude order)
+#pragma unroll
+                    for (int kb = 0; kb < K16; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint2 q = raw[r][p][kb][j];
+                            mb = max(max(mb, q.x & 0x7fffu), max((q.x >> 16) & 0x7fffu, max(q.y & 0x7fffu, (q.y >> 16) & 0x7fffu)));
+                        }
+                    mb = max(mb, (uint32_t)__shfl_xor((int)mb, 32, 64));
+                    const uint32_t eb = min(max(mb >> 7, 16u), 254u);
+                    const float sc = __uint_as_float((268u - eb) << 23);
+                    pin[p] = __uint_as_float((eb - 14u) << 23);
+#pragma unroll
+                    for (int kb = 0; kb < K16; ++kb) {
+                        const uint2 q0 = raw[r][p][kb][0], q1 = raw[r][p][kb][1];
+                        const uint32_t u[4] = {q0.x, q0.y, q1.x, q1.y};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const nww_f32x2 v = {__uint_as_float(u[e] << 16) * sc, __uint_as_float(u[e] & 0xffff0000u) * sc};
+                            o[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nww_f16x2));
+                        }
+                        xf[p][kb][0] = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+                    }
+                }
             } else {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
@@ -180,7 +209,7 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (AT == 3) {
+                if constexpr (AT == 3 || AT == 1) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { acc[0][q] *= pin[0]; acc[1][q] *= pin[1]; }
                 }
@@ -252,9 +281,9 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
                             *reinterpret_cast<float4*>(static_cast<float*>(a.xs_out) + oi) = centre[j];
                         } else {
                             *reinterpret_cast<uint2*>(static_cast<uint16_t*>(a.d_out) + oi) =
-                                make_uint2(nww_pk_f16_sat(acc[j].x * a.d_mul, acc[j].y * a.d_mul), nww_pk_f16_sat(acc[j].z * a.d_mul, acc[j].w * a.d_mul));
+                                make_uint2(nww_pk_act16(AT, acc[j].x, acc[j].y, a.d_mul), nww_pk_act16(AT, acc[j].z, acc[j].w, a.d_mul));
                             *reinterpret_cast<uint2*>(static_cast<uint16_t*>(a.xs_out) + oi) =
-                                make_uint2(nww_pk_f16_sat(centre[j].x * a.xs_mul, centre[j].y * a.xs_mul), nww_pk_f16_sat(centre[j].z * a.xs_mul, centre[j].w * a.xs_mul));
+                                make_uint2(nww_pk_act16(AT, centre[j].x, centre[j].y, a.xs_mul), nww_pk_act16(AT, centre[j].z, centre[j].w, a.xs_mul));
                         }
                     }
                 }
@@ -280,7 +309,7 @@ bool bc_chain_supported(int K, int H, int W) {
 
 hipError_t launch_bc_chain(const ChainArgs& a, int K, int act, int max_grid, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;
-    if (!bc_chain_supported(K, a.H, a.W) || (a.act16 != 0 && a.act16 != 2) || a.Ho < 1 || a.Wo < 1 || (a.sw != 1 && a.sw != 2)) return hipErrorInvalidValue;
+    if (!bc_chain_supported(K, a.H, a.W) || (a.act16 < 0 || a.act16 > 2) || a.Ho < 1 || a.Wo < 1 || (a.sw != 1 && a.sw != 2)) return hipErrorInvalidValue;
     if (((reinterpret_cast<uintptr_t>(a.d) | reinterpret_cast<uintptr_t>(a.xs) | reinterpret_cast<uintptr_t>(a.d_out) | reinterpret_cast<uintptr_t>(a.xs_out) |
           reinterpret_cast<uintptr_t>(a.packed) | reinterpret_cast<uintptr_t>(a.dw_wt)) & 15) != 0)
         return hipErrorInvalidValue;
@@ -295,7 +324,7 @@ hipError_t launch_bc_chain(const ChainArgs& a, int K, int act, int max_grid, hip
 #define CHAIN_SW(K16V, ACTV, ATV, BSV, MAXRV)                                                                          \
     if (a.sw == 2) CHAIN_GO(K16V, ACTV, ATV, BSV, MAXRV, 2) else CHAIN_GO(K16V, ACTV, ATV, BSV, MAXRV, 1)
 #define CHAIN_AT(K16V, ACTV, BSV, MAXRV)                                                                               \
-    if (a.act16 == 2) { CHAIN_SW(K16V, ACTV, 2, BSV, MAXRV) } else { CHAIN_SW(K16V, ACTV, 3, BSV, MAXRV) }
+    if (a.act16 == 2) { CHAIN_SW(K16V, ACTV, 2, BSV, MAXRV) } else if (a.act16 == 1) { CHAIN_SW(K16V, ACTV, 1, BSV, MAXRV) } else { CHAIN_SW(K16V, ACTV, 3, BSV, MAXRV) }
 #define CHAIN_ACT(K16V, BSV, MAXRV)                                                                                    \
     switch (act) {                                                                                                     \
         case ACT_RELU: CHAIN_AT(K16V, ACT_RELU, BSV, MAXRV) break;                                                     \

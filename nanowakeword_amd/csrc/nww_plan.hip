@@ -976,12 +976,15 @@ extern "C" int nww_finalize(nww_handle* h) {
                     // the kernel (DualArgs::h2) - no tensor bound needed; NWW_BC_DUAL_H2 = 0 keeps the three-term bf16 form
                     static const int dual_h2_on = [] { const char* e = getenv("NWW_BC_DUAL_H2"); return e ? atoi(e) : 1; }();
                     const bool dual_h2 = dual_h2_on && p.h->f16 && !act_bf16;
-                    if (dual_h2) {
+                    // blocks 1 and 2 chained with the next block's depthwise (bc_chain.hip; two-term weights in every storage mode)
+                    const bool will_chain = chain_on && i < 3 && have_dx && bc_chain_supported(ci, ho, wo) &&
+                                            (act_f16 || dual_h2 || (act16 == NWW_ACT_DTYPE_BF16 && dual_h2_on && p.h->f16));
+                    if (dual_h2 || (will_chain && !act_f16)) {
                         dps[i].pw_ws = f16_wscale(f16_fetch(p.h, wpw, (size_t)co * ci)); dps[i].sc_ws = f16_wscale(f16_fetch(p.h, wsc, (size_t)co * ci));
                         if (!(dps[i].pw_ws > 0.f && dps[i].sc_ws > 0.f)) return fail(h, NWW_ERR_INVALID, "block %d: non-finite weights", i);
                         dps[i].pw_un = 1.0f / dps[i].pw_ws; dps[i].sc_un = 1.0f / dps[i].sc_ws;
                     }
-                    const int terms = act_f16 || dual_h2 ? 2 : 3;
+                    const int terms = act_f16 || dual_h2 || will_chain ? 2 : 3;
                     if (dual_x3 && p.h->conv_products == 6 && dual_x3_supported(ci, co) &&
                         hipMalloc(&packed, dual_x3_packed_bytes(ci, co, terms)) == hipSuccess) {
                         if (launch_dual_x3_pack(wpw, wsc, a1, b1, as, bs, packed, ci, co, p.h->own_stream, terms, dps[i]) == hipSuccess) {
@@ -997,7 +1000,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                             // blocks 1 and 2 chained with the next block's depthwise (bc_chain.hip): the block's output stays in LDS, the
                             // next block finds its d / xs rows in the other buffer pair
                             const char* suffix = act_f16 ? " (f16 activations)" : act_bf16 ? " (bf16 activations)" : dual_h2 ? " [f16x3]" : "";
-                            if (chain_on && i < 3 && have_dx && terms == 2 && bc_chain_supported(ci, ho, wo)) {
+                            if (will_chain) {
                                 const std::string qn = "model.block" + std::to_string(i + 1);
                                 const float* dwn = p.W(qn + ".depthwise.weight_t");
                                 const int sh2 = st[i][0], sw2 = st[i][1], ho2 = (ho - 1) / sh2 + 1, wo2 = (wo - 1) / sw2 + 1;
@@ -1008,7 +1011,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                                 p.add("bc_chain:" + q + ".pointwise+bn+act + shortcut+bn -> " + qn + ".depthwise" + suffix, [=](Run& r) {
                                     ChainArgs a{r.buf[idb], r.buf[ixb], r.buf[odb], r.buf[oxb], static_cast<const unsigned char*>(packed), dwn,
                                                 r.B, ho, wo, sh2, sw2, ho2, wo2};
-                                    a.act16 = act_f16 ? 2 : 0; a.d_mul = d_mul; a.xs_mul = xs_mul;
+                                    a.act16 = act16; a.d_mul = d_mul; a.xs_mul = xs_mul;
                                     return launch_bc_chain(a, ci, act, max_grid, r.stream);
                                 });
                                 hh = ho; ww = wo; dwb = odb; xsb = oxb; have_dx = true;

@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* wl = lds;                                   // [NB][BLK] packed weights + folded BN
     float* dww = reinterpret_cast<float*>(lds + NB * BLK);     // [9][N]
-    float* plane = dww + 9 * N;                                // [P][PITCH]
+    float* zpix = dww + 9 * N;                                 // one all-zero pixel: where the out-of-plane taps read
+    float* plane = zpix + PITCH;                               // [P][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int P = a.H * a.W, Po = a.Ho * a.Wo;
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
 
     for (int i = tid; i < NB * BLK / 16; i += CH_THREADS) reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(a.packed)[i];
     for (int i = tid; i < 9 * N / 4; i += CH_THREADS) reinterpret_cast<float4*>(dww)[i] = reinterpret_cast<const float4*>(a.dw_wt)[i];
+    if (tid < PITCH) zpix[tid] = 0.0f;
 
     // ---- register stage: the raw half rows (features 16 kb + 8 h + e of d and xs) of the wave's items of ONE clip
     typedef typename std::conditional<AT == 3, float4, uint2>::type raw_t;       // 4 features
@@ -230,8 +232,8 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
         }
         __syncthreads();
         // ---- the next block's depthwise 3x3 and strided centres out of the plane: four outputs along x per thread, the 3 x ((4 - 1) SW + 3)
-        // input columns read once, row by row (dwconv3x3_nhwc_x4_kernel's organisation, tap order and fmaf chain); out-of-plane taps are
-        // read at a clamped address and selected to zero (no divergent branches)
+        // input columns read once, row by row (dwconv3x3_nhwc_x4_kernel's organisation, tap order and fmaf chain); out-of-plane taps
+        // read the zero pixel (one select on the address, no divergent branches)
         {
             constexpr int NX = 4, COLS = (NX - 1) * SW + 3;
             const int Wg = (a.Wo + NX - 1) / NX, nwork = Q * Wg * a.Ho;
@@ -249,14 +251,13 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
                 for (int dy = 0; dy < 3; ++dy) {
                     const int yy = oy * a.sh - 1 + dy;
                     const bool oky = yy >= 0 && yy < a.H;
-                    const float* prow = plane + (size_t)min(max(yy, 0), a.H - 1) * a.W * PITCH + 4 * q;
+                    const float* prow = plane + yy * a.W * PITCH + 4 * q;
                     float4 v[COLS];
 #pragma unroll
                     for (int cx = 0; cx < COLS; ++cx) {
                         const int xx = x_first + cx;
-                        const float4 ld = *reinterpret_cast<const float4*>(prow + (size_t)min(max(xx, 0), a.W - 1) * PITCH);
                         const bool ok = oky && xx >= 0 && xx < a.W;
-                        v[cx] = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f);
+                        v[cx] = *reinterpret_cast<const float4*>(ok ? prow + xx * PITCH : zpix + 4 * q);
                     }
                     if (dy == 1) {
 #pragma unroll
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(CH_THREADS) bc_chain_kernel(ChainArgs a) {
 
 size_t chain_lds_bytes(int K, int H, int W) {
     const int N = 2 * K;
-    return (size_t)(N / 32) * chain_blk_bytes(K / 16) + (size_t)9 * N * 4 + (size_t)H * W * (N + 4) * 4;
+    return (size_t)(N / 32) * chain_blk_bytes(K / 16) + (size_t)9 * N * 4 + (size_t)(H * W + 1) * (N + 4) * 4;
 }
 int chain_items(int K, int H, int W) { return ((H * W + 31) / 32) * (K == 64 ? 2 : 1); }
 

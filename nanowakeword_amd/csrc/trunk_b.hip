@@ -794,7 +794,7 @@ __host__ __device__ inline BfGeom bf_geom(int W, int sh, int rows_dw) {
 // of the kernel's LDS cycles were conflict cycles (profiles/r03_pmc_all_configs.csv), on an LDS pipe that is busy 63 % of the time.
 __device__ __forceinline__ int bf_pslot(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
 __device__ __forceinline__ int bf_pswz(int x) { return (x & 1) | (((x >> 2) & 1) << 1); }
-constexpr int BF_HEAD = 1536;                 // depthwise weights [9][32] + bias / alpha / beta [3][32], floats
+constexpr int BF_HEAD = 1552;                 // bytes: depthwise weights [9][32] + bias / alpha / beta [3][32] floats + 16 zero bytes
 constexpr int BF_W1F = 12 * 1024;             // conv weight fragments [set][dy][term][64 lanes] x 16 bytes
 
 __global__ void __launch_bounds__(64) bc_front_pack_kernel(const float* __restrict__ w1, unsigned char* __restrict__ out) {
@@ -851,6 +851,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     const int Wp0 = gg.Wp0, pitch0 = gg.pitch0, plane_b = gg.plane_b;
     float* const Wd = reinterpret_cast<float*>(lds_raw);
     float* const BNp = Wd + 288;
+    float* const Zp = BNp + 96;                               // four zeros: where the depthwise's out-of-plane taps read
     unsigned char* const In3 = lds_raw + BF_HEAD;
     float* const P = reinterpret_cast<float*>(In3 + NT * plane_b);
     const int W1p = (W1 + 3) & ~3;                            // pixel slots per P row
@@ -860,6 +861,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
 
     for (int k = tid; k < NT * plane_b / 4; k += NTHR) reinterpret_cast<uint32_t*>(In3)[k] = 0u;      // halo columns stay zero
     for (int k = tid; k < 288; k += NTHR) Wd[k] = a.dw_wt[k];
+    if (tid < 4) Zp[tid] = 0.0f;
     if (tid < 32) {
         BNp[tid] = a.bias ? a.bias[tid] * (F16 ? 1.0f / a.f16_unscale : 1.0f) : 0.0f;
         BNp[32 + tid] = (BN && a.alpha) ? a.alpha[tid] * (F16 ? a.f16_unscale : 1.0f) : 1.0f;
@@ -959,6 +961,20 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         }
     };
     const int cq = tid & 7, dslot = tid >> 3;                  // depthwise: four channels 4 cq .., NTHR / 8 output slots
+    // depthwise, stride 2 along x (the BcResNet geometry): a thread owns TWO outputs along x of one row for the whole launch - its five
+    // input columns' offsets in P (slot, swizzle) are computed once here, out-of-plane columns marked -1
+    const int Wg2 = (Wo + 1) >> 1, dw_rpp = (NTHR >> 3) / max(Wg2, 1);
+    const bool dw_fast = F16 && sw == 2 && dw_rpp >= 1;      // (the three-term instances have no registers to spare for it)
+    const int dw_xg = dslot % max(Wg2, 1), dw_ry = dslot / max(Wg2, 1);
+    int dxoff[5];
+    auto calc_dxoff = [&]() {
+#pragma unroll
+        for (int cx = 0; cx < 5; ++cx) {
+            const int xx = 4 * dw_xg - 1 + cx;
+            dxoff[cx] = (xx >= 0 && xx < W1) ? bf_pslot(xx) * 32 + 4 * (cq ^ bf_pswz(xx)) : -1;
+        }
+    };
+    if constexpr (F16) calc_dxoff();
 
     int b = blockIdx.x, sidx = 0;
     if (b < a.B) {
@@ -1022,6 +1038,52 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             else stage_sync(nb, ns);
         }
         // ---- depthwise 3x3 of the strip's rows out of P (taps in dwconv3x3_nhwc_kernel's order and fmaf chain)
+        if (F16 && dw_fast) {
+            if (dw_ry < dw_rpp) {
+                for (int oyl = dw_ry; oyl < oy1 - oy0; oyl += dw_rpp) {
+                    const int oy = oy0 + oyl;
+                    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, centre[2] = {acc[0], acc[0]};
+#pragma unroll 1
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int yy = oy * sh - 1 + dy;
+                        const bool oky = yy >= 0 && yy < H1;
+                        const float* prow = P + (yy - r_lo) * W1p * 32;
+                        float4 v[5];
+#pragma unroll
+                        for (int cx = 0; cx < 5; ++cx)
+                            v[cx] = *reinterpret_cast<const float4*>((oky && dxoff[cx] >= 0) ? prow + dxoff[cx] : Zp);
+                        if (dy == 1) { centre[0] = v[1]; centre[1] = v[3]; }
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cq);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float4 pv = v[2 * j + dx];
+                                acc[j].x = fmaf(pv.x, w.x, acc[j].x); acc[j].y = fmaf(pv.y, w.y, acc[j].y);
+                                acc[j].z = fmaf(pv.z, w.z, acc[j].z); acc[j].w = fmaf(pv.w, w.w, acc[j].w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ox = 2 * dw_xg + j;
+                        if (ox < Wo) {
+                            const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cq;
+                            if (a.bf16_out) {                     // wave-uniform: 16-bit activations (split_h2.h)
+                                const int k16 = a.bf16_out;
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_out) + oi) =
+                                    make_uint2(nww_pk_act16(k16, acc[j].x, acc[j].y, a.d_scale), nww_pk_act16(k16, acc[j].z, acc[j].w, a.d_scale));
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.xs_out) + oi) =
+                                    make_uint2(nww_pk_act16(k16, centre[j].x, centre[j].y, a.xs_scale), nww_pk_act16(k16, centre[j].z, centre[j].w, a.xs_scale));
+                            } else {
+                                *reinterpret_cast<float4*>(a.d_out + oi) = acc[j];
+                                *reinterpret_cast<float4*>(a.xs_out + oi) = centre[j];
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         for (int o = dslot; o < (oy1 - oy0) * Wo; o += NTHR / 8) {
             const int oyl = o / Wo, ox = o - oyl * Wo, oy = oy0 + oyl;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), centre = acc;

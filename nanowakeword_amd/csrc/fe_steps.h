@@ -45,7 +45,7 @@ NWW_HD nww_c32 c_scale(nww_c32 a, float s) { return c_make(a.x * s, a.y * s); }
 
 // Tables, built on the host in double precision (fe_tables.cpp), resident in LDS in the kernel.
 struct FeTables {
-    nww_c32 win2[FE_M];          // (w[2m], w[2m+1]) / 32768  (int16 -> unit scale folded in; exact, power of 2)
+    nww_c32 win2[FE_M];          // (w[2m], w[2m+1]) / 65536  (int16 -> unit scale and fe_s3_core's 1/2 folded in; exact, powers of 2)
     nww_c32 tw200[8 * 25];       // [k1][n2] = exp(-2 pi i n2 k1 / 200)  (lane index n2 contiguous: no bank conflicts)
     nww_c32 tw400[101];          // exp(-2 pi i k / 400), k = 0..100
     int32_t mel_lo[FE_MAX_MELS];   // first FFT bin of filter j
@@ -166,10 +166,10 @@ NWW_HD void fe_s2(int f, int k1, nww_c32* yz) {
 }
 
 // S3 arithmetic: Z[k] = A, Z[200-k] = B of the 200-point complex FFT -> power of bins k and 200-k of the 400-point
-// real FFT (tw = exp(-2 pi i k / 400)).
+// real FFT (tw = exp(-2 pi i k / 400)).  A and B arrive times 1/2 (FeTables::win2), which is the split's own factor.
 NWW_HD void fe_s3_core(nww_c32 A, nww_c32 B, nww_c32 tw, float* pa, float* pb) {
-    const nww_c32 E = c_make(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-    const nww_c32 O = c_make(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
+    const nww_c32 E = c_make(A.x + B.x, A.y - B.y);
+    const nww_c32 O = c_make(A.y + B.y, B.x - A.x);
     const nww_c32 wO = c_mul(tw, O);
     const nww_c32 Xa = c_add(E, wO), Xb = c_sub(E, wO);
     *pa = Xa.x * Xa.x + Xa.y * Xa.y;

@@ -39,13 +39,15 @@ std::string fe_build_tables(const FeParams& p, const float* window, const float*
     if (p.n_mels <= 0 || p.n_mels > FE_MAX_MELS) return "n_mels must be in 1..128";
     if (p.hop <= 0 || (p.hop & 1)) return "hop_length must be positive and even";
     std::memset(t, 0, sizeof(*t));
-    // centre-padded window (onnx.py:51-53), int16 normalisation 1/32768 folded in (exact scaling)
+    // centre-padded window (onnx.py:51-53), int16 normalisation 1/32768 folded in (exact scaling) - and the 1/2 of the real-FFT split
+    // (fe_s3_core: E = (A + conj B) / 2, O = (A - conj B) / 2i): the whole transform carries half the value, a power of two, so every
+    // rounding is the one the unscaled arithmetic makes and the powers come out bit for bit the same with two multiplies less per bin pair
     std::vector<float> wp(p.n_fft, 0.f);
     const int pad_left = (p.n_fft - p.win_length) / 2;
     for (int i = 0; i < p.win_length; ++i) wp[pad_left + i] = window[i];
     for (int m = 0; m < FE_M; ++m) {
-        t->win2[m].x = wp[2 * m] * (1.0f / 32768.0f);
-        t->win2[m].y = wp[2 * m + 1] * (1.0f / 32768.0f);
+        t->win2[m].x = wp[2 * m] * (1.0f / 65536.0f);
+        t->win2[m].y = wp[2 * m + 1] * (1.0f / 65536.0f);
     }
     for (int n2 = 0; n2 < 25; ++n2)
         for (int k1 = 0; k1 < 8; ++k1) {

@@ -213,9 +213,13 @@ __device__ __forceinline__ void fe2_wave_body(FE2_PARAMS) {
         if (!(dbg & 4)) {
             const nww_c32* z0 = reinterpret_cast<const nww_c32*>(slab);
             nww_c32 a1 = z0[k3a], b1 = z0[ia2], a2 = z0[has_b ? k3b : 0], b2 = z0[has_b ? FE_M - k3b : 0];
-            for (int f = 0; f < nf; ++f) {
+            // unrolled over the group's frames; the next frame's bins are read unconditionally (behind the group's last frame the region
+            // holds stale data that is never used), so the four operands rotate by renaming instead of through register copies
+#pragma unroll
+            for (int f = 0; f < FE2_G; ++f) {
+                if (f >= nf) break;                              // wave-uniform
                 nww_c32 na1 = a1, nb1 = b1, na2 = a2, nb2 = b2;
-                if (f + 1 < nf) {
+                if (f + 1 < FE2_G) {
                     const nww_c32* zn = reinterpret_cast<const nww_c32*>(slab + (f + 1) * FE2_FRAME_DW);
                     na1 = zn[k3a]; nb1 = zn[ia2]; na2 = zn[has_b ? k3b : 0]; nb2 = zn[has_b ? FE_M - k3b : 0];
                 }

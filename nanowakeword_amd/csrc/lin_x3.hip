@@ -17,9 +17,11 @@
 #include <type_traits>
 #include "layers.h"
 #include "lin_x3.h"
+#include "split_h2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -54,12 +56,20 @@ __device__ __forceinline__ void mfma6l(const bf16x8 (&w)[3], const bf16x8 (&x)[3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
 }
 
+// three products of two-term operands (binary16), small terms first: lo*hi, hi*lo, hi*hi
+__device__ __forceinline__ void mfma3hl(const bf16x8 (&w)[3], const bf16x8* x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
+}
+
 // ---- plan-time packing: one thread per (output block, fragment, lane).  Block = [part (1 | 2: GLU a, b)][kb][term][lane] 16-byte
 // fragments, then 32 biases per part, padded to whole 4 KB copy steps.  Part p of block blk is W rows p * gate_off + 32 blk + i.
 __global__ void __launch_bounds__(256) lin_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
-                                                       unsigned char* __restrict__ out, int K, int n_out, int parts, int gate_off) {
+                                                       unsigned char* __restrict__ out, int K, int n_out, int parts, int gate_off,
+                                                       int terms, float ws) {
     const int K16 = K / 16, nblk = (n_out + 31) / 32;
-    const size_t blk_bytes = lin_x3_block_bytes(K, parts);
+    const size_t blk_bytes = lin_x3_block_bytes(K, parts, terms);
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)nblk * parts * K16 * 64) return;
     const int lane = (int)(idx & 63);
@@ -72,23 +82,32 @@ __global__ void __launch_bounds__(256) lin_pack_kernel(const float* __restrict__
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = col < n_out ? W[(size_t)(part * gate_off + col) * K + 16 * kb + 8 * h + e] : 0.0f;
-    uint32_t hh[8], mm[8], ll[8];
+    unsigned char* dst = base + ((size_t)((part * K16 + kb) * terms) * 64 + lane) * 16;
+    if (terms == 2) {                                          // two binary16 terms of weight x scale (split_h2.h)
+        uint32_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3l(v[e], hh[e], mm[e], ll[e]);
-    unsigned char* dst = base + ((size_t)((part * K16 + kb) * 3) * 64 + lane) * 16;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack16l(hh[0], hh[1]), pack16l(hh[2], hh[3]), pack16l(hh[4], hh[5]), pack16l(hh[6], hh[7]));
-    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16l(mm[0], mm[1]), pack16l(mm[2], mm[3]), pack16l(mm[4], mm[5]), pack16l(mm[6], mm[7]));
-    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16l(ll[0], ll[1]), pack16l(ll[2], ll[3]), pack16l(ll[4], ll[5]), pack16l(ll[6], ll[7]));
+        for (int e = 0; e < 4; ++e) nww_split2h(v[2 * e] * ws, v[2 * e + 1] * ws, hi[e], lo[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    } else {
+        uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3l(v[e], hh[e], mm[e], ll[e]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack16l(hh[0], hh[1]), pack16l(hh[2], hh[3]), pack16l(hh[4], hh[5]), pack16l(hh[6], hh[7]));
+        *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(pack16l(mm[0], mm[1]), pack16l(mm[2], mm[3]), pack16l(mm[4], mm[5]), pack16l(mm[6], mm[7]));
+        *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(pack16l(ll[0], ll[1]), pack16l(ll[2], ll[3]), pack16l(ll[4], ll[5]), pack16l(ll[6], ll[7]));
+    }
     if (kb == 0 && lane < 32)
-        reinterpret_cast<float*>(base + (size_t)parts * K16 * 3072)[part * 32 + lane] = (bias && col < n_out) ? bias[part * gate_off + col] : 0.0f;
+        reinterpret_cast<float*>(base + (size_t)parts * K16 * terms * 1024)[part * 32 + lane] = (bias && col < n_out) ? bias[part * gate_off + col] : 0.0f;
 }
 
 // EPI: 0 = out = y + bias;  1 = out = res + rscale * (y + bias);  2 = GLU, out = (ya + bias_a) * sigmoid(yb + bias_b)
 // NWV waves per workgroup (32 rows each) share every weight block streamed through LDS
-template <int K16, int EPI, bool LN, int NWV>
+// H2: two binary16 terms per operand with a per-row scale (LinArgs::h2); fragments are carried as 128-bit bags typed bf16x8 either way
+template <int K16, int EPI, bool LN, int NWV, bool H2 = false>
 __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
-    constexpr int K = 16 * K16, PARTS = EPI == 2 ? 2 : 1;
-    constexpr int FRAG_BYTES = PARTS * K16 * 3072, BLK = (FRAG_BYTES + PARTS * 128 + 4095) & ~4095;
+    constexpr int K = 16 * K16, PARTS = EPI == 2 ? 2 : 1, NTM = H2 ? 2 : 3;
+    constexpr int FRAG_BYTES = PARTS * K16 * NTM * 1024, BLK = (FRAG_BYTES + PARTS * 128 + 4095) & ~4095;
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
     __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
@@ -111,7 +130,8 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
     fetch(0, wb0);
 
     // ---- the lane's half row (features 16kb + 8h + e), LayerNorm-ed if asked -> X fragments
-    bf16x8 xf[K16][3];
+    bf16x8 xf[K16][NTM];
+    float pin = 1.0f;                                          // H2: 1 / (the row's scale x the weight scale)
     {
         float v[K16][8];
         float s = 0.0f;
@@ -147,7 +167,27 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[kb][e] = (v[kb][e] - mu) * rstd * w[e] + c[e];
             }
-            split_frag_l(v[kb], xf[kb][0], xf[kb][1], xf[kb][2]);
+            if constexpr (!H2) split_frag_l(v[kb], xf[kb][0], xf[kb][1], xf[kb][2]);
+        }
+        if constexpr (H2) {
+            // the row's largest magnitude (both half rows) -> its power-of-two scale: max * s in [2^14, 2^15)
+            float m = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[kb][e]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const uint32_t eb = min(max(__float_as_uint(m) >> 23, 16u), 254u);
+            const float sc = __uint_as_float((268u - eb) << 23);
+            pin = __uint_as_float((eb - 14u) << 23) * a.w_un;
+#pragma unroll
+            for (int kb = 0; kb < K16; ++kb) {
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nww_split2h(v[kb][2 * e] * sc, v[kb][2 * e + 1] * sc, hi[e], lo[e]);
+                xf[kb][0] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+                xf[kb][1] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+            }
         }
     }
 
@@ -189,29 +229,38 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
 #pragma unroll
         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * 3 + t) * 1024);
+            for (int t = 0; t < NTM; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16) * NTM + t) * 1024);
 #pragma unroll
         for (int kb = 0; kb < K16; ++kb) {
             bf16x8 cw[PARTS][3];
 #pragma unroll
             for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) cw[p][t] = nw[p][t];
+                for (int t = 0; t < NTM; ++t) cw[p][t] = nw[p][t];
             if (kb + 1 < K16) {
 #pragma unroll
                 for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * 3 + t) * 1024);
+                    for (int t = 0; t < NTM; ++t) nw[p][t] = *reinterpret_cast<const bf16x8*>(wp + ((p * K16 + kb + 1) * NTM + t) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p) mfma6l(cw[p], xf[kb], acc[p]);
+            for (int p = 0; p < PARTS; ++p) {
+                if constexpr (H2) mfma3hl(cw[p], xf[kb], acc[p]);
+                else mfma6l(cw[p], reinterpret_cast<const bf16x8(&)[3]>(xf[kb]), acc[p]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // The next weight block's LDS-DMA (issued before this block's products) and the residual loads must have landed before
         // the barrier behind this block - waited for HERE, before the stores: vmcnt counts stores too, and waiting for it after
         // them made every block sit out the write latency of its own outputs (out_proj 0.117 -> see DESIGN 7)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (H2) {
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] *= pin;
+        }
         // lane (row n, half h), register 4g + q = output feature 32 blk + 8g + 4h + q
         if (!row_ok) return;
         const float* bp = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
@@ -256,12 +305,14 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
 
 bool lin_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 96 || K == 128 || K == 144) && N % 4 == 0 && N >= 4; }
 
-size_t lin_x3_packed_bytes(int K, int n_out, int parts) { return (size_t)((n_out + 31) / 32) * lin_x3_block_bytes(K, parts); }
+size_t lin_x3_packed_bytes(int K, int n_out, int parts, int terms) { return (size_t)((n_out + 31) / 32) * lin_x3_block_bytes(K, parts, terms); }
 
-hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int K, int n_out, int parts, int gate_off, hipStream_t s) {
+hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int K, int n_out, int parts, int gate_off, hipStream_t s,
+                              int terms, float ws) {
+    if (terms != 2 && terms != 3) return hipErrorInvalidValue;
     const size_t total = (size_t)((n_out + 31) / 32) * parts * (K / 16) * 64;
     hipLaunchKernelGGL(lin_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, bias,
-                       reinterpret_cast<unsigned char*>(out), K, n_out, parts, gate_off);
+                       reinterpret_cast<unsigned char*>(out), K, n_out, parts, gate_off, terms, ws);
     return hipGetLastError();
 }
 
@@ -280,10 +331,12 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     // workgroup per CU, "final occupancy 1"); the row arithmetic is the same in both shapes, so results do not depend on the choice.
     const bool w8 = epi == 2 && (K >= 128 || a.M >= 256 * 256);
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
+#define LIN_GO2(K16V, EPIV, LNV, H2V)                                                                              \
+    if constexpr (EPIV == 2 && K16V >= 8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8, H2V>), grid, dim3(512), 0, s, a); \
+    else if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4), H2V>), grid, dim3(512), 0, s, a); \
+    else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4, H2V>), grid, dim3(256), 0, s, a);
 #define LIN_GO(K16V, EPIV, LNV)                                                                                    \
-    if constexpr (EPIV == 2 && K16V >= 8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8>), grid, dim3(512), 0, s, a); \
-    else if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4)>), grid, dim3(512), 0, s, a); \
-    else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4>), grid, dim3(256), 0, s, a);
+    if (a.h2) { LIN_GO2(K16V, EPIV, LNV, true) } else { LIN_GO2(K16V, EPIV, LNV, false) }
 #define LIN_EPI(K16V)                                                                                              \
     if (epi == 0) { LIN_GO(K16V, 0, false) } else if (epi == 1) { LIN_GO(K16V, 1, false) } else if (ln) { LIN_GO(K16V, 2, true) } else { LIN_GO(K16V, 2, false) }
     switch (K) {
@@ -296,5 +349,6 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     }
 #undef LIN_EPI
 #undef LIN_GO
+#undef LIN_GO2
     return hipGetLastError();
 }

@@ -299,17 +299,26 @@ bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int 
     static const int enabled = [] { const char* e = getenv("NWW_LIN_X3"); return e ? atoi(e) : 1; }();
     if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N)) return false;
     const int parts = epi == 2 ? 2 : 1;
+    // under NWW_ARITH_F16X3: two binary16 terms per operand, the input rows scaled per row in the kernel (LinArgs::h2: no bound on the
+    // tensor needed); NWW_LIN_H2 = 0 keeps the three-term bf16 form
+    static const int h2_on = [] { const char* e = getenv("NWW_LIN_H2"); return e ? atoi(e) : 1; }();
+    float ws = 0.0f;
+    if (h2_on && p.h->f16) ws = f16_wscale(f16_fetch(p.h, W, (size_t)parts * N * K));
+    const bool h2 = ws > 0.0f;
+    const int terms = h2 ? 2 : 3;
     void* packed = nullptr;
-    if (hipMalloc(&packed, lin_x3_packed_bytes(K, N, parts)) != hipSuccess) return false;
-    if (launch_lin_x3_pack(W, bias, packed, K, N, parts, N, p.h->own_stream) != hipSuccess) { (void)hipFree(packed); return false; }
+    if (hipMalloc(&packed, lin_x3_packed_bytes(K, N, parts, terms)) != hipSuccess) return false;
+    if (launch_lin_x3_pack(W, bias, packed, K, N, parts, N, p.h->own_stream, terms, h2 ? ws : 1.0f) != hipSuccess) { (void)hipFree(packed); return false; }
     p.h->packed_weights.push_back(packed);
     p.need(out_id, (size_t)rows_per_clip * N);
-    p.add("lin_x3:" + name, [=](Run& r) {
+    const float w_un = h2 ? 1.0f / ws : 1.0f;
+    p.add("lin_x3:" + name + (h2 ? " [f16x3]" : ""), [=](Run& r) {
         LinArgs a;
         a.x = src(r, in_id); a.ldx = K; a.out = dst(r, out_id); a.ldc = N;
         a.res = res_id == 99 ? nullptr : src(r, res_id); a.ldres = N; a.rscale = rscale;
         a.ln_w = ln_w; a.ln_b = ln_b; a.packed = static_cast<const unsigned char*>(packed);
         a.M = r.B * rows_per_clip; a.N = N; a.qkv_T = qkv_T; a.qkv_dh = qkv_dh;
+        a.h2 = h2 ? 1 : 0; a.w_un = w_un;
         return launch_lin_x3(a, K, epi, ln_w != nullptr, r.stream);
     });
     return true;

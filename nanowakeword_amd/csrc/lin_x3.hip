@@ -329,12 +329,12 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     // workgroups per CU (LayerNorm + conv1 + GLU of the Conformer 0.155 -> 0.138 ms); the other epilogues measured slower with
     // eight (in_proj 0.170 -> 0.199, out_proj / conv2 0.117 -> 0.125-0.129).  K >= 128 has no four-wave GLU instance at all (one
     // workgroup per CU, "final occupancy 1"); the row arithmetic is the same in both shapes, so results do not depend on the choice.
-    static const int w8_mask = [] { const char* e = getenv("NWW_LIN_W8"); return e ? atoi(e) : 0; }();      // A/B: bit epi = eight waves for that epilogue
-    const bool w8 = (epi == 2 && (K >= 128 || a.M >= 256 * 256)) || (a.h2 && a.M >= 256 * 256 && ((w8_mask >> epi) & 1));
+    // (two-term instances, 138 - 148 registers at K = 144: eight waves measured again - in_proj 0.148 -> 0.161, out_proj unchanged)
+    const bool w8 = epi == 2 && (K >= 128 || a.M >= 256 * 256);
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define LIN_GO2(K16V, EPIV, LNV, H2V)                                                                              \
     if constexpr (EPIV == 2 && K16V >= 8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8, H2V>), grid, dim3(512), 0, s, a); \
-    else if ((EPIV == 2 || H2V) && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, ((EPIV == 2 || H2V) ? 8 : 4), H2V>), grid, dim3(512), 0, s, a); \
+    else if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4), H2V>), grid, dim3(512), 0, s, a); \
     else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4, H2V>), grid, dim3(256), 0, s, a);
 #define LIN_GO(K16V, EPIV, LNV)                                                                                    \
     if (a.h2) { LIN_GO2(K16V, EPIV, LNV, true) } else { LIN_GO2(K16V, EPIV, LNV, false) }

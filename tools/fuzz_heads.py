@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random head shapes against the oracle (features in, logits out): a wider net than the parametrised GPU tests for the
 shape-dependent kernel choices (lin_x3 / ffn_x3 / mha_mfma widths and tails, conv3_x3 fits, BcResNet strips, trunk strips).
-usage: python tools/fuzz_heads.py [n_cases] [seed]   (needs an MI355X)"""
+usage: python tools/fuzz_heads.py [n_cases] [seed] [kinds, comma-separated] [act_dtype]   (needs an MI355X)
+With act_dtype = f16 / bf16 (BcResNet only) the pass mark is 3e-2 / 2e-1 instead of 1e-4: on random features and planes of a few pixels
+the 16-bit modes are noisier than on log-mel clips (round 4: worst of 80 / 60 cases 1.7e-2 / 9.5e-2; float32 storage 3.6e-5 of 250)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,12 +13,12 @@ from nanowakeword_amd.session import HipModel
 from nanowakeword_amd.synth import synth_features, synth_state_dict
 
 
-def run(n_cases=40, seed=0, log=print):
+def run(n_cases=40, seed=0, log=print, kinds=("conformer", "crnn", "bcresnet", "cnn", "e2e_dnn", "dnn", "gru"), act_dtype=None, tol=1e-4):
     """-> (worst |dlogit|, cases that ran)"""
     rng = np.random.default_rng(seed)
     worst, ran = 0.0, 0
     for case in range(n_cases):
-        kind = rng.choice(["conformer", "crnn", "bcresnet", "cnn", "e2e_dnn", "dnn", "gru"])
+        kind = rng.choice(list(kinds))
         act = str(rng.choice(["relu", "gelu", "silu"]))
         if kind == "conformer":
             d, nh = [(32, 2), (32, 8), (64, 4), (96, 4), (96, 2), (128, 4), (144, 4), (144, 8), (80, 4)][rng.integers(0, 9)]
@@ -40,7 +42,8 @@ def run(n_cases=40, seed=0, log=print):
         B = int(rng.choice([1, 2, 5, 17, 33, 130]))
         try:
             sd = synth_state_dict(cfg)
-            m = HipModel(cfg, FrontendConfig(n_mels=min(cfg.input_shape[1], 128) if kind != "e2e_dnn" else cfg.input_shape[0]), state_dict=sd)
+            m = HipModel(cfg, FrontendConfig(n_mels=min(cfg.input_shape[1], 128) if kind != "e2e_dnn" else cfg.input_shape[0]), state_dict=sd,
+                         act_dtype=act_dtype if kind == "bcresnet" else None)
         except (NotImplementedError, ValueError) as e:
             log(f"case {case}: {kind} {cfg.input_shape} refused at create: {str(e)[:80]}")
             continue
@@ -49,13 +52,16 @@ def run(n_cases=40, seed=0, log=print):
         ref = oracle.model_forward(x, sd, cfg).ravel()
         err = float(np.abs(lg - ref).max())
         worst, ran = max(worst, err), ran + 1
-        flag = "" if err <= 1e-4 else "   <-- FAIL"
+        flag = "" if err <= tol else "   <-- FAIL"
         log(f"case {case}: {kind} {cfg.input_shape} B={B} act={act} max|dlogit| {err:.2e}{flag}")
         m.close()
     return worst, ran
 
 
 if __name__ == "__main__":
-    worst, ran = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    ad = sys.argv[4] if len(sys.argv) > 4 else None
+    tol = {"f16": 3e-2, "bf16": 2e-1}.get(ad, 1e-4)
+    kw = {"kinds": tuple(sys.argv[3].split(","))} if len(sys.argv) > 3 and sys.argv[3] else {}
+    worst, ran = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0, act_dtype=ad, tol=tol, **kw)
     print("WORST", worst, "of", ran, "cases")
-    sys.exit(0 if worst <= 1e-4 else 1)
+    sys.exit(0 if worst <= tol else 1)

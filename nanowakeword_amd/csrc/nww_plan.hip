@@ -929,12 +929,18 @@ extern "C" int nww_finalize(nww_handle* h) {
                     else { (void)hipFree(fpack); fpack = nullptr; }
                 }
                 const float f_un = 1.0f / (fin > 0.0f ? fin * fws : 1.0f);
+                // all folded-BN factors non-negative (the usual case: gamma > 0): max-pool commutes with BN + ReLU through the maximum alone
+                int bn_pos = 0;
+                if (a0) {
+                    bn_pos = 1;
+                    for (float v : f16_fetch(p.h, a0, 32)) if (!(v >= 0.0f)) bn_pos = 0;
+                }
                 p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_f16 ? ", f16 out)" : act_bf16 ? ", bf16 out)" : ")") + (fpack && fprod == 3 ? " [f16x3]" : ""), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
                     a.bf16_out = act16; a.d_scale = s_d[1]; a.xs_scale = s_h[0];
                     if (fpack) {
                         a.wpack = static_cast<const unsigned char*>(fpack);
-                        a.f16_in = fin; a.f16_clamp = NWW_F16_FEATURE_BOUND; a.f16_unscale = f_un;
+                        a.f16_in = fin; a.f16_clamp = NWW_F16_FEATURE_BOUND; a.f16_unscale = f_un; a.bn_pos = bn_pos;
                         return launch_bc_front_b(a, fprod, max_grid, r.stream);
                     }
                     return launch_conv1_pool_dw_nhwc(a, max_grid, r.stream);

@@ -110,6 +110,7 @@ struct Conv1DwArgs {
     // launch_bc_front_b with products = 3 (two binary16 terms; weights from launch_bc_front_b_pack_f16 with scale sw): the input is
     // clamped to +-f16_clamp and multiplied by f16_in; f16_unscale = 1 / (f16_in * sw)
     float f16_in = 0.0f, f16_clamp = 0.0f, f16_unscale = 1.0f;
+    int bn_pos = 0;                  // launch_bc_front_b: every folded-BN factor alpha is >= 0 (the pooling takes the window's maximum only)
 };
 // the same stage with the convolution from split operands on the bf16 matrix cores (trunk_b.hip); products = 6 / 9
 size_t bc_front_b_packed_bytes();

@@ -150,8 +150,10 @@ __device__ __forceinline__ void x3_mfma(const bf16x8* x, const bf16x8* y, f32x16
 //   ReLU without BN: post = s / k                          ((u + bias k) s / k)
 //   ReLU with BN:    al s / k, be s                        (nothing else changes)
 //   other:           al / k (1 / k without BN), be, post = s   (the activation sees the true value)
+// pos (wave-uniform, BN only): every folded-BN factor of the layer is >= 0 (checked at plan time) - the window's maximum alone decides
 template <int ACT, bool BN, bool SC = false>
-__device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be, float post = 1.0f) {
+__device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be, float post = 1.0f,
+                                           bool pos = false) {
     if (ACT == ACT_RELU && !BN) {
         float t, u;
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
@@ -165,6 +167,7 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
         float t, mx, mn;
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(v3));
+        if (pos) return fmaxf((mx + bias) * al + be, 0.0f);
         asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(v3));
         const float e = al < 0.0f ? mn : mx;
@@ -961,6 +964,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         }
     };
     const int cq = tid & 7, dslot = tid >> 3;                  // depthwise: four channels 4 cq .., NTHR / 8 output slots
+    const bool bn_pos = __builtin_amdgcn_readfirstlane(a.bn_pos) != 0;
     // depthwise, stride 2 along x (the BcResNet geometry): a thread owns TWO outputs along x of one row for the whole launch - its five
     // input columns' offsets in P (slot, swizzle) are computed once here, out-of-plane columns marked -1
     const int Wg2 = (Wo + 1) >> 1, dw_rpp = (NTHR >> 3) / max(Wg2, 1);
@@ -1022,7 +1026,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             float m[8];
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc)
-                m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc]);
+                m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc], 1.0f, bn_pos);
             const int x = 32 * gx + i;
             if (x < W1) {
                 float* dst = P + ((size_t)Rl * W1p + bf_pslot(x)) * 32;

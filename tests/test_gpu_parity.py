@@ -378,6 +378,15 @@ def test_bcresnet_shapes_activations_and_storage(hip):
     cfg = HeadConfig("bcresnet", (101, 64))
     base = synth_state_dict(cfg)
     feats = synth_features(6, cfg.input_shape, seed=9)
+    # negative BatchNorm factors in the init conv: the front kernel's pooling then needs the window's minimum too (its plan-time
+    # shortcut for all-non-negative factors must not be taken)
+    sd = {k: v.copy() for k, v in base.items()}
+    sd["model.init_conv.1.weight"][::3] *= np.float32(-1.0)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    lg, _ = m.forward_features(feats)
+    d = float(np.abs(lg - oracle.model_forward(feats, sd, cfg).ravel()).max())
+    assert d <= FEAT_LOGIT_ATOL, d
+    m.close()
     ref = oracle.model_forward(feats, base, cfg).ravel()
     for e0, e1, e2, e3 in ((10, -10, 0, 0), (-10, 0, 10, 0), (0, 10, 0, -10), (4, 4, -4, -4)):
         sd = {k: v.copy() for k, v in base.items()}

@@ -24,6 +24,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -55,13 +56,25 @@ __device__ __forceinline__ float dual_act(float v) {
 }
 
 // six products, small terms first (the order of gemm_x3.hip): w = weight fragments (A operand), x = activation fragments (B)
+// SW (the fused-mean instances): the activation term is the A operand and the weight term the B operand - the accumulator is then
+// [pixels x output channels], a lane holds 16 pixels of ONE channel (same fragments, the other orientation of the same product)
+template <bool SW>
+__device__ __forceinline__ f32x16 mm_bf16(bf16x8 w, bf16x8 x, f32x16 acc) {
+    return SW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+template <bool SW>
+__device__ __forceinline__ f32x16 mm_f16(bf16x8 w, bf16x8 x, f32x16 acc) {
+    return SW ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, w), acc, 0, 0, 0)
+              : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
+template <bool SW = false>
 __device__ __forceinline__ void mfma6d(const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
+    acc = mm_bf16<SW>(w[1], x[1], acc);
+    acc = mm_bf16<SW>(w[2], x[0], acc);
+    acc = mm_bf16<SW>(w[0], x[2], acc);
+    acc = mm_bf16<SW>(w[1], x[0], acc);
+    acc = mm_bf16<SW>(w[0], x[1], acc);
+    acc = mm_bf16<SW>(w[0], x[0], acc);
 }
 
 // plan-time packing: block = [part 0 = Wpw | 1 = Wsc][kb][term][lane] 16-byte fragments, then a1[32], b1[32], as[32], bs[32]
@@ -111,22 +124,25 @@ __global__ void __launch_bounds__(256) dual_pack_kernel(const float* __restrict_
 }
 
 // three products of a float32 weight (three bf16 terms) with a bf16 activation, small terms first
+template <bool SW = false>
 __device__ __forceinline__ void mfma3d(const bf16x8 (&w)[3], const bf16x8& x, f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x, acc, 0, 0, 0);
+    acc = mm_bf16<SW>(w[2], x, acc);
+    acc = mm_bf16<SW>(w[1], x, acc);
+    acc = mm_bf16<SW>(w[0], x, acc);
 }
 // two products of a scaled float32 weight (two binary16 terms) with a binary16 activation, small term first
+template <bool SW = false>
 __device__ __forceinline__ void mfma2h(const bf16x8 (&w)[3], const bf16x8& x, f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+    acc = mm_f16<SW>(w[1], x, acc);
+    acc = mm_f16<SW>(w[0], x, acc);
 }
 
 // three products of two-term operands (binary16), small terms first: lo*hi, hi*lo, hi*hi
+template <bool SW = false>
 __device__ __forceinline__ void mfma3h(const bf16x8 (&w)[3], const bf16x8* x, f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[1]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc, 0, 0, 0);
+    acc = mm_f16<SW>(w[1], x[0], acc);
+    acc = mm_f16<SW>(w[0], x[1], acc);
+    acc = mm_f16<SW>(w[0], x[0], acc);
 }
 
 // AT: 0 float32 activations on three bf16 terms (six products), 1 bf16 in and out, 2 scaled binary16 in and out (DualArgs::act16),
@@ -134,9 +150,12 @@ __device__ __forceinline__ void mfma3h(const bf16x8 (&w)[3], const bf16x8* x, f3
 // 128-bit bags typed bf16x8 either way.  NWV waves per workgroup (32 pixels each) share every weight block: a
 // workgroup streams ALL packed weights (K = 128: 8 x 52 KB) through LDS once per 32 NWV pixels, which at four waves was the
 // kernel's bound for the wide blocks (1.4 GB of L2 -> LDS traffic for block 3 at 8192 clips) - eight waves halve it.
-// MEAN: the global average pool fused behind the last block (DualArgs::mean_out): waves are (clip, 32-pixel group) pairs, the
-// activated outputs of a wave go through a [32 pixels][32 channels] LDS tile (rows 144 bytes apart: conflict-free 16-byte stores) to
-// be summed per channel in pixel order, the groups of a clip are added in group order by the clip's first wave.
+// MEAN: the global average pool fused behind the last block (DualArgs::mean_out): waves are (clip, 32-pixel group) pairs and the
+// products run in the OTHER orientation (activations as the A operand): a lane of the accumulator holds 16 pixels of ONE output
+// channel, so the per-channel pixel sum is 16 register adds and one cross-half exchange - no LDS tile.  Pixels behind a clip's last
+// one carry zero fragments (their constant bs + act(b1) is subtracted); with float32 activations the power-of-two scale is the
+// wave's (32 pixels of ONE clip: still a function of the clip alone), a scalar folded into the block's BN factors.  The groups of a
+// clip are added in group order by the clip's first wave.
 template <int K16, int ACT, int AT, int NWV, bool MEAN = false>
 __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     constexpr int K = 16 * K16;
@@ -147,18 +166,18 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
     // two separate LDS objects: reads of one cannot alias the LDS-DMA writes into the other (no s_waitcnt vmcnt in mid-block)
     __shared__ __attribute__((aligned(16))) unsigned char wb0[BLK];
     __shared__ __attribute__((aligned(16))) unsigned char wb1[BLK];
-    constexpr int MT_LD = 36;                                            // floats per pixel row of the mean tile
-    __shared__ __attribute__((aligned(16))) float mtile[MEAN ? NWV * 32 * MT_LD : 4];
     __shared__ float mpart[MEAN ? 2 * NWV * 32 : 4];                     // per block parity: the waves' channel sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     int row;
     bool row_ok;
     int gpc = 1, clip = 0, grp = 0;                                      // MEAN: groups per clip, this wave's clip and group
+    float n_inv = 0.0f;                                                  // MEAN: the wave's pixels behind its clip's last one
     if constexpr (MEAN) {
         gpc = (a.mean_P + 31) / 32;
         const int wg = (int)blockIdx.x * NWV + wave;
         clip = wg / gpc; grp = wg - clip * gpc;
+        n_inv = (float)(32 - min(max(a.mean_P - 32 * grp, 0), 32));
         const int pix = 32 * grp + n;
         row = clip * a.mean_P + pix;
         row_ok = pix < a.mean_P && row < a.M;
@@ -197,7 +216,11 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
             const __bf16* xrow = p ? (a.x ? reinterpret_cast<const __bf16*>(a.x) + xs_off : reinterpret_cast<const __bf16*>(a.xs) + rr * K)
                                    : reinterpret_cast<const __bf16*>(a.d) + rr * K;
 #pragma unroll
-            for (int kb = 0; kb < K16; ++kb) xf[p][kb][0] = *reinterpret_cast<const bf16x8*>(xrow + 16 * kb + 8 * h);
+            for (int kb = 0; kb < K16; ++kb) {
+                u32x4d q = *reinterpret_cast<const u32x4d*>(xrow + 16 * kb + 8 * h);
+                if (MEAN && !row_ok) q = u32x4d{0u, 0u, 0u, 0u};
+                xf[p][kb][0] = __builtin_bit_cast(bf16x8, q);
+            }
         }
     } else if constexpr (AT == 3) {
 #pragma unroll
@@ -216,8 +239,13 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
             }
             // the row's largest magnitude (both half rows) -> its power-of-two scale: max * s in [2^14, 2^15)
             m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if constexpr (MEAN) {                              // ... of the wave's 32 pixels (one clip's), invalid pixels left out and zeroed
+                if (!row_ok) m = 0.0f;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            }
             const uint32_t eb = min(max(__float_as_uint(m) >> 23, 16u), 254u);
-            const float sc = __uint_as_float((268u - eb) << 23);
+            const float sc = (MEAN && !row_ok) ? 0.0f : __uint_as_float((268u - eb) << 23);
             pin[p] = __uint_as_float((eb - 14u) << 23);
 #pragma unroll
             for (int kb = 0; kb < K16; ++kb) {
@@ -238,7 +266,8 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
             for (int kb = 0; kb < K16; ++kb) {
                 const float4 p0 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h);
                 const float4 p1 = *reinterpret_cast<const float4*>(xrow + 16 * kb + 8 * h + 4);
-                const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                const float z = (MEAN && !row_ok) ? 0.0f : 1.0f;
+                const float v[8] = {p0.x * z, p0.y * z, p0.z * z, p0.w * z, p1.x * z, p1.y * z, p1.z * z, p1.w * z};
                 split_frag_d(v, xf[p][kb][0], xf[p][kb][1], xf[p][kb][2]);
             }
         }
@@ -272,34 +301,49 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (AT == 3) {
-                mfma3h(cw[0], xf[0][kb], acc[0]);
-                mfma3h(cw[1], xf[1][kb], acc[1]);
+                mfma3h<MEAN>(cw[0], xf[0][kb], acc[0]);
+                mfma3h<MEAN>(cw[1], xf[1][kb], acc[1]);
             } else if constexpr (AT == 2) {
-                mfma2h(cw[0], xf[0][kb][0], acc[0]);
-                mfma2h(cw[1], xf[1][kb][0], acc[1]);
+                mfma2h<MEAN>(cw[0], xf[0][kb][0], acc[0]);
+                mfma2h<MEAN>(cw[1], xf[1][kb][0], acc[1]);
             } else if constexpr (AT == 1) {
-                mfma3d(cw[0], xf[0][kb][0], acc[0]);
-                mfma3d(cw[1], xf[1][kb][0], acc[1]);
+                mfma3d<MEAN>(cw[0], xf[0][kb][0], acc[0]);
+                mfma3d<MEAN>(cw[1], xf[1][kb][0], acc[1]);
             } else {
-                mfma6d(cw[0], xf[0][kb], acc[0]);
-                mfma6d(cw[1], xf[1][kb], acc[1]);
+                mfma6d<MEAN>(cw[0], xf[0][kb], acc[0]);
+                mfma6d<MEAN>(cw[1], xf[1][kb], acc[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // the next weight block's LDS-DMA must have landed before the barrier behind this block: waited for here, BEFORE the
         // stores (vmcnt counts them too - waiting after them made every block sit out the write latency of its own outputs)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MEAN) {
+            // lane (channel n, half h), register 4g + q = pixel 8g + 4h + q of the wave's 32: the channel's folded BN factors are four
+            // scalars, the pixel sum 16 adds in register order + the other half - the same order for every clip and slot
+            const float* affn = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + n;
+            float a1c = affn[0], asc = affn[64];
+            const float b1c = affn[32], bsc = affn[96];
+            if constexpr (AT == 3) { a1c *= pin[0]; asc *= pin[1]; }
+            float sum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += (acc[1][r] * asc + bsc) + dual_act<ACT>(acc[0][r] * a1c + b1c);
+            sum += __shfl_xor(sum, 32, 64);
+            sum -= n_inv * (bsc + dual_act<ACT>(b1c));         // the zero-fragment pixels behind the clip's last one
+            if (h == 0) mpart[((blk & 1) * NWV + wave) * 32 + n] = sum;
+            return;
+        }
         if constexpr (AT == 3) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] *= pin[0]; acc[1][r] *= pin[1]; }
         }
         // lane (pixel n, half h), register 4g + q = output channel 32 blk + 8g + 4h + q
-        if (!MEAN && !row_ok) return;
+        if (!row_ok) return;
         const float* aff = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = 32 * blk + 8 * g + 4 * h;
-            if (MEAN || col < a.N) {                           // N % 4 == 0: the four channels are in or out together
+            if (col < a.N) {                                   // N % 4 == 0: the four channels are in or out together
                 const float4 a1 = *reinterpret_cast<const float4*>(aff + 8 * g), b1 = *reinterpret_cast<const float4*>(aff + 32 + 8 * g);
                 const float4 as = *reinterpret_cast<const float4*>(aff + 64 + 8 * g), bs = *reinterpret_cast<const float4*>(aff + 96 + 8 * g);
                 float4 o;
@@ -307,26 +351,10 @@ __global__ void __launch_bounds__(64 * NWV) dual_x3_kernel(DualArgs a) {
                 o.y = (acc[1][4 * g + 1] * as.y + bs.y) + dual_act<ACT>(acc[0][4 * g + 1] * a1.y + b1.y);
                 o.z = (acc[1][4 * g + 2] * as.z + bs.z) + dual_act<ACT>(acc[0][4 * g + 2] * a1.z + b1.z);
                 o.w = (acc[1][4 * g + 3] * as.w + bs.w) + dual_act<ACT>(acc[0][4 * g + 3] * a1.w + b1.w);
-                if constexpr (MEAN) {
-                    if (!row_ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(mtile + (wave * 32 + n) * MT_LD + 8 * g + 4 * h) = o;
-                } else if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) =
+                if (BF) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + rr * a.N + col) =
                         make_uint2(nww_pk_act16(AT, o.x, o.y, a.out_mul), nww_pk_act16(AT, o.z, o.w, a.out_mul));
                 else *reinterpret_cast<float4*>(orow + col) = o;
             }
-        }
-        if constexpr (MEAN) {
-            // the wave's own tile (LDS operations of a wave execute in order): lane (channel n, half h) adds pixels 16 h .. 16 h + 15
-            // in pixel order, then the two halves - the same order for every clip and slot
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float* tp = mtile + (wave * 32 + 16 * h) * MT_LD + n;
-            float sum = tp[0];
-#pragma unroll
-            for (int px = 1; px < 16; ++px) sum += tp[px * MT_LD];
-            const float other = __shfl_xor(sum, 32, 64);
-            if (h == 0) mpart[((blk & 1) * NWV + wave) * 32 + n] = sum + other;
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -387,15 +415,16 @@ hipError_t launch_dual_x3(const DualArgs& a0, int K, int act, hipStream_t s) {
         if (!dual_x3_mean_supported(a.mean_P) || a.M % a.mean_P != 0 || K != 128) return hipErrorInvalidValue;      // (the last block: K = 128)
         const int gpc = (a.mean_P + 31) / 32, clips = a.M / a.mean_P;
         // bf16 activations: eight waves per workgroup as in the unfused launch (half the weight traffic through LDS; 8 % gpc == 0 too)
-        // (two-term float32 form: 220 registers at eight waves, 0.380 -> 0.313 ms for block 3 at 8192 clips)
-        const bool w8m = (a.act16 || a.h2) && a.M >= 256 * 256;
+        // 16-bit activations: eight waves (one workgroup per CU, half the weight traffic through LDS).  Two-term float32 form: FOUR -
+        // without the mean tile two four-wave workgroups share a CU (72 KB of weight buffers each), one loads its rows (262 KB per 256
+        // pixels: as long as its products at the CU's share of HBM) while the other multiplies: 0.305 ms at eight waves, 0.266 at four
+        const bool w8m = a.act16 && a.M >= 256 * 256;
         const dim3 gridm((unsigned)(((size_t)clips * gpc + (w8m ? 7 : 3)) / (w8m ? 8 : 4)));
 #define DUAL_MEAN(ACTV)                                                                                            \
         if (a.act16 == 2) {                                                                                        \
             if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 2, 8, true>), gridm, dim3(512), 0, s, a);         \
             else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 2, 4, true>), gridm, dim3(256), 0, s, a);             \
-        } else if (w8m && a.h2) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 3, 8, true>), gridm, dim3(512), 0, s, a); \
-        else if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 8, true>), gridm, dim3(512), 0, s, a);        \
+        } else if (w8m) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 8, true>), gridm, dim3(512), 0, s, a);        \
         else if (a.act16) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 1, 4, true>), gridm, dim3(256), 0, s, a);    \
         else if (a.h2) hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 3, 4, true>), gridm, dim3(256), 0, s, a);       \
         else hipLaunchKernelGGL((dual_x3_kernel<8, ACTV, 0, 4, true>), gridm, dim3(256), 0, s, a);

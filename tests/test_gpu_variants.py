@@ -368,14 +368,15 @@ def test_bcresnet_bf16_activations(HipModel, golden_frontend):
     e = np.abs(lbf - ref)
     print("bcresnet bf16 activations, |dlogit| per clip:", {str(n): float(f"{v:.2e}") for n, v in zip(g["names"], e)},
           f"(float32 path: {np.abs(l32 - ref).max():.2e})")
-    # broadband and real-speech clips: 2e-2 (observed <= 1.3e-2).  Two kinds of input are outside what 8 significant bits can
-    # hold to 2e-2 and are bounded separately: the three synthetic pure-tone / chirp clips, on which this
-    # head's logit already moves by 7.7e-3 under a re-association of float32 sums (observed <= 4.7e-2, bound 0.1), and digital
-    # silence, whose log-mel is -100 dB in every bin - activations of magnitude 1e2..1e3 rounded to 2^-9 (observed 0.36, bound 0.5).
+    # broadband and real-speech clips: 2e-2 (observed <= 6.8e-3).  Two kinds of input are outside what 8 significant bits can hold to
+    # 2e-2 and are bounded separately: the three synthetic pure-tone / chirp clips, on which this head's logit
+    # already moves by 7.7e-3 under a re-association of float32 sums (observed <= 3.2e-2 since the blocks are chained - the depthwise
+    # reads unrounded planes - 4.7e-2 before; bound 6e-2), and digital silence, whose log-mel is -100 dB in every bin: every pixel rounds
+    # the same way (observed 0.079, 0.36 in round 3; bound 0.15).  act_dtype = "f16" is the mode without such carve-outs.
     silent = np.array([str(n).startswith("zeros") for n in g["names"]])
     assert e[~tonal & ~silent].max() <= 2e-2, e
-    assert e[tonal].max() <= 0.1, e
-    assert e[silent].max() <= 0.5, e
+    assert e[tonal].max() <= 6e-2, e
+    assert e[silent].max() <= 0.15, e
     assert np.abs(pbf - 1.0 / (1.0 + np.exp(-lbf.astype(np.float64)))).max() <= 1e-6
     for B in (3, 40):
         x = synth_features(B, cfg.input_shape, seed=B)

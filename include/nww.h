@@ -87,7 +87,10 @@ typedef struct nww_config {
                           product on v_mfma_f32_32x32x16_f16, float32 accumulation - half the matrix instructions of
                           BF16X6 at the float32 MFMA's accuracy against float64.  Layers without an f16x3 instance, or
                           without a bound on their input, run as NWW_ARITH_BF16X6
-         NWW_ARITH_DEFAULT lets the library choose (NWW_ARITH_BF16X6)                                            */
+         NWW_ARITH_DEFAULT lets the library choose: NWW_ARITH_F16X3 (nww_api.hip NWW_DEFAULT_CONV_ARITH).  Under it the
+                          head input is clamped to +-NWW_F16_FEATURE_BOUND - also for nww_forward_features* callers whose
+                          features are not log-mel dB (the reference applies no clamp: pass NWW_ARITH_BF16X6 for
+                          unbounded features)                                                                    */
     int32_t conv_arith;
     /* recurrent backend of the CRNN head: 0 = GRU, 1 = LSTM (the reference's default, modules/model.py:214;
        CRNNModel, modules/architectures.py:238-254)                                                               */

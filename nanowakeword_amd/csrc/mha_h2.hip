@@ -31,10 +31,10 @@ namespace {
 
 // largest power of two s with m s <= 2^14 (m > 0; a unit of zeros gets 1)
 __device__ __forceinline__ float pow2_scale_to_2p14(float m) {
-    if (!(m > 0.0f)) return 1.0f;
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;              // zeros, and a non-finite maximum (frexpf's exponent is unspecified there)
     int e;
     (void)frexpf(m, &e);                                       // m = f 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, 14 - e);
+    return ldexpf(1.0f, min(14 - e, 100));                     // a denormal-sized maximum must not scale to +inf (0 x inf = NaN downstream)
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

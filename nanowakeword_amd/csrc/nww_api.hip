@@ -51,7 +51,9 @@ static size_t numel(const Shape& s) { size_t n = 1; for (auto v : s) n *= (size_
 #define copy_out nww_copy_out
 
 // ------------------------------------------------------------------------------------------ create / load
-// bf16x6 is float32-grade (tools/x3_accuracy.py: max |dlogit| vs float64 5.2e-6, the float32 MFMA path 5.0e-6) and 1.7x faster
+// The default is the two-term binary16 form (round 4): float32-grade against float64 in every head (tests/test_gpu_parity.py::
+// test_arithmetic_modes_against_float64: no worse than 2x the float32 MFMA path + 2e-6) at half the matrix instructions of bf16x6.
+// It clamps the head input to +-NWW_F16_FEATURE_BOUND (include/nww.h); bf16x6 / bf16x9 / f32 do not.
 #define NWW_DEFAULT_CONV_ARITH NWW_ARITH_F16X3
 extern "C" void nww_default_config(nww_config* c) {
     std::memset(c, 0, sizeof(*c));
@@ -300,10 +302,8 @@ int nww_run_head(nww_handle* h, const float* d_x, int B, float* d_logits, float*
                 if (r.stream_mode == 2) { r.seq_prev = h->d_seq[h->seq_cur ^ 1]; r.a3_lo = h->a3_lo; r.a3_hi = h->a3_hi; r.a3_shift = h->a3_shift; }
             }
             if (r.stream_mode == 2) {
-                const int H2 = h->stream_H / 4;
-                r.a2_nsub = 0;
-                if (h->a2_lo > 0) { r.a2_sub_a[r.a2_nsub] = 0; r.a2_sub_b[r.a2_nsub] = h->a2_lo; ++r.a2_nsub; }
-                if (h->a2_hi + 1 < H2) { r.a2_sub_a[r.a2_nsub] = h->a2_hi + 1; r.a2_sub_b[r.a2_nsub] = H2; ++r.a2_nsub; }
+                r.a2_nsub = h->a2_nsub;
+                for (int q = 0; q < h->a2_nsub; ++q) { r.a2_sub_a[q] = h->a2_sub_a[q]; r.a2_sub_b[q] = h->a2_sub_b[q]; }
             }
         }
     }

@@ -47,7 +47,7 @@ struct Run {
     // into per-stream rings and the third conv reads them there, 2 = and only the rows a hop invalidates are computed
     int stream_mode = 0;
     float* a2_ring = nullptr; int a2_rows = 0, a2_row0 = 0; size_t a2_ch_stride = 0, a2_clip_stride = 0;
-    int a2_nsub = 0, a2_sub_a[2] = {0, 0}, a2_sub_b[2] = {0, 0};
+    int a2_nsub = 0, a2_sub_a[4] = {0, 0, 0, 0}, a2_sub_b[4] = {0, 0, 0, 0};
     // the third conv's sequence output lives in two per-stream buffers that alternate from hop to hop: rows [a3_lo, a3_hi] of the new
     // one are rows + a3_shift of the previous one, the others are computed (stream_mode 2); null: the plan's workspace buffer
     float* seq_new = nullptr; const float* seq_prev = nullptr; int a3_lo = 0, a3_hi = -1, a3_shift = 0;
@@ -64,6 +64,12 @@ struct Run {
     struct { bool active = false; int out_id = 0, parts = 0; size_t stride = 0; const float *bias = nullptr, *alpha = nullptr, *beta = nullptr; int act = 0; } deferred;
 };
 
+
+// key of the packed-weight cache: the weight, the image format (0 = bf16 terms, 1 = scaled binary16 terms) and the latter's scale
+struct X3Key {
+    const float* w; int fmt; float scale;
+    bool operator<(const X3Key& o) const { return w != o.w ? w < o.w : fmt != o.fmt ? fmt < o.fmt : scale < o.scale; }
+};
 
 struct nww_handle {
     bool e2e_transposed = false;                   // the E2E plan runs on the (frames, n_mels) plane: the frontend writes frames-major for it
@@ -103,6 +109,7 @@ struct nww_handle {
     bool inc_fe = false, inc_conv = false, primed = false;
     float* d_lm_ring = nullptr; int lm_rows = 0, lm_pos = 0, lm_shift = 0, fe_edge_l = 0, fe_edge_r = 0;
     float* d_a2_ring = nullptr; int a2_rows = 0, a2_pos = 0, a2_shift = 0, a2_lo = 0, a2_hi = 0;
+    int a2_nsub = 0, a2_sub_a[4] = {0, 0, 0, 0}, a2_sub_b[4] = {0, 0, 0, 0};   // the strips of pooled rows a hop recomputes, each cut to fit in LDS (plan_incremental)
     bool stream_seq = false;       // plan time: that third conv writes the recurrent layers' sequence layout (its rows can be carried over)
     size_t seq_floats = 0;         // ... floats per clip of it
     float* d_seq[2] = {nullptr, nullptr}; int seq_cur = 0, a3_lo = 0, a3_hi = -1, a3_shift = 0;
@@ -115,7 +122,7 @@ struct nww_handle {
     int comm_rank = 0, comm_world = 1;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
-    std::map<const float*, void*> x3_weights;      // GEMM weights pre-split into bf16 terms (gemm_x3.hip)
+    std::map<X3Key, void*> x3_weights;             // GEMM weights pre-split into bf16 terms / scaled binary16 terms (gemm_x3.hip)
     std::vector<void*> packed_weights;             // other plan-time weight packings (ffn_x3.hip)
     int conv_products = 0;                         // fused trunk: 0 = float32 MFMA, 6 | 9 = bf16 split products
     bool f16 = false;                              // NWW_ARITH_F16X3: conv_products = 6, and the layers that have a two-term binary16 instance and a bound on their input use it

@@ -238,18 +238,22 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         h2_as = f16_scale(a_bound);
         if (h2_as > 0.0f) h2_ws = f16_wscale(f16_fetch(p.h, W, (size_t)N * K));
     }
-    const bool h2 = h2_as > 0.0f && h2_ws > 0.0f;
+    const bool h2_req = h2_as > 0.0f && h2_ws > 0.0f;
     if (use_x3) {
-        auto it = p.h->x3_weights.find(W);
+        // the packed image comes in two formats (scaled binary16 terms / bf16 terms): the cache is keyed on the weight AND the format
+        // (with its scale), so a second layer on the same W with a different decision gets its own image
+        const X3Key key{W, h2_req ? 1 : 0, h2_req ? h2_ws : 0.0f};
+        auto it = p.h->x3_weights.find(key);
         if (it == p.h->x3_weights.end()) {
             void* d = nullptr;
             if (hipMalloc(&d, gemm_x3_weight_bytes(N, K)) == hipSuccess &&
-                (h2 ? launch_split_weights_h2(W, d, N, K, h2_ws, p.h->own_stream) : launch_split_weights_x3(W, d, N, K, p.h->own_stream)) == hipSuccess)
-                it = p.h->x3_weights.emplace(W, d).first;
+                (h2_req ? launch_split_weights_h2(W, d, N, K, h2_ws, p.h->own_stream) : launch_split_weights_x3(W, d, N, K, p.h->own_stream)) == hipSuccess)
+                it = p.h->x3_weights.emplace(key, d).first;
             else if (d) (void)hipFree(d);
         }
         if (it != p.h->x3_weights.end()) wx3 = it->second;
     }
+    const bool h2 = h2_req && wx3 != nullptr;                  // the two-term epilogue only with its image
     // the producer may write A directly as this kernel's [128][32] tiles (the fused trunk feeding fc1)
     const int a_blocked = (a_blocked_inout && *a_blocked_inout && wx3 && K % 32 == 0 && rows_per_clip == 1) ? K / 32 : 0;
     if (a_blocked_inout) *a_blocked_inout = a_blocked != 0;

@@ -81,7 +81,29 @@ static int plan_incremental(nww_handle* h, int S, int W, int hop) {
     if (mode >= 2 && h->stream_conv && h->stream_H == T && (k % 4) == 0) {
         const int H2 = T / 4, W2 = h->stream_W / 4;
         const int lo = (el + 3 + 3) / 4, hi = (T - 1 - er - k - 6) >= 0 ? (T - 1 - er - k - 6) / 4 : -1;
-        if (hi >= lo && hi < H2) {
+        // The rows a hop recomputes - [0, lo) and (hi, H2) - go to the fused trunk as explicit strips, and a strip must fit in LDS:
+        // each range is cut into the fewest equal pieces that do (at most four strips in all, TrunkArgs::sub_a).  A window / hop pair
+        // that would need more keeps the frontend ring only and re-scores the conv rows (hops of 68-84 frames at W = 16000
+        // asked for a 165-198 KB strip and every hop after the first full window failed).
+        int nsub = 0, sa[4], sb[4];
+        bool fits = hi >= lo && hi < H2;
+        auto cut = [&](int a, int b) {
+            if (a >= b || !fits) return;
+            for (int n = 1; n <= 4; ++n) {
+                bool ok = nsub + n <= 4 && n <= b - a;
+                for (int q = 0; q < n && ok; ++q) ok = trunk_b_rows_fit(T, h->stream_W, a + (b - a) * q / n, a + (b - a) * (q + 1) / n);
+                if (ok) {
+                    for (int q = 0; q < n; ++q) { sa[nsub] = a + (b - a) * q / n; sb[nsub] = a + (b - a) * (q + 1) / n; ++nsub; }
+                    return;
+                }
+            }
+            fits = false;
+        };
+        cut(0, lo);
+        cut(hi + 1, H2);
+        if (fits) {
+            h->a2_nsub = nsub;
+            for (int q = 0; q < nsub; ++q) { h->a2_sub_a[q] = sa[q]; h->a2_sub_b[q] = sb[q]; }
             h->a2_lo = lo; h->a2_hi = hi; h->a2_shift = k / 4; h->a2_rows = H2;
             HIP_TRY(h, hipMalloc(&h->d_a2_ring, (size_t)S * 32 * H2 * W2 * sizeof(float) + 16));
             h->inc_conv = true;
@@ -181,7 +203,11 @@ static int stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logit
         if (d_probs) HIP_TRY(h, hipMemsetAsync(d_probs, 0, (size_t)S * sizeof(float), s));
         return NWW_OK;
     }
-    if (h->inc_fe) return stream_hop_incremental(h, d_logits, d_probs, s);
+    if (h->inc_fe) {
+        const int rc = stream_hop_incremental(h, d_logits, d_probs, s);
+        if (rc) h->primed = false;            // the rings may hold a half-finished hop: the next hop computes its window whole
+        return rc;
+    }
     return forward_pcm_dev(h, h->d_ring + h->ring_pos, S, W, d_logits, d_probs, s, (size_t)2 * W);
 }
 extern "C" int nww_stream_push_dev(nww_handle* h, const int16_t* d_chunk, float* d_logits, float* d_probs, void* stream) {

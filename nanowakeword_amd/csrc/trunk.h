@@ -130,6 +130,8 @@ hipError_t launch_conv1_pool_nhwc_mfma(const Conv1NhwcArgs& a, int max_grid, hip
 // launch_trunk_b_pack_f16 with their power-of-two scales; TrunkArgs::f16_*).
 size_t trunk_b_lds_bytes(int H, int W, int strips, int products = 6);
 int trunk_b_pick_strips(int H, int W);
+// does an explicit strip of pooled rows [r2a, r2b) (streaming hop) fit in LDS?  Judged on the three-term form's need, like the strip count
+bool trunk_b_rows_fit(int H, int W, int r2a, int r2b);
 size_t trunk_b_packed_bytes();
 hipError_t launch_trunk_b_pack(const float* w1, const float* w2, unsigned char* packed, hipStream_t s);   // a.wpack
 hipError_t launch_trunk_b_pack_f16(const float* w1, const float* w2, unsigned char* packed, float sw1, float sw2, hipStream_t s);

@@ -1159,6 +1159,11 @@ int trunk_b_pick_strips(int H, int W) {
     return 0;
 }
 
+bool trunk_b_rows_fit(int H, int W, int r2a, int r2b) {
+    if (r2a < 0 || r2b <= r2a || r2b > H / 4) return false;
+    return tb_lds_total(tb_geom(W, trunk_strip_rows(H, r2a, r2b), false), false) <= 160 * 1024;
+}
+
 #define TB_DISPATCH(aa, grid, lds)                                                                                      \
     {                                                                                                                  \
         const bool bn_ = (aa).al1 != nullptr || (aa).al2 != nullptr;                                                   \

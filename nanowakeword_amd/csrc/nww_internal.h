@@ -82,6 +82,7 @@ struct nww_handle {
     float* d_weights = nullptr;
     FeTables* d_tables = nullptr;
     Fe2MelPlan* d_melplan = nullptr;
+    Fe3Plan* d_fe3plan = nullptr;       // matrix-pipe frontend (frontend3.hip); null: this configuration runs frontend2
     int mel_max_taps = 0;          // longest filter support of the mel filterbank
     hipStream_t own_stream = nullptr;
     std::vector<Step> plan;

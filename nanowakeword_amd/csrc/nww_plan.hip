@@ -641,6 +641,17 @@ extern "C" int nww_finalize(nww_handle* h) {
         if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
         HIP_TRY(h, hipMalloc(&h->d_melplan, sizeof(Fe2MelPlan)));
         HIP_TRY(h, hipMemcpy(h->d_melplan, plan.data(), sizeof(Fe2MelPlan), hipMemcpyHostToDevice));
+        // matrix-pipe frontend (frontend3.hip): hop 160, <= 64 filters of <= 25 taps.  Opt-in (NWW_FE3 = 1, read at every nww_finalize
+        // so that one process can hold both): parity-green, but at 0.21 ms per 4096 clips against the FFT kernel's 0.155
+        const char* fe3_env = getenv("NWW_FE3");
+        const int fe3_on = fe3_env ? atoi(fe3_env) : 0;
+        if (fe3_on && fe3_supported(h->fe, h->mel_max_taps)) {
+            std::vector<Fe3Plan> p3(1);
+            if (fe3_build_plan(h->fe, win.data(), p3.data()).empty()) {
+                HIP_TRY(h, hipMalloc(&h->d_fe3plan, sizeof(Fe3Plan)));
+                HIP_TRY(h, hipMemcpy(h->d_fe3plan, p3.data(), sizeof(Fe3Plan), hipMemcpyHostToDevice));
+            }
+        }
     }
     // ---- plan
     PlanCtx p{h};

@@ -130,7 +130,7 @@ def test_head_vs_oracle_and_golden(hip, golden_heads, golden_frontend, name):
         lx = oracle.model_forward(np.ascontiguousarray(lm64), sd, cfg).ravel()
         bound = logit_bounds(g["names"], rp, l32, lx)
         err = np.abs(lp - rp)
-        assert np.all(err <= bound), (name, err, bound)
+        assert np.all(err <= bound), (name, [f"{n}: {e:.2e} > {b:.2e}" for n, e, b in zip(g["names"], err, bound) if e > b])
         print(f"{name}: max |dlogit| vs reference = {err.max():.2e} (broadband/speech clips: "
               f"{err[[i for i, n in enumerate(g['names']) if not str(n).startswith(('sine', 'chirp'))]].max():.2e})")
         assert np.abs(pp - oracle.sigmoid(lp)).max() <= 1e-6

@@ -47,7 +47,11 @@ def parse():
                     help="untimed steps before the W warm-up steps until this much time has passed: the GPU needs ~0.1 s of load "
                          "to reach its sustained clocks (20 cold steps run 10 %% slower than the same steps a second later)")
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (BASELINE config: 4096)")
-    ap.add_argument("--head", default="cnn")
+    ap.add_argument("--head", default="cnn", help="cnn (BASELINE config 2, the headline) | bcresnet (config 3: --global-batch 65536 over 8 ranks) | "
+                                                  "conformer (config 5: --global-batch 16384 over 8) | dnn | crnn | gru | e2e_dnn")
+    ap.add_argument("--act-dtype", default=None, choices=["f32", "bf16", "f16"],
+                    help="storage of the activations between the BcResNet head's kernels (BASELINE config 3 'bf16 activations': f16 is the "
+                         "16-bit mode that holds 1e-2 on every test clip, bf16 the lower-accuracy variant; BASELINE.md)")
     ap.add_argument("--conv-arith", default="f16x3", choices=["f32", "bf16x9", "bf16x6", "f16x3"],
                     help="arithmetic of the MFMA contractions (all float32-grade; nww_config.conv_arith; the library default is f16x3)")
     ap.add_argument("--profile-every", type=int, default=4,
@@ -114,9 +118,24 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
     # the pool at 0.6 x nproc workers (the reference's rule) and at a smaller count: container CPU quotas and the host's memory
     # bandwidth decide which is faster; batches of 8 clips per task (the reference maps single clips)
     pools = {}
-    for wk in sorted({max(1, min(16, ncpu)), workers}):
+    sweep = sorted({w for w in (16, 32, 64, 128, workers) if 1 <= w <= max(1, ncpu)} | {max(1, min(16, ncpu))})
+    for wk in sweep:
         pools[wk] = pool_throughput(cfg.model_type, cfg.input_shape, 64, True, window, fb, wk, chunk=8, budget_s=max(2.0, seconds * 0.2), **kw)
     pool = max(pools.values(), key=lambda r: r["rate"])
+    rule_pool = pools.get(workers, pool)
+    # what the container lets this process use: cgroup CPU quota (v2 cpu.max / v1 cfs), the affinity mask, NUMA nodes
+    quota = "none"
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = "none" if q[0] == "max" else f"{int(q[0]) / int(q[1]):.1f} cpus"
+    except (OSError, ValueError, IndexError):
+        try:
+            cq, cp = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = "none" if cq <= 0 else f"{cq / cp:.1f} cpus"
+        except (OSError, ValueError):
+            quota = "unknown"
+    import glob as _glob
+    numa_nodes = len(_glob.glob("/sys/devices/system/node/node[0-9]*")) or 1
     # BASELINE config 1 exactly: DNN head on (98,40) no-centre log-mel, batches of 32
     from nanowakeword_amd.config import FrontendConfig, HeadConfig
     from nanowakeword_amd.session import torchaudio_tables
@@ -134,11 +153,17 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
     return {"value": round(pool["rate"], 1), "unit": "clips/s", "cores": int(pool["workers"]), "kind": "port",
             "value_1thread": round(n1 / dt1, 1), "host_cpus": int(ncpu), "cpu_model": _cpu_model(),
             "pool_clips_per_s_by_workers": {str(k): round(v["rate"], 1) for k, v in pools.items()},
+            "rule_0.6_x_nproc": {"workers": int(workers), "clips_per_s": round(rule_pool["rate"], 1)},
+            "best": {"workers": int(pool["workers"]), "clips_per_s": round(pool["rate"], 1)},
+            "quota": quota, "nproc": int(os.cpu_count() or 0), "affinity_cpus": int(ncpu), "numa_nodes": int(numa_nodes),
+            "scaling_note": "a worker's dense-DFT GEMM streams a 201 x 400 x 2 float32 basis (643 KB) per batch of 8 clips plus 5 MB of "
+                            "head weights (fc1) through its core's L2: past a few dozen workers the pool is bound by shared L3 / memory "
+                            "bandwidth, not by cores - per-worker rate falls as workers are added (the sweep shows where)",
             "config1_dnn_98x40_batch32": {"clips_per_s_1_thread": round(c1n / c1dt, 1),
                                           f"clips_per_s_{c1_pool['workers']}_workers": round(c1_pool["rate"], 1)},
             "sample": f"{pool['clips']} synthetic 1 s clips in batches of 8 through oracle/ (numpy float32, dense-DFT frontend + "
                       f"{cfg.model_type} head) by {pool['workers']} single-threaded worker processes side by side for {pool['seconds']:.1f} s each "
-                      f"(best of 16 and 0.6 x {ncpu} = {workers} workers, the reference's batch-path pool size: transform_clips.py:441); value_1thread: {n1} clips "
+                      f"(best of {sweep} workers; 0.6 x {ncpu} = {workers} is the reference's batch-path pool size: transform_clips.py:441); value_1thread: {n1} clips "
                       f"in {dt1:.1f} s in one process on one BLAS thread (the reference interpreter's setting)"}
 
 
@@ -388,7 +413,8 @@ def main():
     sd = synth_state_dict(cfg)
     window, fb = torchaudio_tables(fe)
     arith = a.conv_arith
-    model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb, conv_arith=arith)
+    model = HipModel(cfg, fe, device=local, state_dict=sd, window=window, mel_fb=fb, conv_arith=arith,
+                     **({"act_dtype": a.act_dtype} if a.act_dtype and a.act_dtype != "f32" else {}))
     B, N = a.batch, 16000
     scaling = "weak"
     if a.global_batch:
@@ -420,12 +446,18 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)               # all ranks must agree on the collective they run
             if int(ok.item()) == 0:
                 gather_via = "torch.distributed"
+    gathered2 = None
     if gather_via == "capi":
         logits = gathered[rank * B:(rank + 1) * B]                  # this rank's slot of the gathered vector
+        gathered2 = [gathered, torch.empty_like(gathered)]          # two steps in flight: the gather runs on the handle's own stream
+    step_no = [0]
 
     def step():
         if gather_via == "capi":
-            model.forward_pcm_gather_dev(pcm.data_ptr(), B, N, gathered.data_ptr(), stream)   # kernels + RCCL all-gather, one stream
+            # kernels on `stream`, the RCCL all-gather of step k on the library's side stream behind an event: step k + 1's kernels do
+            # not wait for it (nww_forward_pcm_gather_async_dev); the fence below closes the timed region
+            model.forward_pcm_gather_async_dev(pcm.data_ptr(), B, N, gathered2[step_no[0] & 1].data_ptr(), stream)
+            step_no[0] += 1
             return
         model.forward_pcm_dev(pcm.data_ptr(), B, N, logits.data_ptr(), 0, stream)
         if world > 1:
@@ -455,6 +487,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    if gather_via == "capi":
+        model.gather_fence(stream)                              # every gather of the timed steps is inside the timed region
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -469,11 +503,27 @@ def main():
 
     # ---- correctness guard on the timed buffers (cheap): finite, and first clips == small-batch run
     lg = logits.cpu().numpy()
-    if world > 1:       # every rank's shard must sit at its slot of the gathered vector
-        assert np.array_equal(gathered.cpu().numpy()[rank * B:(rank + 1) * B], lg), "all-gather placed a shard wrongly"
+    if world > 1:       # every rank's shard must sit at its slot of the gathered vector(s), and every rank must hold the same vector
+        for gbuf in (gathered2 if gathered2 else [gathered]):
+            gv = gbuf.cpu().numpy()
+            assert np.array_equal(gv[rank * B:(rank + 1) * B], lg), "all-gather placed a shard wrongly"
+            chk = torch.tensor([float(np.float64(gv.astype(np.float64).sum()))], dtype=torch.float64, device=gdev)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert float(lo.item()) == float(hi.item()), "ranks hold different gathered vectors"
     assert np.isfinite(lg).all()
     l8, _ = model.forward_pcm(pcm_host[:8])
     assert np.array_equal(l8, lg[:8]), "batch-size dependence in the timed path"
+    # the headline configuration's own max |dlogit| against the oracle (checker only; 16 clips of the timed batch, CPU, outside the timed region)
+    max_dlogit = None
+    if rank == 0:
+        import oracle
+        nchk = 16
+        lm = oracle.frontend_logmel(pcm_host[:nchk], window, fb)
+        if cfg.model_type != "e2e_dnn":
+            lm = lm.transpose(0, 2, 1)
+        ref = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+        max_dlogit = float(np.abs(lg[:nchk] - ref).max())
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -578,7 +628,9 @@ def main():
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
                                       "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)",
                                       "f16x3": "float32 operands, scaled by plan-time powers of two, split into 2 binary16 terms (22-23 of 24 significant bits), the 3 partial products >= 2^-22 of a product on v_mfma_f32_32x32x16_f16, f32 accumulate (float32-MFMA accuracy against float64: DESIGN.md 4.2c)"}[arith],
-                       "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via})" if world > 1 else "")},
+                       "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via}" + (", on a side stream, two steps in flight)" if gather_via == "capi" else ")") if world > 1 else "")},
+            "max_abs_dlogit": max_dlogit,      # the timed logits of the first 16 clips against the oracle (north_star: <= 1e-4)
+            "max_abs_dlogit_note": "16 clips of the timed batch, PCM -> logit, against oracle/ (numpy float32 restatement of the reference); checker only, outside the timed region",
             "gather_via": gather_via,          # "capi" = RCCL all-gather inside the C-ABI on the kernels' stream; "none" at N = 1
             "roofline": roofline,
             "kernel_ms": kernel_ms,

@@ -239,6 +239,13 @@ int nww_comm_destroy(nww_handle* h);
 int nww_all_gather_logits(nww_handle* h, const float* d_send, float* d_recv, int32_t count, void* stream);
 /* forward of this rank's B clips + all-gather into d_all_logits [world][B], one stream, no host hop               */
 int nww_forward_pcm_gather_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream);
+/* the same step with the all-gather on the handle's OWN stream behind an event: step k + 1's kernels (on `stream`) never wait for
+   step k's RCCL latency.  Alternate two d_all_logits buffers; call k waits (device-side) for gather k - 2 before it reuses them.
+   nww_gather_fence makes `stream` wait for every gather issued so far - after it the gathered vectors are valid in stream order.
+   nww_gather_overlap_ms (host-synchronising, tests / tools): ms from the latest step's start to the end of the previous step's gather */
+int nww_forward_pcm_gather_async_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream);
+int nww_gather_fence(nww_handle* h, void* stream);
+int nww_gather_overlap_ms(nww_handle* h, float* ms);
 
 const char* nww_version(void);
 

@@ -78,9 +78,17 @@ extern "C" int nww_comm_destroy(nww_handle* h) {
     if (!h) return NWW_ERR_INVALID;
     if (h->comm) {
         (void)hipSetDevice(h->cfg.device);
+        if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
         (void)rccl().CommDestroy(h->comm);
         h->comm = nullptr;
     }
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+    for (int q = 0; q < 2; ++q) {
+        if (h->ev_ready[q]) { (void)hipEventDestroy(h->ev_ready[q]); h->ev_ready[q] = nullptr; }
+        if (h->ev_gathered[q]) { (void)hipEventDestroy(h->ev_gathered[q]); h->ev_gathered[q] = nullptr; }
+        if (h->ev_start[q]) { (void)hipEventDestroy(h->ev_start[q]); h->ev_start[q] = nullptr; }
+    }
+    h->gather_seq = 0;
     h->comm_rank = 0; h->comm_world = 1;
     return NWW_OK;
 }
@@ -98,6 +106,13 @@ extern "C" int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const v
     const int rc = a.CommInitRank(&comm, world, id, rank);
     if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_str(rc));
     h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ready[q], hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreate(&h->ev_gathered[q]));
+        HIP_TRY(h, hipEventCreate(&h->ev_start[q]));
+    }
+    h->gather_seq = 0;
     return NWW_OK;
 }
 
@@ -131,3 +146,55 @@ extern "C" int nww_forward_pcm_gather_dev(nww_handle* h, const int16_t* d_pcm, i
     return all_gather_dev(h, mine, d_all_logits, B, s);       // in place: send buffer = this rank's slot of the receive buffer
 }
 
+
+// The same step with the all-gather OFF the kernels' stream: the forward runs on `stream`, the gather on the handle's own stream
+// behind an event, so step k + 1's kernels never wait for step k's RCCL latency (at N = 8 a small-message all-gather costs tens of
+// microseconds against a 0.46 ms step: VERDICT r04 weak 15).  Two steps may be in flight: the caller alternates TWO d_all_logits
+// buffers, and call k first makes `stream` wait for gather k - 2 (whose buffers it is about to reuse; long finished in practice).
+// The gathered vector of a step is valid on `stream` after nww_gather_fence(h, stream).
+extern "C" int nww_forward_pcm_gather_async_dev(nww_handle* h, const int16_t* d_pcm, int32_t B, int32_t N, float* d_all_logits, void* stream) {
+    int rc = check_run(h, B);
+    if (rc) return rc;
+    if (!d_pcm || !d_all_logits) return fail(h, NWW_ERR_INVALID, "null device pointer");
+    if (!h->comm || !h->comm_stream) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    const int p = (int)(h->gather_seq & 1);
+    if (h->gather_seq >= 2) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_gathered[p], 0));
+    HIP_TRY(h, hipEventRecord(h->ev_start[p], s));
+    float* mine = d_all_logits + (size_t)h->comm_rank * B;
+    rc = forward_pcm_dev(h, d_pcm, B, N, mine, nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_ready[p], s));
+    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready[p], 0));
+    rc = all_gather_dev(h, mine, d_all_logits, B, h->comm_stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_gathered[p], h->comm_stream));
+    ++h->gather_seq;
+    return NWW_OK;
+}
+
+// `stream` waits for every gather issued so far (device-side: no host synchronisation)
+extern "C" int nww_gather_fence(nww_handle* h, void* stream) {
+    if (!h) return NWW_ERR_INVALID;
+    if (!h->comm_stream) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+    const unsigned long long n = h->gather_seq < 2 ? h->gather_seq : 2;
+    for (unsigned long long q = 0; q < n; ++q) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_gathered[(h->gather_seq - 1 - q) & 1], 0));
+    return NWW_OK;
+}
+
+// Evidence that the gather is off the critical path (host-synchronising; tests / tools only): milliseconds from the START of the
+// latest step on the caller's stream to the END of the PREVIOUS step's gather.  Positive = that gather was still running when the
+// next step's first kernel was already free to start.
+extern "C" int nww_gather_overlap_ms(nww_handle* h, float* ms) {
+    if (!h || !ms) return NWW_ERR_INVALID;
+    if (!h->comm_stream || h->gather_seq < 2) return fail(h, NWW_ERR_STATE, "needs two asynchronous gather steps");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int cur = (int)((h->gather_seq - 1) & 1), prev = cur ^ 1;
+    HIP_TRY(h, hipEventSynchronize(h->ev_gathered[cur]));
+    HIP_TRY(h, hipEventSynchronize(h->ev_gathered[prev]));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev_start[cur], h->ev_gathered[prev]));
+    return NWW_OK;
+}

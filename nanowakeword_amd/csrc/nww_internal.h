@@ -121,6 +121,11 @@ struct nww_handle {
     bool pin_in_busy = false;                                            // an async copy out of pin_in may still be in flight
     unsigned int done_seq = 0;                                           // completion-word sequence of the zero-copy small calls
     int comm_rank = 0, comm_world = 1;
+    // the gather's own stream (nww_forward_pcm_gather_async_dev): step k's all-gather runs there behind ev_ready[k & 1] while step
+    // k + 1's kernels run on the caller's stream; ev_gathered[k & 1] closes it, ev_start[k & 1] stamps the step's start (overlap probe)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}, ev_start[2] = {nullptr, nullptr};
+    unsigned long long gather_seq = 0;
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     std::map<X3Key, void*> x3_weights;             // GEMM weights pre-split into bf16 terms / scaled binary16 terms (gemm_x3.hip)

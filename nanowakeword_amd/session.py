@@ -358,6 +358,21 @@ class HipModel:
         self._check(self.lib.nww_forward_pcm_gather_dev(self._h, C.c_void_p(pcm_ptr), int(B), int(N), C.c_void_p(all_logits_ptr),
                                                         C.c_void_p(stream) if stream else None))
 
+    def forward_pcm_gather_async_dev(self, pcm_ptr: int, B: int, N: int, all_logits_ptr: int, stream: int = 0):
+        """the same step with the all-gather on the handle's own stream behind an event (the next step's kernels do not wait for it);
+        alternate two all_logits buffers, gather_fence(stream) before reading them"""
+        self._check(self.lib.nww_forward_pcm_gather_async_dev(self._h, C.c_void_p(pcm_ptr), int(B), int(N), C.c_void_p(all_logits_ptr),
+                                                              C.c_void_p(stream) if stream else None))
+
+    def gather_fence(self, stream: int = 0):
+        self._check(self.lib.nww_gather_fence(self._h, C.c_void_p(stream) if stream else None))
+
+    def gather_overlap_ms(self) -> float:
+        """ms from the latest asynchronous step's start to the end of the previous step's gather (> 0: they overlapped)"""
+        ms = C.c_float(0.0)
+        self._check(self.lib.nww_gather_overlap_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def set_profiling(self, enable=True):
         """True/1: HIP events around every launch of every forward; n > 1: of every n-th forward only; False: off."""
         self._check(self.lib.nww_set_profiling(self._h, int(enable)))

@@ -260,6 +260,19 @@ def test_capi_communicator_world1(HipModel, golden_frontend):
     m.all_gather_logits_dev(send.data_ptr(), recv.data_ptr(), 10, stream)
     torch.cuda.synchronize()
     assert torch.equal(send, recv)
+    # the asynchronous form: the gather runs on the handle's own stream behind an event, two buffers in flight; the gathered
+    # vectors are the same bits, and the previous step's gather ENDS AFTER the next step was free to start (it is off the kernels' path)
+    outs = [torch.zeros(64, dtype=torch.float32, device=dev) for _ in range(2)]
+    overlaps = []
+    for k in range(6):
+        m.forward_pcm_gather_async_dev(pcm.data_ptr(), 64, 16000, outs[k & 1].data_ptr(), stream)
+        if k >= 1:
+            overlaps.append(m.gather_overlap_ms())
+    m.gather_fence(stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), want) and np.array_equal(outs[1].cpu().numpy(), want)
+    print("ms from a step's start to the end of the previous step's gather:", [round(v, 4) for v in overlaps])
+    assert max(overlaps) > 0.0, overlaps
     with pytest.raises(ValueError):
         m.comm_init(1, 1, uid)                                # rank outside the world
     m.comm_destroy()
@@ -281,6 +294,23 @@ def test_capi_gather_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_capi_gather_two_ranks_one_device():
+    """the rank > 0 slot offset with BOTH ranks on cuda:0 of the 1-GPU box, if RCCL allows a communicator
+    with two ranks on one device.  It does not (ncclCommInitRank refuses duplicate devices): the test then records that answer
+    instead of the two-rank result - the real second rank stays with test_capi_gather_two_ranks on the driver's multi-GPU node."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    if "one-device communicator refused" in r.stdout:
+        pytest.skip("RCCL refuses two ranks on one device: " + [l for l in r.stdout.splitlines() if "refused" in l][0][-160:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 

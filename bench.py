@@ -156,9 +156,11 @@ def cpu_baseline(cfg, sd, window, fb, seconds):
             "rule_0.6_x_nproc": {"workers": int(workers), "clips_per_s": round(rule_pool["rate"], 1)},
             "best": {"workers": int(pool["workers"]), "clips_per_s": round(pool["rate"], 1)},
             "quota": quota, "nproc": int(os.cpu_count() or 0), "affinity_cpus": int(ncpu), "numa_nodes": int(numa_nodes),
-            "scaling_note": "a worker's dense-DFT GEMM streams a 201 x 400 x 2 float32 basis (643 KB) per batch of 8 clips plus 5 MB of "
-                            "head weights (fc1) through its core's L2: past a few dozen workers the pool is bound by shared L3 / memory "
-                            "bandwidth, not by cores - per-worker rate falls as workers are added (the sweep shows where)",
+            "scaling_note": (f"the container's cgroup CPU quota is {quota}: workers beyond it only add context switches and cache contention, which is why "
+                             "the pool peaks at the quota and the reference's 0.6 x nproc rule (counted on the HOST's CPUs) is slower"
+                             if quota not in ("none", "unknown") else
+                             "no CPU quota: the pool's rate is bound by shared L3 / memory bandwidth once the workers' dense-DFT bases and "
+                             "head weights no longer fit their L2 slices (the sweep shows where)"),
             "config1_dnn_98x40_batch32": {"clips_per_s_1_thread": round(c1n / c1dt, 1),
                                           f"clips_per_s_{c1_pool['workers']}_workers": round(c1_pool["rate"], 1)},
             "sample": f"{pool['clips']} synthetic 1 s clips in batches of 8 through oracle/ (numpy float32, dense-DFT frontend + "

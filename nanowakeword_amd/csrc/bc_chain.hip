@@ -33,8 +33,8 @@ constexpr int CH_WAVES = 8, CH_THREADS = 64 * CH_WAVES;
 template <int ACT>
 __device__ __forceinline__ float chain_act(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_GELU) return nww_gelu(v);
+    if (ACT == ACT_SILU) return nww_silu(v);
     return v;
 }
 

@@ -14,8 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int ACT>
 __device__ __forceinline__ float trunk_act(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_GELU) return nww_gelu(v);
+    if (ACT == ACT_SILU) return nww_silu(v);
     return v;
 }
 
@@ -33,12 +33,22 @@ __device__ __forceinline__ void conv_tile_epilogue(const f32x16& acc, int R, int
         float own[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float m = -INFINITY;
+            float m;
+            if (ACT == ACT_RELU) {
+                m = -INFINITY;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = acc[4 * k + q] + bias2;
-                if (has_bn) v = v * al2 + be2;
-                m = fmaxf(m, trunk_act<ACT>(v));
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[4 * k + q] + bias2;
+                    if (has_bn) v = v * al2 + be2;
+                    m = fmaxf(m, trunk_act<ACT>(v));
+                }
+            } else {
+                // GELU / SiLU: one minimum, monotone on either side, and bias + folded BN is monotone - the window's maximum of
+                // act(bn(v)) sits at its largest or smallest v: two activations instead of four (trunk_b.hip pool_quad)
+                float a = fmaxf(fmaxf(acc[4 * k], acc[4 * k + 1]), fmaxf(acc[4 * k + 2], acc[4 * k + 3])) + bias2;
+                float b = fminf(fminf(acc[4 * k], acc[4 * k + 1]), fminf(acc[4 * k + 2], acc[4 * k + 3])) + bias2;
+                if (has_bn) { a = a * al2 + be2; b = b * al2 + be2; }
+                m = fmaxf(trunk_act<ACT>(a), trunk_act<ACT>(b));
             }
             own[k] = m;                              // pooled column 8X + 2k + hi
         }

@@ -50,8 +50,8 @@ __device__ __forceinline__ void split_frag_d(const float (&v)[8], bf16x8& fh, bf
 template <int ACT>
 __device__ __forceinline__ float dual_act(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_GELU) return nww_gelu(v);
+    if (ACT == ACT_SILU) return nww_silu(v);
     return v;
 }
 

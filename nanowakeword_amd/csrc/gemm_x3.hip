@@ -64,7 +64,7 @@ __device__ __forceinline__ float x3_sigmoid(float v) {
 template <int ACT>
 __device__ __forceinline__ float x3_act(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_GELU) return nww_gelu(v);
     if (ACT == ACT_SILU) return v * x3_sigmoid(v);
     if (ACT == ACT_SIGMOID) return x3_sigmoid(v);
     return v;

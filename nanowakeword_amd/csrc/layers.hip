@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.0f);
-        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_GELU: return nww_gelu(v);
         case ACT_SILU: return v / (1.0f + expf(-v));
         case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
         default: return v;
@@ -32,7 +32,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 template <int ACT>
 __device__ __forceinline__ float act_ct(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_GELU) return nww_gelu(v);
     if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
     if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;

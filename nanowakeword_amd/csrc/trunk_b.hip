@@ -93,8 +93,8 @@ constexpr int NFRAG = 27 + 6;           // packed image size (the three-term for
 template <int ACT>
 __device__ __forceinline__ float tb_act(float v) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_GELU) return nww_gelu(v);
+    if (ACT == ACT_SILU) return nww_silu(v);
     return v;
 }
 // v -> three float32 bit patterns whose upper 16 bits are the bf16 terms (lo has at most 8 significant bits left)
@@ -173,14 +173,17 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
         const float e = al < 0.0f ? mn : mx;
         return fmaxf((e + bias) * al + be, 0.0f);
     }
-    float m = -INFINITY;
-    const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float t = v[q] + bias;
-        if (BN) t = t * al + be;
-        m = fmaxf(m, tb_act<ACT>(t));
-    }
+    // GELU / SiLU fall to their single minimum (x = -0.75 / -1.28) and rise after it, and bias + folded BN is monotone: over the
+    // window, act(bn(v)) is largest at the window's LARGEST or SMALLEST v - two activations per pooled value instead of four
+    // (the activation, 6-22 instructions, was 2/3 of the non-ReLU trunk: 0.68 ms against ReLU's 0.25)
+    float t, mx, mn;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
+    asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(v3));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
+    asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(v3));
+    float a = mx + bias, b = mn + bias;
+    if (BN) { a = a * al + be; b = b * al + be; }
+    const float m = fmaxf(tb_act<ACT>(a), tb_act<ACT>(b));
     return SC ? m * post : m;
 }
 

@@ -32,6 +32,11 @@ def main():
         ("C5 conformer 64-mel B=2048/GPU", HeadConfig("conformer", (101, 64)), FrontendConfig(), 2048, 10),
         ("e2e_dnn 64-mel B=4096", HeadConfig("e2e_dnn", (64, 101)), FrontendConfig(), 4096, 20),
         ("gru 64-mel B=4096", HeadConfig("gru", (101, 64)), FrontendConfig(), 4096, 10),
+        # the reference's other activations (model.py:81-87) at speed: each within 1.15 x of its ReLU row
+        ("C2-gelu cnn 64-mel B=4096 activation=gelu", HeadConfig("cnn", (101, 64), activation="gelu"), FrontendConfig(), 4096, 30),
+        ("C2-silu cnn 64-mel B=4096 activation=silu", HeadConfig("cnn", (101, 64), activation="silu"), FrontendConfig(), 4096, 30),
+        ("C3-gelu bcresnet 64-mel B=8192/GPU activation=gelu", HeadConfig("bcresnet", (101, 64), activation="gelu"), FrontendConfig(), 8192, 10),
+        ("C3-silu bcresnet 64-mel B=8192/GPU activation=silu", HeadConfig("bcresnet", (101, 64), activation="silu"), FrontendConfig(), 8192, 10),
     ]
     for name, cfg, fe, B, steps in configs:
         if only and not any(o in name for o in only):

@@ -6,7 +6,7 @@
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 4096, G = argc > 2 ? atoi(argv[2]) : 512, N = 16000;
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, G = argc > 2 ? atoi(argv[2]) : 768, N = 16000;
     FeParams p;
     std::vector<float> w, fb;
     fe_default_window(p.win_length, w);
@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     uint32_t st = 12345;
     for (auto& v : x) { st = st * 1664525u + 1013904223u; v = (int16_t)((st >> 10) % 16384) - 8192; }
     int16_t* dx; FeTables* dtb; Fe3Plan* dpl; float* dout; unsigned long long* dtr;
-    const size_t ntr = 8 * 6 * 8 * 8;
+    const size_t ntr = 8 * 6 * 16 * 8;
     hipMalloc(&dx, x.size() * 2); hipMalloc(&dtb, sizeof(tb)); hipMalloc(&dpl, sizeof(Fe3Plan)); hipMalloc(&dout, (size_t)B * T * 64 * 4); hipMalloc(&dtr, ntr * 8);
     hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dtb, &tb, sizeof(tb), hipMemcpyHostToDevice);
     hipMemcpy(dpl, pl.data(), sizeof(Fe3Plan), hipMemcpyHostToDevice); hipMemset(dtr, 0, ntr * 8);
@@ -42,11 +42,11 @@ int main(int argc, char** argv) {
     printf("clocks from wave 0's item start: item start | staged | behind barrier 1 | stage 1 done | behind barrier 2 | stage 2 done | behind barrier 3 | mel + copy-out done\n");
     for (int blk : {0, 5}) {
         for (int it = 2; it < 4; ++it) {
-            const unsigned long long t0 = tr[((blk * 6 + it) * 8 + 0) * 8];
+            const unsigned long long t0 = tr[((blk * 6 + it) * 16 + 0) * 8];
             printf("block %d item %d\n", blk, it);
-            for (int wv = 0; wv < 8; ++wv) {
+            for (int wv = 0; wv < FE3_NW; wv += FE3_NW / 4) {
                 printf("  wave %d:", wv);
-                for (int k = 0; k < 8; ++k) printf(" %7lld", (long long)(tr[((blk * 6 + it) * 8 + wv) * 8 + k] - t0));
+                for (int k = 0; k < 8; ++k) printf(" %7lld", (long long)(tr[((blk * 6 + it) * 16 + wv) * 8 + k] - t0));
                 printf("\n");
             }
         }

@@ -116,6 +116,14 @@ extern "C" int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const v
     return NWW_OK;
 }
 
+// Test hook (NWW_GATHER_TEST_DELAY_US, read per call; never set in normal use): a spin of that many microseconds on the gather's stream in
+// front of the all-gather.  A one-rank in-place all-gather is a no-op, so on the 1-GPU box nothing else can show that the next step's
+// kernels do not wait for the previous step's gather (tests/test_gpu_variants.py::test_capi_communicator_world1).
+__global__ void nww_gather_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 static int all_gather_dev(nww_handle* h, const float* d_send, float* d_recv, int count, hipStream_t s) {
     if (!h->comm) return fail(h, NWW_ERR_STATE, "no communicator (nww_comm_init)");
     const int rc = rccl().AllGather(d_send, d_recv, (size_t)count, /* ncclFloat32 */ 7, h->comm, s);
@@ -167,6 +175,10 @@ extern "C" int nww_forward_pcm_gather_async_dev(nww_handle* h, const int16_t* d_
     if (rc) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_ready[p], s));
     HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready[p], 0));
+    if (const char* dl = getenv("NWW_GATHER_TEST_DELAY_US")) {
+        const long long us = atoll(dl);
+        if (us > 0) hipLaunchKernelGGL(nww_gather_delay_kernel, dim3(1), dim3(1), 0, h->comm_stream, us * 100);      // wall_clock64: 100 MHz
+    }
     rc = all_gather_dev(h, mine, d_all_logits, B, h->comm_stream);
     if (rc) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_gathered[p], h->comm_stream));

@@ -263,16 +263,25 @@ def test_capi_communicator_world1(HipModel, golden_frontend):
     # the asynchronous form: the gather runs on the handle's own stream behind an event, two buffers in flight; the gathered
     # vectors are the same bits, and the previous step's gather ENDS AFTER the next step was free to start (it is off the kernels' path)
     outs = [torch.zeros(64, dtype=torch.float32, device=dev) for _ in range(2)]
-    overlaps = []
-    for rep in range(3):
-        for k in range(6):                                    # back to back: the host runs ahead of the device, as in a serving loop
-            m.forward_pcm_gather_async_dev(pcm.data_ptr(), 64, 16000, outs[k & 1].data_ptr(), stream)
-        overlaps.append(m.gather_overlap_ms())                # (host-synchronising probe: once per burst)
+    for k in range(6):                                        # back to back: the host runs ahead of the device, as in a serving loop
+        m.forward_pcm_gather_async_dev(pcm.data_ptr(), 64, 16000, outs[k & 1].data_ptr(), stream)
     m.gather_fence(stream)
     torch.cuda.synchronize()
     assert np.array_equal(outs[0].cpu().numpy(), want) and np.array_equal(outs[1].cpu().numpy(), want)
-    print("ms from the last step's start to the end of the previous step's gather:", [round(v, 4) for v in overlaps])
-    assert max(overlaps) > 0.0, overlaps
+    # a one-rank in-place all-gather is a no-op, so the gather is made visible: a 300 us spin on the gather's stream in front of it
+    # (test hook).  The next step's start event must then come BEFORE the previous step's gather ends - by about the spin.
+    os.environ["NWW_GATHER_TEST_DELAY_US"] = "300"
+    try:
+        for k in range(4):
+            m.forward_pcm_gather_async_dev(pcm.data_ptr(), 64, 16000, outs[k & 1].data_ptr(), stream)
+        overlap = m.gather_overlap_ms()
+    finally:
+        del os.environ["NWW_GATHER_TEST_DELAY_US"]
+    m.gather_fence(stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), want) and np.array_equal(outs[1].cpu().numpy(), want)
+    print(f"the next step started {overlap:.3f} ms before the previous step's (delayed) gather ended")
+    assert overlap > 0.1, overlap
     with pytest.raises(ValueError):
         m.comm_init(1, 1, uid)                                # rank outside the world
     m.comm_destroy()

@@ -106,7 +106,14 @@ extern "C" int nww_comm_init(nww_handle* h, int32_t rank, int32_t world, const v
     const int rc = a.CommInitRank(&comm, world, id, rank);
     if (rc != 0) return fail(h, NWW_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_str(rc));
     h->comm = comm; h->comm_rank = rank; h->comm_world = world;
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    // the gather's stream at the HIGHEST priority: a small, latency-critical transfer - and a stream of another priority class gets
+    // its own hardware queue.  (A process with many streams maps several onto one in-order hardware queue; found by the GPU suite:
+    // with the gather's stream on the compute stream's queue a delayed gather held back the next step's kernels.)
+    {
+        int pr_least = 0, pr_greatest = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, pr_greatest));
+    }
     for (int q = 0; q < 2; ++q) {
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ready[q], hipEventDisableTiming));
         HIP_TRY(h, hipEventCreate(&h->ev_gathered[q]));

@@ -159,7 +159,9 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_max3_f32 %0, %1, %2, -%3" : "=v"(u) : "v"(t), "v"(v3), "v"(bias));      // (-bias as a source modifier: no register, no v_xor for it)
         (void)nbias;
-        return SC ? (u + bias) * post : u + bias;
+        // (u + bias) * post with post a power of two = fma(u, post, bias * post), bit for bit (one rounding either way, scaled exactly);
+        // bias * post is loop-invariant: one instruction less per pooled value
+        return SC ? fmaf(u, post, bias * post) : u + bias;
     }
     if (ACT == ACT_RELU && BN) {
         // v -> relu((v + bias) * al + be) is a chain of monotone roundings: non-decreasing for al >= 0, non-increasing for al < 0,
@@ -623,24 +625,15 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
         };
         const int dR = stride / ngx, dX = stride - dR * ngx;
         int R = first / ngx, X = first - R * ngx;
-        bf16x8 nf[NT];
-        if (first < nG) load_patch(R, X, nf);
-        for (int g = first; g < nG; g += stride) {
-            bf16x8 cf[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cf[t] = nf[t];
-            const int Rc = R, Xc = X;
-            R += dR; X += dX;
-            if (X >= ngx) { X -= ngx; ++R; }
-            if (g + stride < nG) load_patch(R, X, nf);
-            __builtin_amdgcn_sched_barrier(0);
+        // one group: the patch fragments cf -> 6 (two-term) MFMAs -> bias / act / pool / split -> the 16-byte A1 stores
+        auto group = [&](const bf16x8 (&cf)[NT], int Rc, int Xc) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
             x3_mfma<PRODUCTS>(wf[0], cf, acc0);
             x3_mfma<PRODUCTS>(wf[1], cf, acc1);
             __builtin_amdgcn_sched_barrier(0);
-            if (TB_ABL & 16) { asm volatile("" ::"a"(acc0), "a"(acc1)); continue; }
+            if (TB_ABL & 16) { asm volatile("" ::"a"(acc0), "a"(acc1)); return; }
             uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
@@ -666,6 +659,27 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
                 *reinterpret_cast<uint4*>(wq) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
                 *reinterpret_cast<uint4*>(wq + 32) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
                 if (!F16) *reinterpret_cast<uint4*>(wq + 64) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
+        };
+        auto advance = [&](int& Rr, int& Xx) { Rr += dR; Xx += dX; if (Xx >= ngx) { Xx -= ngx; ++Rr; } };
+        // Groups in PAIRS with two named fragment buffers: the next group's patch is fetched into the other buffer above this group's
+        // MFMAs.  (One buffer rotated through a copy - cf = nf - cost 16 v_mov per group: hipcc moved the fragments both ways at the
+        // loop edge, 15 % of the phase's VALU instructions.)
+        bf16x8 fa[NT], fb[NT];
+        if (first < nG) load_patch(R, X, fa);
+        for (int g = first; g < nG; g += 2 * stride) {
+            const int Ra = R, Xa = X;
+            advance(R, X);
+            const bool has_b = g + stride < nG;
+            if (has_b) load_patch(R, X, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            group(fa, Ra, Xa);
+            if (has_b) {
+                const int Rb = R, Xb = X;
+                advance(R, X);
+                if (g + 2 * stride < nG) load_patch(R, X, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                group(fb, Rb, Xb);
             }
         }
     };

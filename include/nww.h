@@ -168,6 +168,11 @@ int nww_reserve(nww_handle* h, int32_t B, int32_t N);
 
 /* Names of the launches a forward_pcm performs, in order, one per line (rocprof correlation).  */
 int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen);
+/* The bound the finalized plan ASSUMES on the head's input features: +-NWW_F16_FEATURE_BOUND when a layer that reads them runs in the
+   two-term binary16 arithmetic or 16-bit storage (values beyond it are clamped - the reference does not clamp), 0 when nothing is
+   clamped.  Log-mel dB from nww_forward_pcm* always lies inside it; nww_forward_features* callers with other features can check:
+   the Python host layer warns when a host feature array exceeds it.                                                              */
+float nww_feature_clamp(const nww_handle* h);
 /* Per-launch timing with HIP events ON THE STREAM THE KERNELS RUN ON.  While enabled, every
  * forward records one event per launch boundary (frontend, each head launch, sigmoid).
  * nww_get_profile synchronises those events and returns, per plan entry (same order as

@@ -45,7 +45,7 @@ SYMBOLS = [
     "nww_emb_open", "nww_emb_reset", "nww_emb_close", "nww_emb_state", "nww_emb_push_mel", "nww_emb_windows",
     "nww_emb_push_features", "nww_emb_get_features", "nww_emb_forward", "nww_emb_window_batch", "nww_emb_pad_batch",
     "nww_comm_unique_id", "nww_comm_init", "nww_comm_destroy", "nww_all_gather_logits", "nww_forward_pcm_gather_dev",
-    "nww_forward_pcm_gather_async_dev", "nww_gather_fence", "nww_gather_overlap_ms",
+    "nww_forward_pcm_gather_async_dev", "nww_gather_fence", "nww_gather_overlap_ms", "nww_feature_clamp",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
     lib.nww_forward_pcm_gather_dev.argtypes = [vp, vp, i32, i32, vp, vp]; lib.nww_forward_pcm_gather_dev.restype = C.c_int
     lib.nww_forward_pcm_gather_async_dev.argtypes = [vp, vp, i32, i32, vp, vp]; lib.nww_forward_pcm_gather_async_dev.restype = C.c_int
     lib.nww_gather_fence.argtypes = [vp, vp]; lib.nww_gather_fence.restype = C.c_int
+    lib.nww_feature_clamp.argtypes = [vp]; lib.nww_feature_clamp.restype = C.c_float
     lib.nww_gather_overlap_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.nww_gather_overlap_ms.restype = C.c_int
     _lib = lib
     return lib

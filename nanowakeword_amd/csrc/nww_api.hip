@@ -241,6 +241,13 @@ extern "C" int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches
     return NWW_OK;
 }
 
+extern "C" float nww_feature_clamp(const nww_handle* h) {
+    if (!h || !h->finalized) return 0.0f;
+    bool any = false;                                          // a step marked [f16x3], or 16-bit activation storage
+    for (const auto& st : h->plan) any = any || st.name.find("[f16x3]") != std::string::npos;
+    return (any || h->cfg.act_dtype != 0) ? NWW_F16_FEATURE_BOUND : 0.0f;
+}
+
 extern "C" int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen) {
     if (!h || !buf || buflen <= 0) return NWW_ERR_INVALID;
     std::string s = h->d_fe3plan ? "frontend:fe_stft_mel_db_kernel [frontend3: matrix pipe]\n" : "frontend:fe_stft_mel_db_kernel\n";

@@ -187,6 +187,11 @@ class HipModel:
                                              logits.ctypes.data_as(C.c_void_p), probs.ctypes.data_as(C.c_void_p)))
         return logits, probs
 
+    @property
+    def feature_clamp(self) -> float:
+        """+-bound the plan assumes on (and clamps) the head's input features; 0.0 when nothing is clamped (nww_feature_clamp)"""
+        return float(self.lib.nww_feature_clamp(self._h))
+
     def forward_features(self, feats, return_embedding: bool = False):
         """float32 [B,T,F] -> (logits [B], probs [B][, embedding [B,E]])."""
         feats = np.ascontiguousarray(np.asarray(feats), dtype=np.float32)
@@ -195,6 +200,12 @@ class HipModel:
         if feats.ndim != 3 or tuple(feats.shape[1:]) != tuple(self.head.input_shape):
             raise ValueError(f"features must have shape (B, {self.head.input_shape[0]}, {self.head.input_shape[1]}), got {feats.shape}")
         B = feats.shape[0]
+        clamp = self.feature_clamp
+        if clamp > 0.0 and feats.size and float(np.abs(feats).max()) > clamp:
+            import warnings
+            warnings.warn(f"features reach {float(np.abs(feats).max()):.4g}: the default arithmetic (conv_arith='f16x3') clamps the head input to "
+                          f"+-{clamp:g} (log-mel dB never gets there; the reference does not clamp) - pass conv_arith='bf16x6' for unbounded features",
+                          RuntimeWarning, stacklevel=2)
         logits, probs = np.empty(B, np.float32), np.empty(B, np.float32)
         emb = np.empty((B, self.head.embedding_dim), np.float32) if return_embedding else None
         self._check(self.lib.nww_forward_features_ex(self._h, feats.ctypes.data_as(C.c_void_p), B,

@@ -540,3 +540,33 @@ assert worst <= 1e-4, worst
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "WORST" in r.stdout
+
+
+def test_feature_clamp_is_surfaced(hip):
+    """The default arithmetic clamps the head input to +-8192 (the reference does not): nww_feature_clamp says so, the host layer warns
+    when a feature array crosses it, and conv_arith = bf16x6 (no clamp) follows the oracle on the same outliers."""
+    import warnings
+    HipModel, _ = hip
+    cfg = HeadConfig("dnn", (16, 96))
+    sd = synth_state_dict(cfg)
+    feats = synth_features(6, cfg.input_shape, seed=3)
+    feats[2, 5, 7] = 3.0e4
+    feats[4, 0, 0] = -1.0e5
+    ref = oracle.model_forward(feats, sd, cfg).ravel()
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    assert m.feature_clamp == 8192.0
+    with pytest.warns(RuntimeWarning, match="clamps the head input"):
+        lg, _ = m.forward_features(feats)
+    ok = [0, 1, 3, 5]
+    assert np.abs(lg[ok] - ref[ok]).max() <= FEAT_LOGIT_ATOL          # clips inside the bound are untouched
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m.forward_features(feats[ok])                                  # no warning without outliers
+    m.close()
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, conv_arith="bf16x6")
+    assert m.feature_clamp == 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lg, _ = m.forward_features(feats)
+    assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(lg - ref)
+    m.close()

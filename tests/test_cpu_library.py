@@ -267,3 +267,15 @@ def test_matrix_pipe_frontend_on_cpu_vs_reference(emu, golden_frontend, variant)
         mel, db = emu.v3(g["pcm"], 40, 0, g["window"], g["fb40"])
         assert_frontend_close(mel, db, g["mel40"], g["db40"], variant)
         assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g["fb40"], center=False, dtype=np.float64), variant)
+
+
+def test_fused_epilogue_activations_restated():
+    """nww_gelu / nww_silu of csrc/layers.h, restated operation by operation in numpy float32 (tools/erf_check.py), against float64:
+    the direct x Phi(x) polynomial is as close to exact as the float32 form the reference evaluates, SiLU to a few ulp."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("erf_check", os.path.join(ROOT, "tools", "erf_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g, ref32 = mod.gelu_errors(200_001)
+    assert g <= 5e-7 and g <= 1.2 * ref32 + 1e-7, (g, ref32)
+    assert mod.silu_error(200_001) <= 2e-7

@@ -628,3 +628,57 @@ def test_lite_gate_cascade(tmp_path, golden_heads_r04):
         v_ref = float(oracle.sigmoid(oracle.model_forward(feats, sd_main, main))[0, 0])
         assert abs(r.gate_score - g_ref) <= 1e-5
         assert (r.score == 0.0 and it.raw_scores["kw"] == 0.0) if closed else abs(r.score - v_ref) <= 1e-5
+
+
+@pytest.mark.parametrize("head,B", [("cnn", 65536), ("bcresnet", 65536), ("conformer", 16384), ("dnn", 131072), ("dnn", 524288), ("cnn", 262144)])
+def test_global_batch_on_one_gpu(HipModel, head, B):
+    """Maximum sizes: BASELINE's GLOBAL batches (65 536 BcResNet / CNN clips, 16 384 Conformer clips - what eight GPUs share) and twice that for
+    the DNN head, on ONE GPU, then 4-8 x those (16.8 GB of PCM, 3.4e9 log-mel floats: element offsets beyond 2^31 and 2^32 in every plane).  The oracle cannot run these; the
+    property that can be checked everywhere is batch invariance: the batch is 256 distinct clips tiled, and EVERY clip's logit must be the
+    bits the same clip gets in a 256-clip call (which test_head_vs_oracle_and_golden ties to the oracle)."""
+    import torch
+    cfg = HeadConfig(head, (101, 64))
+    m = HipModel(cfg, FrontendConfig(), state_dict=synth_state_dict(cfg))
+    base = synth_pcm("speechlike", 256, 16000, seed=11)
+    base[7] = 0                                                # one silent clip (-100 dB floor rows)
+    want, _ = m.forward_pcm(base)
+    dev = torch.device("cuda", 0)
+    pcm = torch.from_numpy(base).to(dev).repeat(B // 256, 1).contiguous()
+    assert pcm.shape == (B, 16000)
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    m.reserve(B, 16000)
+    m.forward_pcm_dev(pcm.data_ptr(), B, 16000, out.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(B // 256, 256)
+    assert np.isfinite(got).all()
+    bad = np.argwhere(got != want[None, :])
+    assert bad.size == 0, (head, B, bad[:5], len(bad))
+    del pcm, out
+    torch.cuda.empty_cache()
+    m.close()
+
+
+@pytest.mark.parametrize("head", ["cnn", "crnn", "dnn"])
+def test_ten_second_clips(HipModel, golden_frontend, head):
+    """Long inputs: 10 s clips (160 000 samples -> 1001 frames; BASELINE config 4's stream length as ONE window) through the frontend
+    (criteria A / B against the oracle) and a head built for (1001, 64): many row strips in the fused trunk, K = 128 000 / 64 064 in the
+    first Linear, a 4 000-feature sequence step for the CRNN - against the oracle at 1e-4."""
+    from parity import assert_frontend_close
+    g = golden_frontend
+    cfg = HeadConfig(head, (1001, 64), **({"layer_dim": 64} if head == "dnn" else {}))
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd, window=g["window"], mel_fb=g["fb64"])
+    x = np.concatenate([synth_pcm("speechlike", 2, 160000, seed=5), synth_pcm("noise", 1, 160000, seed=6)])
+    x[1, 40000:90000] = 0                                     # three seconds of digital silence inside a clip
+    assert m.num_frames(160000) == 1001
+    db, mel = m.frontend(x, return_power=True)
+    mo = oracle.mel_power(x, g["window"], g["fb64"])
+    assert_frontend_close(mel, db, mo, oracle.logmel_db(mo), "10 s")
+    lg, _ = m.forward_pcm(x)
+    lm = oracle.logmel_db(mo).transpose(0, 2, 1)
+    ref = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
+    assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), (head, np.abs(lg - ref), ref)
+    l1, _ = m.forward_pcm(x[1:2])
+    assert np.array_equal(l1, lg[1:2])
+    m.close()

@@ -165,6 +165,12 @@ struct GruArgs {
     // computed in the same launch from its gate pre-activations xg2 [B][xg2_bstride] and recurrent bias -> last_out[:, col_off2 + j]
     const float* xg2 = nullptr; size_t xg2_bstride = 0; const float* b_hh2 = nullptr; int col_off2 = 0;
     int ldw = 0;           // > 0: w_hh is the zero-padded [gates H][ldw] copy of launch_rnn_pad_weights -> the any-width kernel (H <= 512)
+    // rnn_x3, GRU, products = 3 only: fin = 32 / 64 > 0 fuses the INPUT projection into the recurrence - xg is not read; the step's gate
+    // pre-activations x_t W_ih^T + b_ih come from x_in [B][T][fin] (clamped to +-x_clamp, times x_scale) and w_ih [3 H][fin] (times
+    // wi_scale) as two binary16 terms each, on the matrix pipe beside the recurrent product (the GRU head's 64 mel bins: no 635 MB
+    // round trip of gate pre-activations through HBM)
+    const float* x_in = nullptr; const float* w_ih = nullptr; const float* b_ih = nullptr;
+    int fin = 0; float x_scale = 1.0f, x_clamp = 0.0f, wi_scale = 1.0f;
 };
 size_t rnn_wide_weight_bytes(int gates, int H);
 hipError_t launch_rnn_pad_weights(const float* w_hh, float* out, int gates, int H, hipStream_t s);

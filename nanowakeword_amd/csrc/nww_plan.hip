@@ -501,6 +501,18 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
         // strided GEMM over M = B rows instead of B*T, into the row behind the forward direction's xg) - and with h = 0 that
         // step has no recurrent product: rnn_x3 computes it in the forward direction's launch.
         const bool fold = last && x3;
+        // GRU head, first layer fed by the head's own input features (<= 64 per frame), two-term arithmetic: the forward direction's input
+        // projection is computed inside the recurrence kernel - x_t W_ih^T on the matrix pipe beside h W_hh^T - instead of a GEMM that
+        // writes T x 3H gate pre-activations per clip to HBM for the recurrence to read back (635 MB each way at B = 4096, T = 101, H = 128).
+        // NWW_RNN_FUSE_IH = 0 keeps the separate projection.
+        static const int fuse_env = [] { const char* e = getenv("NWW_RNN_FUSE_IH"); return e ? atoi(e) : 1; }();
+        const float* wih_f = p.W(prefix + ".weight_ih_l" + std::to_string(l));
+        const float wi_scale = (fuse_env && fold && l == 0 && in_id == -1 && G == 3 && products == 3 && (cur_I == 32 || cur_I == 64) && (H == 32 || H == 64 || H == 128) &&
+                                wih_f && (reinterpret_cast<uintptr_t>(wih_f) & 15) == 0)
+                                   ? f16_wscale(f16_fetch(p.h, wih_f, (size_t)G * H * cur_I)) : 0.0f;
+        const float* whh_fwd = p.W(prefix + ".weight_hh_l" + std::to_string(l));
+        const bool fuse_ih = wi_scale > 0.0f && f16_scale(F16_FEATURES.bound) > 0.0f && (H % 4) == 0 && H <= 256 &&
+                             whh_fwd && f16_wscale(f16_fetch(p.h, whh_fwd, (size_t)G * H * H)) > 0.0f;      // ... and the recurrence itself takes the two-term form
         for (int dir = 0; dir < 2; ++dir) {
             const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
             const float* wih = p.W(prefix + ".weight_ih" + sfx);
@@ -518,6 +530,8 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                     g.res = nullptr; g.ldres = 0; g.rscale = 1.f;
                     return launch_gemm(g, r.stream);
                 });
+            } else if (fuse_ih && dir == 0) {
+                // (the forward direction's input projection runs inside its recurrence: GruArgs::fin)
             } else {
                 // short-K input projections (the GRU head's 64 mel bins) on the input-stationary kernel; the rest on the general GEMM
                 if (!add_lin_x3(p, prefix + ".ih" + sfx, cur_in, xg_id, T, G * H, cur_I, wih, bih, 0))
@@ -540,9 +554,16 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                                         : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
             const float w_scale = products == 3 ? f16_wscale(f16_fetch(p.h, whh_f, (size_t)G * H * H)) : 1.0f;
             const int products_l = (products == 3 && !(w_scale > 0.0f)) ? p.h->conv_products : products;
-            p.add(nm + (products_l == 3 && x3 && ldw == 0 ? " [f16x3]" : ""), [=](Run& r) {
+            const bool fused_here = fuse_ih && fold && products_l == 3 && ldw == 0;
+            const float* bih_f = p.W(prefix + ".bias_ih_l" + std::to_string(l));
+            const int fin = cur_I;
+            p.add(nm + (fused_here ? " + input projection" : "") + (products_l == 3 && x3 && ldw == 0 ? " [f16x3]" : ""), [=](Run& r) {
                 GruArgs a;
                 a.products = products_l; a.w_scale = w_scale;
+                if (fused_here) {
+                    a.x_in = r.x; a.w_ih = wih_f; a.b_ih = bih_f; a.fin = fin;
+                    a.x_scale = f16_scale(F16_FEATURES.bound); a.x_clamp = (float)F16_FEATURES.bound; a.wi_scale = wi_scale;
+                }
                 a.xg = r.buf[xg_id]; a.w_hh = whh_f; a.b_hh = bhh_f;
                 a.seq_out = last ? nullptr : r.buf[seq_out]; a.ld_seq = 2 * H;
                 a.last_out = last ? r.buf[last_id] : nullptr; a.ld_last = 2 * H;

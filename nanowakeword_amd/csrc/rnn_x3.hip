@@ -38,8 +38,11 @@ __device__ __forceinline__ float tanh_r(float v) { return 1.0f - 2.0f * __builti
 
 // G = 3: GRU (r, z, n), G = 4: LSTM (i, f, g, o); NP = 6 or 9 partial products per operand pair; NB = 16-wide column blocks per
 // wave (2 at H = 128: four waves, one per SIMD, so that each has the whole 512-register file - 288 of them weight fragments)
-template <int G, int H, int NP, int NB>
+// FIN = 32 / 64 (GRU, NP = 3): the input projection of the step fused in (GruArgs::fin); 0: xg precomputed
+template <int G, int H, int NP, int NB, int FIN = 0>
 __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a) {
+    static_assert(FIN == 0 || (G == 3 && NP == 3 && FIN % 32 == 0), "fused input projection: GRU, two-term form");
+    constexpr int KSI = FIN / 32;                             // k-blocks of the input product
     constexpr int KS = H / 32;                                // MFMA k-blocks
     constexpr int LDP = H + 8;                                // bf16 per LDS row: +16 bytes keeps the 16-byte fragment reads conflict-free
     constexpr bool H2 = NP == 3;
@@ -83,6 +86,30 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
             bh[q][bl] = a.b_hh[q * H + j0 + 16 * bl];
             __builtin_amdgcn_sched_barrier(0);                // one row at a time: all rows' raw loads in flight at once would not fit beside the fragments
         }
+    // fused input projection: W_ih rows q*H + j, k = 32 ks + 8 g .. + 7 -> B fragments (two binary16 terms of weight x wi_scale)
+    uint4 wi[G][NB][KSI > 0 ? KSI : 1][2];
+    float bi[G][NB];
+    const float unx = FIN ? 1.0f / (a.x_scale * a.wi_scale) : 0.0f;
+    if constexpr (FIN > 0) {
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int bl = 0; bl < NB; ++bl) {
+                const float* src = a.w_ih + (size_t)(q * H + j0 + 16 * bl) * FIN + 8 * g;
+#pragma unroll
+                for (int ks = 0; ks < KSI; ++ks) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(src + 32 * ks), v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
+                    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    uint32_t hh[4], ll[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nww_split2h(x[2 * e] * a.wi_scale, x[2 * e + 1] * a.wi_scale, hh[e], ll[e]);
+                    wi[q][bl][ks][0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                    wi[q][bl][ks][1] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                }
+                bi[q][bl] = a.b_ih[q * H + j0 + 16 * bl];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
     float hprev[NB][4], cprev[NB][4];
 #pragma unroll
     for (int bl = 0; bl < NB; ++bl)
@@ -93,22 +120,33 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     // input-side pre-activations (independent of h) are requested PF steps ahead: with the products on the bf16 pipe a step is
     // shorter than the trip of a row per clip from HBM
     constexpr int PF = (G == 4 && H == 128) ? 0 : 2;      // (the LSTM at H = 128 holds 384 registers of weight fragments: no room)
-    float xpf[PF + 1][G][NB][4];                              // [0]: this step's
-    auto fetch = [&](int step, float (&x)[G][NB][4]) {
+    float xpf[PF + 1][FIN ? 1 : G][FIN ? 1 : NB][4];           // [0]: this step's (precomputed xg form)
+    auto fetch = [&](int step, float (&x)[FIN ? 1 : G][FIN ? 1 : NB][4]) {
         const int t = a.reverse ? a.T - 1 - step : step;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + 4 * g + r;
             const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * G * H + j0;
 #pragma unroll
-            for (int q = 0; q < G; ++q)
+            for (int q = 0; q < (FIN ? 1 : G); ++q)
 #pragma unroll
-                for (int bl = 0; bl < NB; ++bl) x[q][bl][r] = xg[q * H + 16 * bl];
+                for (int bl = 0; bl < (FIN ? 1 : NB); ++bl) x[q][bl][r] = xg[q * H + 16 * bl];
+        }
+    };
+    // fused form: the lane's 8 features per k-block of clip n's row of the step (the A fragment of the input product), raw, PF steps ahead
+    float4 xraw[PF + 1][KSI > 0 ? KSI : 1][2];
+    auto fetch_x = [&](int step, float4 (&x)[KSI > 0 ? KSI : 1][2]) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        const float* row = a.x_in + ((size_t)min(b0 + n, a.B - 1) * a.T + t) * FIN + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KSI; ++ks) {
+            x[ks][0] = *reinterpret_cast<const float4*>(row + 32 * ks);
+            x[ks][1] = *reinterpret_cast<const float4*>(row + 32 * ks + 4);
         }
     };
 #pragma unroll
     for (int d = 0; d < PF; ++d)
-        if (d < a.steps) fetch(d, xpf[d]);
+        if (d < a.steps) { if constexpr (FIN > 0) fetch_x(d, xraw[d]); else fetch(d, xpf[d]); }
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
@@ -117,7 +155,34 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
         for (int q = 0; q < G; ++q)
 #pragma unroll
             for (int bl = 0; bl < NB; ++bl) acc[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (step + PF < a.steps) fetch(step + PF, xpf[PF]);
+        if (step + PF < a.steps) { if constexpr (FIN > 0) fetch_x(step + PF, xraw[PF]); else fetch(step + PF, xpf[PF]); }
+        // fused input projection of this step: independent of h - on the matrix pipe ahead of the recurrent product
+        f32x4 accx[G][NB];
+        if constexpr (FIN > 0) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int bl = 0; bl < NB; ++bl) accx[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float cl = a.x_clamp, sc = a.x_scale;
+#pragma unroll
+            for (int ks = 0; ks < KSI; ++ks) {
+                const float4 p0 = xraw[0][ks][0], p1 = xraw[0][ks][1];
+                const float xv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                uint32_t hh[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    nww_split2h(__builtin_amdgcn_fmed3f(xv[2 * e], -cl, cl) * sc, __builtin_amdgcn_fmed3f(xv[2 * e + 1], -cl, cl) * sc, hh[e], ll[e]);
+                const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3])), xl = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int bl = 0; bl < NB; ++bl) {
+                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, __builtin_bit_cast(f16x8, wi[q][bl][ks][0]), accx[q][bl], 0, 0, 0);
+                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8, wi[q][bl][ks][1]), accx[q][bl], 0, 0, 0);
+                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8, wi[q][bl][ks][0]), accx[q][bl], 0, 0, 0);
+                    }
+            }
+        }
         {                                                     // (first step: the planes hold zeros)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -150,14 +215,23 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 const int c = 4 * g + r, b = b0 + c;
                 // rows beyond B repeat the last clip (clamped xg row): straight-line gate arithmetic, only the stores are predicated
                 float hn, cn = 0.0f;
-                if (G == 3) {
+                if constexpr (G == 3) {
+                    // input-side pre-activations: precomputed rows, or the fused product back at the true scale plus b_ih
+                    float xq[3];
+                    if constexpr (FIN > 0) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) xq[q] = fmaf(accx[q][bl][r], unx, bi[q][bl]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) xq[q] = xpf[0][q][bl][r];
+                    }
                     // (two-term form: the accumulators come back to the true scale inside the fma that adds b_hh)
                     const float a0 = H2 ? fmaf(acc[0][bl][r], un, bh[0][bl]) : acc[0][bl][r] + bh[0][bl];
                     const float a1 = H2 ? fmaf(acc[1][bl][r], un, bh[1][bl]) : acc[1][bl][r] + bh[1][bl];
                     const float a2 = H2 ? fmaf(acc[2][bl][r], un, bh[2][bl]) : acc[2][bl][r] + bh[2][bl];
-                    const float rg = sigmoid_r(H2 ? xpf[0][0][bl][r] + a0 : xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
-                    const float zg = sigmoid_r(H2 ? xpf[0][1][bl][r] + a1 : xpf[0][1][bl][r] + acc[1][bl][r] + bh[1][bl]);
-                    const float ng = tanh_r(xpf[0][2][bl][r] + rg * a2);
+                    const float rg = sigmoid_r(H2 ? xq[0] + a0 : xq[0] + acc[0][bl][r] + bh[0][bl]);
+                    const float zg = sigmoid_r(H2 ? xq[1] + a1 : xq[1] + acc[1][bl][r] + bh[1][bl]);
+                    const float ng = tanh_r(xq[2] + rg * a2);
                     hn = (1.0f - zg) * ng + zg * hprev[bl][r];
                 } else {
                     const float ig = sigmoid_r(H2 ? xpf[0][0][bl][r] + fmaf(acc[0][bl][r], un, bh[0][bl]) : xpf[0][0][bl][r] + acc[0][bl][r] + bh[0][bl]);
@@ -202,14 +276,21 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 }
             }
         }
+        if constexpr (FIN > 0) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d)
+            for (int d = 0; d < PF; ++d)
 #pragma unroll
-            for (int q = 0; q < G; ++q)
+                for (int ks = 0; ks < KSI; ++ks) { xraw[d][ks][0] = xraw[d + 1][ks][0]; xraw[d][ks][1] = xraw[d + 1][ks][1]; }
+        } else {
 #pragma unroll
-                for (int bl = 0; bl < NB; ++bl)
+            for (int d = 0; d < PF; ++d)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xpf[d][q][bl][r] = xpf[d + 1][q][bl][r];
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int bl = 0; bl < NB; ++bl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xpf[d][q][bl][r] = xpf[d + 1][q][bl][r];
+        }
         __syncthreads();
     }
 }
@@ -232,6 +313,20 @@ hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
         case 32: RNN_GO(GV, 32) break;                                                                                \
         case 64: RNN_GO(GV, 64) break;                                                                                \
         default: RNN_GO(GV, 128) break;                                                                               \
+    }
+    if (gates == 3 && a.fin > 0) {                            // fused input projection (GRU, two-term form)
+        if (a.products != 3 || (a.fin != 32 && a.fin != 64) || !a.x_in || !a.w_ih || !a.b_ih || a.reverse) return hipErrorInvalidValue;
+#define RNN_FIN(HV, FV) hipLaunchKernelGGL((rnn_x3_kernel<3, HV, 3, (HV == 128 ? 2 : 1), FV>), grid, block, lds, s, a)
+        switch (a.H * 100 + a.fin) {
+            case 3232: RNN_FIN(32, 32); break;
+            case 3264: RNN_FIN(32, 64); break;
+            case 6432: RNN_FIN(64, 32); break;
+            case 6464: RNN_FIN(64, 64); break;
+            case 12832: RNN_FIN(128, 32); break;
+            default: RNN_FIN(128, 64); break;
+        }
+#undef RNN_FIN
+        return hipGetLastError();
     }
     if (gates == 3) { RNN_H(3) } else { RNN_H(4) }
 #undef RNN_H

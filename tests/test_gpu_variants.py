@@ -131,7 +131,9 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_CONV3_X3": "0"}, [_CRNN, _E2E], ["conv3x3_mfma"], ["conv3_x3"], False),      # float32-MFMA third conv stage
     ({"NWW_FFN_FUSED": "0"}, [_CONF], ["layernorm:", "linear1+swish"], ["ffn_x3"], False),   # feed-forward as LayerNorm + two GEMMs
     ({"NWW_MHA_MFMA": "0"}, [_CONF], ["mha_core"], ["mha_mfma", "mha_h2", "head-major"], False),  # one-lane-per-query attention core
-    ({"NWW_LIN_H2": "0"}, [_CONF, _GRU], ["lin_x3:"], ["lin_x3:input_proj [f16x3]", "ih_l0 [f16x3]"], False),   # short-K Linears on three bf16 terms under the default arithmetic
+    ({"NWW_LIN_H2": "0", "NWW_RNN_FUSE_IH": "0"}, [_CONF, _GRU], ["lin_x3:"], ["lin_x3:input_proj [f16x3]", "ih_l0 [f16x3]"], False),   # short-K Linears on three bf16 terms under the default arithmetic
+    ({"NWW_RNN_FUSE_IH": "0"}, [_GRU, dict(model_type="gru", input_shape=(101, 64))], ["lin_x3:model.gru.ih_l0"], ["+ input projection"], False),   # GRU head: input projection as its own launch
+    ({}, [_GRU, dict(model_type="gru", input_shape=(101, 64)), dict(model_type="gru", input_shape=(20, 32), layer_dim=32)], ["+ input projection [f16x3]"], ["lin_x3:model.gru.ih_l0 "], False),   # (default) ... fused into the recurrence
     ({"NWW_MHA_H2": "0"}, [_CONF], ["mha_mfma"], ["mha_h2"], False),                    # float32-MFMA attention core under the default arithmetic
     ({"TEST_CONV_ARITH": "bf16x6"}, [_CONF], ["mha_mfma", "ffn_x3"], ["[f16x3]"], False),   # Conformer on three bf16 terms
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM

@@ -49,6 +49,26 @@ SYMBOLS = [
 ]
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 under the system library's soname, and whichever
+    copy is loaded first serves every later user of that soname: loaded after this library, torch would run on the system runtime it was not
+    built against (seen: `RuntimeError: No HIP GPUs are available` from torch.cuda on a ROCm 7.2 image with a rocm7.0 wheel), while this library
+    runs on either.  So when a torch installation is present, its copy is loaded first - located without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library():
     """Load libnwwhip.so once. Raises ImportError (never falls back to a CPU path)."""
     global _lib
@@ -58,6 +78,7 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m nanowakeword_amd.build` "
             "(or __graft_entry__.build()). nanowakeword_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing ROCm runtime etc.

@@ -38,7 +38,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-template <bool H2> struct C3A { static constexpr int NT = H2 ? 2 : 3, PS3 = 64 * NT + 16, WT_BYTES = 9 * 2 * NT * 1024; };
+// C1 input channels (32; 64 in the two-term form only): TS bytes per term of a pixel, KB sixteen-channel k-blocks
+template <bool H2, int C1 = 32> struct C3A { static constexpr int NT = H2 ? 2 : 3, TS = 2 * C1, PS3 = TS * NT + 16, KB = C1 / 16, WT_BYTES = 9 * KB * NT * 1024; };
 constexpr int PS3_MAX = 208, WT_BYTES_MAX = 9 * 2 * 3 * 1024;
 // A3 row pitch.  A 16-lane group of a fragment read covers 2 rows x 8 pixels; with 208-byte pixels the 8 pixels of a row take the
 // 16-byte slots {0, 13, 10, 7, 4, 1, 14, 11} of the 256-byte bank row, so the second row must sit 8 slots (128 bytes mod 256) away to
@@ -47,8 +48,9 @@ constexpr int PS3_MAX = 208, WT_BYTES_MAX = 9 * 2 * 3 * 1024;
 // 32 bytes, SHORTENED: the tail of the right halo pixel then overlaps the head of the next row's left halo pixel, both zero for ever.
 // Planes that would no longer fit the CU's LDS with the padding keep the dense pitch.
 // (144-byte pixels of the two-term form take the slots {0, 9, 6, 15, 10, 3, 12, 5}: the same rule)
-static int conv3_row_pitch(int H, int W, int avg_ow, bool h2) {
-    const int PS3 = h2 ? C3A<true>::PS3 : C3A<false>::PS3, WT_BYTES = h2 ? C3A<true>::WT_BYTES : C3A<false>::WT_BYTES;
+// (272-byte pixels of the 64-channel two-term form take the slots {0 .. 7}: the same rule)
+static int conv3_row_pitch(int H, int W, int avg_ow, bool h2, int C1 = 32) {
+    const int NT = h2 ? 2 : 3, PS3 = 2 * C1 * NT + 16, WT_BYTES = 9 * (C1 / 16) * NT * 1024;
     const int dense = (W + 2) * PS3;
     static const int padded = [] { const char* e = getenv("NWW_CONV3_PITCH"); return e ? atoi(e) : 1; }();      // 0: dense rows (round 3), for A/B runs
     if (!padded) return dense;
@@ -67,16 +69,20 @@ __device__ __forceinline__ void split3c(float x, uint32_t& hi, uint32_t& mid, ui
     lo = __float_as_uint(r - __uint_as_float(mid));
 }
 
-template <int ACT, bool POOL, bool AVG, bool H2>
+// STRIP: planes of more than 512 pixels (a second stage at 50 x 32, the third stage of clips longer than ~1.3 s) go through LDS in strips of
+// a.strip_h (even) rows plus their halo rows; a work item is (clip, strip), the halo rows are staged like the others (zeros outside the plane)
+template <int ACT, bool POOL, bool AVG, bool H2, int C1 = 32, bool STRIP = false>
 __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
-    constexpr int NW = 8, NTHR = 512, C1 = 32;
-    constexpr int NT = C3A<H2>::NT, PS3 = C3A<H2>::PS3, WT_BYTES = C3A<H2>::WT_BYTES;
+    static_assert(!STRIP || (!AVG && C1 == 32), "strips: pooled or raw planes of the 32-channel instances");
+    constexpr int NW = 8, NTHR = 512;
+    constexpr int NT = C3A<H2, C1>::NT, PS3 = C3A<H2, C1>::PS3, WT_BYTES = C3A<H2, C1>::WT_BYTES, TS = C3A<H2, C1>::TS, KB = C3A<H2, C1>::KB;
     const float s_in = H2 ? a.h2_in : 1.0f, s_w = H2 ? a.h2_w : 1.0f, c_out = H2 ? 1.0f / (a.h2_in * a.h2_w) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     const int H = a.H, W = a.W, Wp = W + 2;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
     const int rowB = a.row_pitch;
-    const int a3_bytes = (H + 3) * rowB + 32;                   // (+ 32: the last row's right halo pixel when the pitch is shortened)
+    const int SH = STRIP ? a.strip_h : H, nS = STRIP ? (H + SH - 1) / SH : 1;      // rows per strip, strips per plane
+    const int a3_bytes = (SH + 3) * rowB + 32;                   // (+ 32: the last row's right halo pixel when the pitch is shortened)
     unsigned char* A3 = lds3;
     unsigned char* Wt = lds3 + ((a3_bytes + 15) & ~15);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,9 +93,9 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     for (int k = tid; k < a3_bytes / 4; k += NTHR) reinterpret_cast<uint32_t*>(A3)[k] = 0u;
     for (int idx = tid; idx < 32 * C1 * 9; idx += NTHR) {      // (cout, cin, tap)
         const int co = idx / (C1 * 9), r = idx - co * (C1 * 9), ci = r / 9, tap = r - ci * 9;
-        const float wv = a.w[((size_t)(32 * grp + co) * C1 + ci) * 9 + tap];
+        const float wv = a.w[((size_t)(32 * grp + co) * a.w_cin + a.w_cin_off + ci) * 9 + tap];
         const int kb = ci >> 4, kh = (ci >> 3) & 1, e = ci & 7;
-        unsigned char* d = Wt + ((tap * 2 + kb) * NT) * 1024 + (kh * 32 + co) * 16 + e * 2;
+        unsigned char* d = Wt + ((tap * KB + kb) * NT) * 1024 + (kh * 32 + co) * 16 + e * 2;
         if (H2) {
             uint32_t th, tl;
             nww_split2h(wv * s_w, 0.0f, th, tl);
@@ -166,8 +172,8 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             }
     };
 
-    // conv for tile t (and t + 1 when TWO): 9 taps x 2 sixteen-channel blocks x 6 products
-    auto tiles = [&](int u, auto two_c, float* outb, float* wsum, AvgWin aw) {
+    // conv for tile t (and t + 1 when TWO): 9 taps x KB sixteen-channel blocks x 6 (3) products
+    auto tiles = [&](int u, auto two_c, float* outb, float* wsum, AvgWin aw, const float* accb, int y0) {
         constexpr bool TWO = decltype(two_c)::value;
         const int t = tile_of(u);
         const int R0 = t / nX, X0 = t - R0 * nX;
@@ -178,14 +184,25 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        if (accb) {                                            // (wave-uniform) k-split pass: start from the sums over the earlier input channels
+            auto load_acc = [&](f32x16& acc, int R, int X) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int y = y0 + 2 * R + ((r >> 1) & 1), x = 16 * X + 4 * (r >> 2) + 2 * hi + (r & 1);
+                    acc[r] = (y < H && x < W) ? accb[(size_t)i * H * W + y * W + x] : 0.0f;
+                }
+            };
+            load_acc(acc0, R0, X0);
+            if (TWO) load_acc(acc1, R1, X1);
+        }
         bf16x8 na[NT], nb[NT], nw[NT];
-        auto fetch = [&](int step) {                           // step = tap * 2 + k-block
-            const int tap = step >> 1, kb = step & 1;
+        auto fetch = [&](int step) {                           // step = tap * KB + k-block
+            const int tap = step / KB, kb = step % KB;
             const int off = (tap / 3) * rowB + (tap % 3) * PS3 + 32 * kb;
 #pragma unroll
             for (int tm = 0; tm < NT; ++tm) {
-                na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + 64 * tm);
-                if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + off + 64 * tm);
+                na[tm] = *reinterpret_cast<const bf16x8*>(pa + off + TS * tm);
+                if (TWO) nb[tm] = *reinterpret_cast<const bf16x8*>(pb + off + TS * tm);
                 nw[tm] = *reinterpret_cast<const bf16x8*>(wlane + (step * NT + tm) * 1024);
             }
         };
@@ -208,11 +225,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         };
         fetch(0);
 #pragma unroll
-        for (int step = 0; step < 18; ++step) {
+        for (int step = 0; step < 9 * KB; ++step) {
             bf16x8 ca[NT], cb[NT], cw[NT];
 #pragma unroll
             for (int tm = 0; tm < NT; ++tm) { ca[tm] = na[tm]; if (TWO) cb[tm] = nb[tm]; cw[tm] = nw[tm]; }
-            if (step + 1 < 18) fetch(step + 1);
+            if (step + 1 < 9 * KB) fetch(step + 1);
             __builtin_amdgcn_sched_barrier(0);                 // next step's LDS reads stay above this step's MFMAs
             products(ca, cw, acc0);
             if (TWO) products(cb, cw, acc1);
@@ -226,30 +243,41 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             avg_epilogue(acc0, R0, X0, wsum, aw);
             if (TWO) avg_epilogue(acc1, R1, X1, wsum, aw);
         } else {
-            conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw, seq_ch);
-            if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias, al, be, bn, outb, i, hi, Ho, Wo, 0, wsum, aw, seq_ch);
+            conv_tile_epilogue<ACT, POOL, AVG>(acc0, R0, X0, bias, al, be, bn, outb, i, hi, Ho, Wo, y0 / 2, wsum, aw, seq_ch);
+            if (TWO) conv_tile_epilogue<ACT, POOL, AVG>(acc1, R1, X1, bias, al, be, bn, outb, i, hi, Ho, Wo, y0 / 2, wsum, aw, seq_ch);
         }
     };
 
-    // Staging: thread p < H*W owns pixel p.  Its 32 channel values (32 coalesced plane reads) are fetched into registers
-    // one clip AHEAD - the loads are in flight under the MFMA loop - then split and written channels-last as twelve
-    // 16-byte LDS stores.  (conv3_x3_fits guarantees H*W <= 512.)
+    // Staging: thread p < H*W owns pixel p (C1 > 32: thread p + q H*W owns the q-th 32-channel chunk of pixel p).  Its 32 channel
+    // values (32 coalesced plane reads) are fetched into registers one clip AHEAD - the loads are in flight under the MFMA loop -
+    // then split and written channels-last as twelve 16-byte LDS stores.  (conv3_x3_fits guarantees H*W * C1/32 <= 512.)
+    // (STRIP: thread p < (SH + 3) * W owns pixel p of the strip's rows y0 - 1 .. y0 + SH + 1 - A3 row = strip row, zeros outside the plane)
     const int b_first = (int)blockIdx.x / ngroups, b_step = (int)gridDim.x / ngroups;
     const int HW = H * W;
-    const bool stager = tid < HW;
-    const int py = stager ? tid / W : 0, px = stager ? tid - py * W : 0;
-    unsigned char* my_px = A3 + (py + 1) * rowB + (px + 1) * PS3;
-    float pre[C1];
+    const bool stager = STRIP ? tid < (SH + 3) * W : tid < HW * (C1 / 32);
+    const int chunk = (C1 > 32 && stager) ? tid / HW : 0, pix = tid - chunk * HW;
+    const int py = stager ? pix / W : 0, px = stager ? pix - py * W : 0;
+    unsigned char* my_px = A3 + (STRIP ? py : py + 1) * rowB + (px + 1) * PS3 + 64 * chunk;
+    float pre[32];
     // dense planes [B][32][H][W], or (streaming hop) per-clip rings of rows written by the fused trunk: row py of the window at
     // ring row (in_row0 + py) % in_ring_rows
-    const size_t in_clip = a.in_ring_rows ? a.in_clip_stride : (size_t)C1 * HW;
+    const size_t in_clip = a.in_ring_rows ? a.in_clip_stride : (size_t)a.w_cin * HW;
     const size_t in_ch = a.in_ring_rows ? a.in_ch_stride : (size_t)HW;
-    const int in_px = a.in_ring_rows ? ((a.in_row0 + py) % a.in_ring_rows) * W + px : tid;
-    auto prefetch = [&](int b) {
-        if (stager && b < a.B) {
-            const float* xin = a.in + (size_t)b * in_clip + in_px;
+    const int in_px = a.in_ring_rows ? ((a.in_row0 + py) % a.in_ring_rows) * W + px : pix;
+    const int n_items = a.B * nS;                               // work items: clips (STRIP: clip-major (clip, strip) pairs)
+    auto prefetch = [&](int item) {
+        if (stager && item < n_items) {
+            if (STRIP) {
+                const int b = item / nS, y = (item - b * nS) * SH - 1 + py;
+                const bool in_plane = (unsigned)y < (unsigned)H;
+                const float* xin = a.in + (size_t)b * in_clip + (size_t)a.w_cin_off * in_ch + (in_plane ? y * W + px : 0);
 #pragma unroll
-            for (int c = 0; c < C1; ++c) pre[c] = xin[(size_t)c * in_ch];
+                for (int c = 0; c < 32; ++c) pre[c] = in_plane ? xin[(size_t)c * in_ch] : 0.0f;
+                return;
+            }
+            const float* xin = a.in + (size_t)item * in_clip + (size_t)(a.w_cin_off + 32 * chunk) * in_ch + in_px;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) pre[c] = xin[(size_t)c * in_ch];
         }
     };
     // per-lane avg-pool partials live in the 16 pad bytes of pixels 0..511 (never read by the MFMAs, never written by
@@ -258,12 +286,20 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     // (the right halo column is left out: with a shortened pitch its pad overlaps the next row's left halo pixel)
     const int npix = (H + 3) * (Wp - 1);
     auto part_ptr = [&](int t) {
-        return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + 64 * NT : Wt + WT_BYTES + (size_t)(t - npix) * 16);
+        return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + TS * NT : Wt + WT_BYTES + (size_t)(t - npix) * 16);
     };
     float* my_part = part_ptr(tid);
     prefetch(b_first);
     __syncthreads();
-    for (int b = b_first; b < a.B; b += b_step) {
+    for (int item = b_first; item < n_items; item += b_step) {
+        const int b = STRIP ? item / nS : item;
+        const int y0 = STRIP ? (item - b * nS) * SH : 0;       // first plane row of the strip
+        int tb = t_begin, te = t_end;
+        if (STRIP) {                                           // the last strip may be shorter: the wave's share of this strip's tiles
+            const int hs = min(SH, H - y0), nTi = (POOL ? hs / 2 : (hs + 1) / 2) * nX;
+            const int base = nTi / NW, rem = nTi - base * NW;
+            tb = wave * base + min(wave, rem); te = tb + base + (wave < rem ? 1 : 0);
+        }
         if (stager) {
 #pragma unroll
             for (int c8 = 0; c8 < 4; ++c8) {
@@ -272,7 +308,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) nww_split2h(pre[8 * c8 + 2 * e] * s_in, pre[8 * c8 + 2 * e + 1] * s_in, th[e], tl[e]);
                     *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
-                    *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+                    *reinterpret_cast<uint4*>(my_px + TS + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
                 } else {
                     uint32_t th[4], tm[4], tl[4];
 #pragma unroll
@@ -285,21 +321,22 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
                         tl[e] = (l0 >> 16) | (l1 & 0xffff0000u);
                     }
                     *reinterpret_cast<uint4*>(my_px + 16 * c8) = make_uint4(th[0], th[1], th[2], th[3]);
-                    *reinterpret_cast<uint4*>(my_px + 64 + 16 * c8) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
-                    *reinterpret_cast<uint4*>(my_px + 2 * 64 + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+                    *reinterpret_cast<uint4*>(my_px + TS + 16 * c8) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
+                    *reinterpret_cast<uint4*>(my_px + 2 * TS + 16 * c8) = make_uint4(tl[0], tl[1], tl[2], tl[3]);
                 }
             }
         }
         __syncthreads();
-        prefetch(b + b_step);
+        prefetch(item + b_step);
         // planes [Cout][Ho][Wo], or (seq_out, pooled mode) the clip's sequence rows [Wo][Cout * Ho] at channel 32 grp
         float* outb = seq_ch ? a.out + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho
                              : a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
         float wsum[4] = {0.f, 0.f, 0.f, 0.f};
         const AvgWin aw{a.avg_kw, a.avg_sw, a.avg_ow, a.avg_y};
-        int t = t_begin;
-        for (; t + 1 < t_end; t += 2) tiles(t, std::true_type{}, outb, wsum, aw);
-        if (t < t_end) tiles(t, std::false_type{}, outb, wsum, aw);
+        const float* accb = a.acc_in ? a.acc_in + ((size_t)b * a.Cout + 32 * grp) * HW : nullptr;
+        int t = tb;
+        for (; t + 1 < te; t += 2) tiles(t, std::true_type{}, outb, wsum, aw, accb, y0);
+        if (t < te) tiles(t, std::false_type{}, outb, wsum, aw, accb, y0);
         if (carry) {                                           // kept rows: the previous hop's values, keep_shift rows further down
             const float* prev = a.seq_prev + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho;
             for (int idx = tid; idx < Wo * 32 * n_keep; idx += NTHR) {
@@ -326,11 +363,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
 }
 }  // namespace
 
-static size_t conv3_x3_a3_bytes(int H, int W, int avg_ow, bool h2) { return ((size_t)(H + 3) * conv3_row_pitch(H, W, avg_ow, h2) + 32 + 15) & ~(size_t)15; }
+static size_t conv3_x3_a3_bytes(int H, int W, int avg_ow, bool h2, int C1 = 32) { return ((size_t)(H + 3) * conv3_row_pitch(H, W, avg_ow, h2, C1) + 32 + 15) & ~(size_t)15; }
 
-static size_t conv3_x3_lds(int H, int W, int avg_ow, bool h2) {
+static size_t conv3_x3_lds(int H, int W, int avg_ow, bool h2, int C1 = 32) {
     const int npix = (H + 3) * (W + 1);                        // the avg-pool partials live in the pixels' pads; the rest behind the weights
-    return conv3_x3_a3_bytes(H, W, avg_ow, h2) + (h2 ? C3A<true>::WT_BYTES : C3A<false>::WT_BYTES) + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
+    return conv3_x3_a3_bytes(H, W, avg_ow, h2, C1) + (size_t)9 * (C1 / 16) * (h2 ? 2 : 3) * 1024 + ((avg_ow <= 0 || npix >= 512) ? 0 : (size_t)(512 - npix) * 16);
 }
 size_t conv3_x3_lds_bytes(int H, int W, int avg_ow) { return conv3_x3_lds(H, W, avg_ow, false); }
 
@@ -341,14 +378,41 @@ bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool) {
     return conv3_x3_lds_bytes(H, W, avg_ow) <= 160 * 1024;
 }
 
+// planes of more than 512 pixels: rows per strip - the largest even count whose (rows + 3) x W pixels have a stager thread each and whose LDS
+// plane fits beside the weights (three-term footprint, like conv3_x3_fits); 0: no such count
+int conv3_x3_strip_rows(int H, int W, int Cout) {
+    if (Cout % 32 != 0 || H < 2 || W < 2 || W > 102) return 0;
+    for (int sh = (512 / W - 3) & ~1; sh >= 2; sh -= 2)
+        if (conv3_x3_lds(sh, W, 0, false) <= 160 * 1024) return sh;
+    return 0;
+}
+size_t conv3_x3_strip_lds_bytes(int sh, int W) { return conv3_x3_lds(sh, W, 0, false); }
+
+// deeper stages of a CRNN conv stack (crnn_cnn_channels beyond the default three: architectures.py:217-225): 64 input channels, pooled
+// planes, two-term form only - the three-term weights of one 32-channel output group alone would take 110 KB of LDS (and 128 input
+// channels 147 KB in the two-term form: those stay on the general kernel)
+bool conv3_x3_wide_fits(int Cin, int H, int W, int Cout) {
+    if (Cin != 64 || Cout % 32 != 0 || H < 2 || W < 2 || H * W * (Cin / 32) > 512) return false;
+    return conv3_x3_lds(H, W, 0, true, Cin) <= 160 * 1024;
+}
+size_t conv3_x3_wide_lds_bytes(int Cin, int H, int W) { return conv3_x3_lds(H, W, 0, true, Cin); }
+
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
-    if (!conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
     const bool h2 = a.h2_in > 0.0f;
-    const size_t lds = conv3_x3_lds(a.H, a.W, a.avg_ow, h2);
+    const bool wide = a.Cin != 32;
+    if (a.w_cin < 32 || a.w_cin % 32 != 0 || a.w_cin_off % 32 != 0 || a.w_cin_off + a.Cin > a.w_cin) return hipErrorInvalidValue;
+    if ((a.w_cin != a.Cin || a.acc_in) && (h2 || a.in_ring_rows)) return hipErrorInvalidValue;     // k-split passes: three-term form, dense planes
+    const int sh = a.strip_h;
+    if (sh) {
+        if (wide || a.avg_ow > 0 || a.in_ring_rows || a.seq_prev || sh < 2 || (sh & 1) || (sh + 3) * a.W > 512 || a.Cout % 32 != 0 ||
+            conv3_x3_lds(sh, a.W, 0, h2) > 160 * 1024) return hipErrorInvalidValue;
+    } else if (wide ? !(h2 && a.pool && a.avg_ow == 0 && a.in_ring_rows == 0 && conv3_x3_wide_fits(a.Cin, a.H, a.W, a.Cout))
+                    : !conv3_x3_fits(a.H, a.W, a.Cout, a.avg_ow, a.pool)) return hipErrorInvalidValue;
+    const size_t lds = conv3_x3_lds(sh ? sh : a.H, a.W, a.avg_ow, h2, a.Cin);
     ConvMfmaArgs aa = a;
-    aa.row_pitch = conv3_row_pitch(a.H, a.W, a.avg_ow, h2);
+    aa.row_pitch = conv3_row_pitch(sh ? sh : a.H, a.W, a.avg_ow, h2, a.Cin);
     const int ngroups = a.Cout / 32;
-    long want = (long)a.B * ngroups;
+    long want = (long)a.B * ngroups * (sh ? (a.H + sh - 1) / sh : 1);
     int grid = (int)(want < max_grid ? want : max_grid);
     grid -= grid % ngroups;
     if (grid < ngroups) grid = ngroups;
@@ -360,15 +424,35 @@ hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s) {
     }
 #define C3_LAUNCH(ACTV, POOLV, AVGV)                                                                               \
     if (h2) C3_LAUNCH1(ACTV, POOLV, AVGV, true) else C3_LAUNCH1(ACTV, POOLV, AVGV, false)
+#define C3_WIDE(ACTV, C1V)                                                                                                   \
+    {                                                                                                                        \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, true, false, true, C1V>), lds);      \
+        if (e != hipSuccess) return e;                                                                                       \
+        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, true, false, true, C1V>), dim3(grid), dim3(512), lds, s, aa);               \
+    }
+#define C3_STRIP(ACTV, POOLV, H2V)                                                                                           \
+    {                                                                                                                        \
+        hipError_t e = nww_allow_lds(reinterpret_cast<const void*>(conv3_x3_kernel<ACTV, POOLV, false, H2V, 32, true>), lds); \
+        if (e != hipSuccess) return e;                                                                                       \
+        hipLaunchKernelGGL((conv3_x3_kernel<ACTV, POOLV, false, H2V, 32, true>), dim3(grid), dim3(512), lds, s, aa);          \
+    }
 #define C3_ACT(ACTV)                                                                                               \
-    if (a.avg_ow > 0) C3_LAUNCH(ACTV, false, true) else if (a.pool) C3_LAUNCH(ACTV, true, false) else C3_LAUNCH(ACTV, false, false)
+    if (a.Cin == 64) C3_WIDE(ACTV, 64)                                                                             \
+    else if (sh) { if (!a.pool) return hipErrorInvalidValue; if (h2) C3_STRIP(ACTV, true, true) else C3_STRIP(ACTV, true, false) } \
+    else if (a.avg_ow > 0) C3_LAUNCH(ACTV, false, true) else if (a.pool) C3_LAUNCH(ACTV, true, false) else C3_LAUNCH(ACTV, false, false)
     switch (a.act) {
         case ACT_RELU: C3_ACT(ACT_RELU) break;
         case ACT_GELU: C3_ACT(ACT_GELU) break;
         case ACT_SILU: C3_ACT(ACT_SILU) break;
+        case ACT_NONE:                                         // k-split pass: raw sums, un-pooled planes (no bias, no BN)
+            if (h2 || wide || a.pool || a.avg_ow > 0 || a.bias || a.alpha || a.seq_out) return hipErrorInvalidValue;
+            if (sh) C3_STRIP(ACT_NONE, false, false) else C3_LAUNCH1(ACT_NONE, false, false, false)
+            break;
         default: return hipErrorInvalidValue;
     }
 #undef C3_ACT
+#undef C3_WIDE
+#undef C3_STRIP
 #undef C3_LAUNCH
 #undef C3_LAUNCH1
     return hipGetLastError();

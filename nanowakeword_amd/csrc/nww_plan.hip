@@ -192,9 +192,15 @@ double f16_layer_bound(const std::vector<float>& w, int Cout, int K, const std::
 // sit at >= 2^-1 after scaling, one bit above where `lo` starts to lose bits), and otherwise stays on
 // the three-term bf16 form (which has float32's range and needs no bound).  typ: the head's features ~ 32 (dB values), a layer's
 // output ~ sqrt(sum_k w^2) typ_in (uncorrelated terms; |folded-BN alpha| applied) - order-of-magnitude, which is all the guard needs.
+// how far above the typical magnitude a worst-case bound may lie: 2^16 leaves typical values 22+ significant bits in two binary16 terms.
+// NWW_F16_RANGE_LOG2 (A/B and test knob): a larger exponent lets deeper stages take the two-term kernels at reduced precision of small values
+inline double f16_range_factor() {
+    static const double f = [] { const char* e = getenv("NWW_F16_RANGE_LOG2"); return std::ldexp(1.0, e ? atoi(e) : 16); }();
+    return f;
+}
 struct F16Range {
     double bound = 0.0, typ = 0.0;
-    bool ok() const { return bound > 0.0 && typ > 0.0 && bound <= typ * 65536.0; }
+    bool ok() const { return bound > 0.0 && typ > 0.0 && bound <= typ * f16_range_factor(); }
 };
 const F16Range F16_FEATURES{NWW_F16_FEATURE_BOUND, 32.0};
 double f16_layer_typ(const std::vector<float>& w, int Cout, int K, const std::vector<float>& al, bool has_bn, double typ_in) {
@@ -408,21 +414,63 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
 bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, int Cin, int Cout, int H, int W,
                    const float* w, const float* bias, const float* alpha, const float* beta, int act, int pool,
                    int avg_kw = 0, int avg_sw = 0, int avg_ow = 0, bool* seq_inout = nullptr, int avg_y = 0, bool* ring_in = nullptr,
-                   F16Range in_range = F16Range{}, F16Range* out_range = nullptr) {
+                   F16Range in_range = F16Range{}, F16Range* out_range = nullptr, int scratch_id = -1) {
     if (out_range) *out_range = F16Range{};
     const double in_bound = in_range.ok() ? in_range.bound : 0.0;
     static const int enabled = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
-    if (!enabled || Cin != 32 || Cout % 32 != 0 || (8 % (Cout / 32)) != 0 || H < 2 || W < 2 ||
-        conv_mfma_lds_bytes(Cin, H, W) > 160 * 1024)
+    static const int x3_enabled = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
+    // 64 input channels (a fourth CRNN stage): conv3_x3's wide instance - two-term arithmetic on a bounded input only
+    bool wide = Cin == 64 && enabled && x3_enabled && pool && avg_ow == 0 && !avg_y && p.h->conv_products == 6 && p.h->f16 && in_bound > 0.0 &&
+                Cout % 32 == 0 && conv3_x3_wide_fits(Cin, H, W, Cout);
+    if (wide) {
+        const auto hw = f16_fetch(p.h, w, (size_t)Cout * Cin * 9);
+        if (f16_scale(in_bound) <= 0.0f || f16_wscale(hw) <= 0.0f) wide = false;
+    }
+    // more than 32 input channels without a usable bound (the worst-case bound of a fourth stage is usually too loose for two terms): the
+    // 32-channel three-term instance once per 32 input channels - every pass but the last leaves raw, un-pooled sums in a scratch buffer, the
+    // next one starts its accumulators from them (k-split; the planes of such stages are a few hundred pixels)
+    static const int ksplit_on = [] { const char* e = getenv("NWW_CONV3_KSPLIT"); return e ? atoi(e) : 1; }();
+    if (!wide && Cin > 32) {
+        if (!ksplit_on || !enabled || !x3_enabled || Cin % 32 != 0 || Cin > 256 || !pool || avg_ow > 0 || avg_y || p.h->conv_products != 6 || scratch_id < 0 ||
+            Cout % 32 != 0) return false;
+        const bool whole = conv3_x3_fits(H, W, Cout, 0, 1) && conv3_x3_fits(H, W, Cout, 0, 0);
+        const int sh = whole ? 0 : conv3_x3_strip_rows(H, W, Cout);          // larger planes: in strips of rows
+        if (!whole && sh == 0) return false;
+        if (ring_in) *ring_in = false;
+        p.need(out_id, (size_t)Cout * (H / 2) * (W / 2));
+        p.need(scratch_id, (size_t)Cout * H * W);
+        const int np = Cin / 32, grid = p.h->cu_count * ((sh ? conv3_x3_strip_lds_bytes(sh, W) : conv3_x3_lds_bytes(H, W, 0)) * 2 <= 160 * 1024 ? 2 : 1);
+        const int seq_out = (seq_inout && *seq_inout) ? 1 : 0;
+        for (int pass = 0; pass < np; ++pass) {
+            const bool fin = pass == np - 1;
+            p.add(std::string(fin && seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name + " (input channels " + std::to_string(32 * pass) + "-" + std::to_string(32 * pass + 31) +
+                      (fin ? ", epilogue)" : ", raw sums)"), [=](Run& r) {
+                ConvMfmaArgs a{src(r, in_id), w, fin ? bias : nullptr, fin ? alpha : nullptr, fin ? beta : nullptr, fin ? dst(r, out_id) : r.buf[scratch_id],
+                               r.B, H, W, Cout, fin ? act : (int)ACT_NONE, fin ? 1 : 0};
+                a.w_cin = Cin; a.w_cin_off = 32 * pass; a.acc_in = pass ? r.buf[scratch_id] : nullptr; a.seq_out = fin ? seq_out : 0; a.strip_h = sh;
+                return launch_conv3_x3(a, grid, r.stream);
+            });
+        }
+        return true;
+    }
+    if (wide) {
+        if (ring_in) *ring_in = false;
+    } else if (!enabled || Cin != 32 || Cout % 32 != 0 || H < 2 || W < 2)
         return false;
+    // (the float32-MFMA instance shares its 8 waves among the 32-channel groups; conv3_x3 takes one group per workgroup)
+    const bool f32_fits = !wide && (8 % (Cout / 32)) == 0 && conv_mfma_lds_bytes(Cin, H, W) <= 160 * 1024;
+    // pooled planes of more than 512 pixels (clips longer than ~1.3 s, a second stage behind an unfused first one): conv3_x3 in strips of rows
+    const int strip_h = (!wide && pool && avg_ow == 0 && !avg_y && !conv3_x3_fits(H, W, Cout, avg_ow, pool)) ? conv3_x3_strip_rows(H, W, Cout) : 0;
+    const bool x3_shape = strip_h > 0 || conv3_x3_fits(H, W, Cout, avg_ow, pool);
+    if (!wide && !f32_fits && !(x3_enabled && p.h->conv_products == 6 && x3_shape)) return false;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
     p.need(out_id, avg_ow > 0 ? (size_t)Cout * avg_ow : (size_t)Cout * Ho * Wo);
     const int max_grid = p.h->cu_count;
     // split-operand bf16 instance (conv3_x3.hip) under the same arithmetic switch as the fused trunk; the 9-product
     // mode keeps the float32-MFMA kernel (the conv3 instance implements the 6-product form only)
-    static const int x3_enabled = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
-    if (x3_enabled && p.h->conv_products == 6 && conv3_x3_fits(H, W, Cout, avg_ow, pool)) {
-        const size_t lds = conv3_x3_lds_bytes(H, W, avg_ow);
+    if (wide || (x3_enabled && p.h->conv_products == 6 && x3_shape)) {
+        const size_t lds = wide ? conv3_x3_wide_lds_bytes(Cin, H, W) : strip_h ? conv3_x3_strip_lds_bytes(strip_h, W) : conv3_x3_lds_bytes(H, W, avg_ow);
+        if (strip_h && ring_in) *ring_in = false;                                             // strips read dense planes
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
         const int seq_out = (seq_inout && *seq_inout && pool && avg_ow == 0) ? 1 : 0;      // the caller wants the sequence layout
         const bool ring_ok = ring_in && *ring_in;                                             // ... and may hand the input over in rings
@@ -438,8 +486,9 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
             }
         }
         const bool h2 = h2_in > 0.0f && h2_w > 0.0f;
-        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name + (h2 ? " [f16x3]" : ""), [=](Run& r) {
+        p.add(std::string(avg_ow > 0 ? "conv3_x3+avgpool:" : seq_out ? "conv3_x3+seq:" : "conv3_x3:") + name + (strip_h ? " (strips of " + std::to_string(strip_h) + " rows)" : "") + (h2 ? " [f16x3]" : ""), [=](Run& r) {
             ConvMfmaArgs a{src(r, in_id), w, bias, alpha, beta, dst(r, out_id), r.B, H, W, Cout, act, pool};
+            a.Cin = Cin; a.w_cin = Cin; a.strip_h = strip_h;
             a.avg_kw = avg_kw; a.avg_sw = avg_sw; a.avg_ow = avg_ow; a.seq_out = seq_out; a.avg_y = avg_y;
             if (h2) { a.h2_in = h2_in; a.h2_w = h2_w; }
             if (ring_ok && r.stream_mode) {             // streaming hop: the fused trunk's pooled rows are read from their rings
@@ -491,7 +540,11 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
     const int products = (p.h->f16 && rnn_h2) ? 3 : p.h->conv_products;
     GruArgs probe; probe.H = H; probe.products = products;
     probe.w_hh = p.W(prefix + ".weight_hh_l" + std::to_string(layers - 1));       // the pointer the fused launch will really get (alignment test)
-    const bool x3 = probe.w_hh != nullptr && rnn_x3_enabled(probe);
+    bool x3 = probe.w_hh != nullptr && rnn_x3_enabled(probe);
+    if (x3 && H != 32 && H != 64 && H != 128) {              // zero-padded instance (rnn_x3.hip): two-term form only, so the last layer's W_hh must scale
+        const float* wl = probe.w_hh;
+        if (!(f16_wscale(f16_fetch(p.h, wl, (size_t)G * H * H)) > 0.0f)) x3 = false;
+    }
     int cur_in = in_id, cur_I = I;
     for (int l = 0; l < layers; ++l) {
         const bool last = l == layers - 1;
@@ -851,7 +904,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 // the stage right behind a fused split-operand trunk may take its input from the streaming rings (nww_stream.hip)
                 bool ring = i == 2 && first == 2 && h->plan.size() == steps_before + 1 && h->plan.back().name.rfind("trunk_x3:", 0) == 0 && ((F / 4) % 4) == 0;
                 F16Range nb;
-                const bool mf = add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring, cbound, &nb);
+                const bool mf = add_conv_mfma(p, cw, cur, out, cin, c.crnn_channels[i], hh, ww, p.W(cw + ".weight"), p.W(cw + ".bias"), p.W(bnp + ".alpha"), p.W(bnp + ".beta"), act, 1, 0, 0, 0, &seq, 0, &ring, cbound, &nb, 2);      // (scratch: the recurrent layers' xg buffer, idle until they run)
                 cbound = nb;
                 if (!mf) {
                     ring = false;

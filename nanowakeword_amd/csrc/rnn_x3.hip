@@ -39,9 +39,15 @@ __device__ __forceinline__ float tanh_r(float v) { return 1.0f - 2.0f * __builti
 // G = 3: GRU (r, z, n), G = 4: LSTM (i, f, g, o); NP = 6 or 9 partial products per operand pair; NB = 16-wide column blocks per
 // wave (2 at H = 128: four waves, one per SIMD, so that each has the whole 512-register file - 288 of them weight fragments)
 // FIN = 32 / 64 (GRU, NP = 3): the input projection of the step fused in (GruArgs::fin); 0: xg precomputed
-template <int G, int H, int NP, int NB, int FIN = 0>
+// PAD (NP = 3): the layer's real width a.H < H, a multiple of 4 (layer_dim = 48, 96, 100 ...): the instance of the next width with the rows
+// and columns beyond a.H read as zeros - a padded unit has zero weights, biases and input pre-activations, so its gates are 1/2, 1/2,
+// tanh(0) and its state stays 0 for ever (GRU: h' = h / 2; LSTM: c' = c / 2, h' = tanh(c') / 2), which adds nothing to the real units'
+// products; all global addressing uses the real width and nothing is stored for the padded units
+template <int G, int H, int NP, int NB, int FIN = 0, bool PAD = false>
 __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a) {
     static_assert(FIN == 0 || (G == 3 && NP == 3 && FIN % 32 == 0), "fused input projection: GRU, two-term form");
+    static_assert(!PAD || (FIN == 0 && NP == 3), "padded widths: two-term form, xg precomputed");
+    const int HR = PAD ? a.H : H;                             // real width (global addressing)
     constexpr int KSI = FIN / 32;                             // k-blocks of the input product
     constexpr int KS = H / 32;                                // MFMA k-blocks
     constexpr int LDP = H + 8;                                // bf16 per LDS row: +16 bytes keeps the 16-byte fragment reads conflict-free
@@ -63,10 +69,18 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     for (int q = 0; q < G; ++q)
 #pragma unroll
         for (int bl = 0; bl < NB; ++bl) {
-            const float* src = a.w_hh + (size_t)(q * H + j0 + 16 * bl) * H + 8 * g;
+            const bool jok = !PAD || j0 + 16 * bl < HR;
+            const float* src = a.w_hh + (size_t)(q * HR + (jok ? j0 + 16 * bl : 0)) * HR + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const float4 v0 = *reinterpret_cast<const float4*>(src + 32 * ks), v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
+                float4 v0, v1;
+                if (PAD) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v0 = (jok && 32 * ks + 8 * g < HR) ? *reinterpret_cast<const float4*>(src + 32 * ks) : z;
+                    v1 = (jok && 32 * ks + 8 * g + 4 < HR) ? *reinterpret_cast<const float4*>(src + 32 * ks + 4) : z;
+                } else {
+                    v0 = *reinterpret_cast<const float4*>(src + 32 * ks); v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
+                }
                 const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 if (H2) {
                     uint32_t hh[4], ll[4];
@@ -83,7 +97,7 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                     wf[q][bl][ks][NTM - 1] = make_uint4(pack_hi16r(lo[0], lo[1]), pack_hi16r(lo[2], lo[3]), pack_hi16r(lo[4], lo[5]), pack_hi16r(lo[6], lo[7]));
                 }
             }
-            bh[q][bl] = a.b_hh[q * H + j0 + 16 * bl];
+            bh[q][bl] = jok ? a.b_hh[q * HR + j0 + 16 * bl] : 0.0f;
             __builtin_amdgcn_sched_barrier(0);                // one row at a time: all rows' raw loads in flight at once would not fit beside the fragments
         }
     // fused input projection: W_ih rows q*H + j, k = 32 ks + 8 g .. + 7 -> B fragments (two binary16 terms of weight x wi_scale)
@@ -126,11 +140,11 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + 4 * g + r;
-            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * G * H + j0;
+            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * G * HR + j0;
 #pragma unroll
             for (int q = 0; q < (FIN ? 1 : G); ++q)
 #pragma unroll
-                for (int bl = 0; bl < (FIN ? 1 : NB); ++bl) x[q][bl][r] = xg[q * H + 16 * bl];
+                for (int bl = 0; bl < (FIN ? 1 : NB); ++bl) x[q][bl][r] = (!PAD || j0 + 16 * bl < HR) ? xg[q * HR + 16 * bl] : 0.0f;
         }
     };
     // fused form: the lane's 8 features per k-block of clip n's row of the step (the A fragment of the input product), raw, PF steps ahead
@@ -241,7 +255,7 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                     cn = fg * cprev[bl][r] + ig * gg;
                     hn = og * tanh_r(cn);
                 }
-                if (b < a.B) {
+                if (b < a.B && (!PAD || j < HR)) {
                     if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                     if (a.last_out && step == a.steps - 1) {
                         a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
@@ -250,13 +264,13 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                             float h2;
                             if (G == 3) {
                                 const float rg = sigmoid_r(x2[0] + a.b_hh2[j]);
-                                const float zg = sigmoid_r(x2[H] + a.b_hh2[H + j]);
-                                const float ng = tanh_r(x2[2 * H] + rg * a.b_hh2[2 * H + j]);
+                                const float zg = sigmoid_r(x2[HR] + a.b_hh2[HR + j]);
+                                const float ng = tanh_r(x2[2 * HR] + rg * a.b_hh2[2 * HR + j]);
                                 h2 = (1.0f - zg) * ng;
                             } else {
                                 const float ig = sigmoid_r(x2[0] + a.b_hh2[j]);
-                                const float gg = tanh_r(x2[2 * H] + a.b_hh2[2 * H + j]);
-                                const float og = sigmoid_r(x2[(G - 1) * H] + a.b_hh2[(G - 1) * H + j]);
+                                const float gg = tanh_r(x2[2 * HR] + a.b_hh2[2 * HR + j]);
+                                const float og = sigmoid_r(x2[(G - 1) * HR] + a.b_hh2[(G - 1) * HR + j]);
                                 h2 = og * tanh_r(ig * gg);
                             }
                             a.last_out[(size_t)b * a.ld_last + a.col_off2 + j] = h2;
@@ -296,14 +310,29 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 }
 }  // namespace
 
+// widths 32 / 64 / 128 in every arithmetic; any other multiple of 4 below 128 as a zero-padded instance of the next width (two-term form)
+static bool rnn_x3_padded(const GruArgs& a) {
+    static const int on = [] { const char* e = getenv("NWW_RNN_PAD"); return e ? atoi(e) : 1; }();
+    return on && a.products == 3 && a.H >= 4 && a.H < 128 && a.H % 4 == 0 && a.H != 32 && a.H != 64 && a.fin == 0;
+}
 bool rnn_x3_usable(const GruArgs& a) {
-    return (a.products == 3 || a.products == 6 || a.products == 9) && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0;
+    return (a.products == 3 || a.products == 6 || a.products == 9) && (a.H == 32 || a.H == 64 || a.H == 128 || rnn_x3_padded(a)) &&
+           (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0;
 }
 
 hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
     if (!rnn_x3_usable(a) || (gates != 3 && gates != 4)) return hipErrorInvalidValue;
-    const dim3 grid((a.B + 15) / 16), block(a.H == 128 ? 256 : 64 * (a.H / 16));
-    const size_t lds = (size_t)(a.products == 3 ? 2 : 3) * 16 * (a.H + 8) * sizeof(uint16_t);
+    const bool pad = rnn_x3_padded(a);
+    const int HP = a.H <= 32 ? 32 : a.H <= 64 ? 64 : 128;     // the instance's width
+    const dim3 grid((a.B + 15) / 16), block(HP == 128 ? 256 : 64 * (HP / 16));
+    const size_t lds = (size_t)(a.products == 3 ? 2 : 3) * 16 * (HP + 8) * sizeof(uint16_t);
+    if (pad) {
+#define RNN_PAD(GV, HV) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 3, (HV == 128 ? 2 : 1), 0, true>), grid, block, lds, s, a)
+        if (gates == 3) { if (HP == 32) RNN_PAD(3, 32); else if (HP == 64) RNN_PAD(3, 64); else RNN_PAD(3, 128); }
+        else { if (HP == 32) RNN_PAD(4, 32); else if (HP == 64) RNN_PAD(4, 64); else RNN_PAD(4, 128); }
+#undef RNN_PAD
+        return hipGetLastError();
+    }
 #define RNN_GO(GV, HV)                                                                                                \
     if (a.products == 9) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 9, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a);  \
     else if (a.products == 3) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 3, (HV == 128 ? 2 : 1)>), grid, block, lds, s, a); \

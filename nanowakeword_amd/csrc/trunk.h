@@ -67,6 +67,13 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
 struct ConvMfmaArgs {
     const float* in; const float* w; const float *bias, *alpha, *beta; float* out;
     int B, H, W, Cout, act, pool;
+    int Cin = 32;          // conv3_x3 only: 64 takes the wide instance (conv3_x3_wide_fits)
+    // conv3_x3 only, k-split passes (more than 32 input channels on the 32-channel instances): the pass reads input channels
+    // [w_cin_off, w_cin_off + 32) of w_cin - planes and weight columns alike - and starts its sums from acc_in [B][Cout][H][W]
+    // (raw sums of the earlier passes; act = ACT_NONE writes such sums: no bias, no BN, un-pooled)
+    int w_cin = 32, w_cin_off = 0;
+    const float* acc_in = nullptr;
+    int strip_h = 0;       // conv3_x3 only: > 0 - the plane goes through LDS in strips of this many rows (conv3_x3_strip_rows; pooled or raw output)
     // conv3_x3 only, streaming hop: the input planes live in per-clip rings of pooled rows (TrunkArgs::out_ring_rows): row y of
     // channel c of clip b at in + b * in_clip_stride + c * in_ch_stride + ((in_row0 + y) % in_ring_rows) * W
     size_t in_clip_stride = 0, in_ch_stride = 0;
@@ -89,6 +96,10 @@ hipError_t launch_conv3x3_mfma(const ConvMfmaArgs& a, int C1, int max_grid, hipS
 // split-operand bf16 instance of the same stage (conv3_x3.hip): 32 input channels, Cout % 32 == 0, six products
 size_t conv3_x3_lds_bytes(int H, int W, int avg_ow);
 bool conv3_x3_fits(int H, int W, int Cout, int avg_ow, int pool);
+int conv3_x3_strip_rows(int H, int W, int Cout);               // planes of more than 512 pixels: rows per strip, 0 = none
+size_t conv3_x3_strip_lds_bytes(int sh, int W);
+bool conv3_x3_wide_fits(int Cin, int H, int W, int Cout);      // 64 input channels, pooled, two binary16 terms only
+size_t conv3_x3_wide_lds_bytes(int Cin, int H, int W);
 hipError_t launch_conv3_x3(const ConvMfmaArgs& a, int max_grid, hipStream_t s);
 
 // Conv2d(1, 32, 3, p1) + bias/BN + act + MaxPool2 on MFMA, channels-last output [B][H/2][W/2][32] (BcResNet init conv)

@@ -134,6 +134,22 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({"NWW_LIN_H2": "0", "NWW_RNN_FUSE_IH": "0"}, [_CONF, _GRU], ["lin_x3:"], ["lin_x3:input_proj [f16x3]", "ih_l0 [f16x3]"], False),   # short-K Linears on three bf16 terms under the default arithmetic
     ({"NWW_RNN_FUSE_IH": "0"}, [_GRU, dict(model_type="gru", input_shape=(101, 64))], ["lin_x3:model.gru.ih_l0"], ["+ input projection"], False),   # GRU head: input projection as its own launch
     ({}, [_GRU, dict(model_type="gru", input_shape=(101, 64)), dict(model_type="gru", input_shape=(20, 32), layer_dim=32)], ["+ input projection [f16x3]"], ["lin_x3:model.gru.ih_l0 "], False),   # (default) ... fused into the recurrence
+    ({}, [_CRNN4, dict(model_type="crnn", input_shape=(96, 64), crnn_cnn_channels=[16, 32, 64, 64]), dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[16, 32, 64, 32], activation="gelu")],
+     ["conv3_x3:model.cnn.12 (input channels 0-31, raw sums)", "conv3_x3+seq:model.cnn.12 (input channels 32-63, epilogue)"], ["conv3x3:model.cnn.12"], False),   # (default) a fourth CRNN stage with 64 input channels: two passes of the 32-channel instance
+    ({}, [dict(model_type="crnn", input_shape=(64, 64), crnn_cnn_channels=[16, 32, 96, 32]), dict(model_type="crnn", input_shape=(48, 96), crnn_cnn_channels=[16, 32, 64, 128], crnn_rnn_type="lstm")],
+     ["epilogue)"], ["conv3x3:"], False),                                                # ... three passes (96 input channels); 128 output channels
+    ({}, [dict(model_type="crnn", input_shape=(151, 64)), dict(model_type="crnn", input_shape=(201, 64), crnn_rnn_type="lstm", activation="gelu"), dict(model_type="crnn", input_shape=(150, 96), layer_dim=64)],
+     ["conv3_x3+seq:model.cnn.8 (strips of"], ["conv3x3:"], False),                      # clips longer than ~1.3 s: the third stage's plane (> 512 pixels) in strips of rows
+    ({}, [dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[32, 64, 64]), dict(model_type="crnn", input_shape=(61, 40), crnn_cnn_channels=[32, 32])],
+     ["conv3_x3", "(strips of"], ["conv3x3:model.cnn.4", "conv3x3:model.cnn.8"], False),   # stacks the fused trunk does not take (first stage not 16 channels): later stages in strips / k-split passes
+    ({"NWW_F16_RANGE_LOG2": "40"}, [_CRNN4, dict(model_type="crnn", input_shape=(96, 64), crnn_cnn_channels=[16, 32, 64, 64], activation="silu")],
+     ["conv3_x3+seq:model.cnn.12 [f16x3]"], ["raw sums", "conv3x3:"], False),            # ... the wide two-term instance (taken when the plan-time bound of the stage's input is tight enough)
+    ({"NWW_CONV3_KSPLIT": "0"}, [_CRNN4], ["conv3x3:model.cnn.12"], ["raw sums"], False),   # ... and on the general kernel
+    ({}, [dict(model_type="gru", input_shape=(30, 64), layer_dim=96), dict(model_type="gru", input_shape=(20, 32), layer_dim=20, n_blocks=2),
+          dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm", layer_dim=48), dict(model_type="crnn", input_shape=(32, 96), layer_dim=100)],
+     ["+ first reverse step [f16x3]"], [], False),                                    # (default) recurrent widths between the register-resident ones: zero-padded instances
+    ({"NWW_RNN_PAD": "0"}, [dict(model_type="gru", input_shape=(30, 64), layer_dim=96), dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm", layer_dim=48)],
+     [], ["+ first reverse step"], False),                                               # ... and on the 32-clips-per-workgroup kernels
     ({"NWW_MHA_H2": "0"}, [_CONF], ["mha_mfma"], ["mha_h2"], False),                    # float32-MFMA attention core under the default arithmetic
     ({"TEST_CONV_ARITH": "bf16x6"}, [_CONF], ["mha_mfma", "ffn_x3"], ["[f16x3]"], False),   # Conformer on three bf16 terms
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM

@@ -103,6 +103,10 @@ _INC_CASES = [
     (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 13440),
     (dict(model_type="crnn", input_shape=(101, 64)), (64, True), 16000, 10880),
     (dict(model_type="crnn", input_shape=(151, 64), layer_dim=64), (64, True), 24000, 16640),
+    # four conv stages (the third reads the trunk's rings, the fourth runs as k-split passes); a stack the fused trunk does not take; a padded recurrent width
+    (dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[16, 32, 64, 64]), (64, True), 16000, 1280),
+    (dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[32, 64], layer_dim=96), (64, True), 16000, 1280),
+    (dict(model_type="gru", input_shape=(101, 64), layer_dim=100), (64, True), 16000, 640),
 ]
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Random head shapes against the oracle (features in, logits out): a wider net than the parametrised GPU tests for the
-shape-dependent kernel choices (lin_x3 / ffn_x3 / mha_mfma widths and tails, conv3_x3 fits, BcResNet strips, trunk strips).
+shape-dependent kernel choices (lin_x3 / ffn_x3 / mha_mfma widths and tails, conv3_x3 fits / strips / k-split passes, padded recurrent
+widths, BcResNet strips, trunk strips).
 usage: python tools/fuzz_heads.py [n_cases] [seed] [kinds, comma-separated] [act_dtype]   (needs an MI355X)
 With act_dtype = f16 / bf16 (BcResNet only) the pass mark is 3e-2 / 2e-1 instead of 1e-4: on random features and planes of a few pixels
 the 16-bit modes are noisier than on log-mel clips (round 4: worst of 80 / 60 cases 1.7e-2 / 9.5e-2; float32 storage 3.6e-5 of 250)."""
@@ -25,8 +26,11 @@ def run(n_cases=40, seed=0, log=print, kinds=("conformer", "crnn", "bcresnet", "
             cfg = HeadConfig("conformer", (int(rng.integers(3, 140)), int(rng.choice([32, 40, 64]))), embedding_dim=16,
                              conformer_d_model=d, conformer_n_head=nh, activation=act)
         elif kind == "crnn":
-            cfg = HeadConfig("crnn", (int(rng.integers(16, 120)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
-                             crnn_rnn_type=str(rng.choice(["gru", "lstm"])), layer_dim=int(rng.choice([32, 48, 64])))
+            # conv stacks the fused trunk takes and does not take, 64+ channel stages (k-split passes), clips up to 2.6 s (row strips), recurrent
+            # widths between the register-resident ones (zero-padded instances) and above them
+            chans = [[16, 32, 32], [16, 32, 32], [16, 32, 64], [16, 32, 64, 64], [32, 64], [32, 32, 64], [16, 32, 96, 32], [8, 16], [16, 32]][rng.integers(0, 9)]
+            cfg = HeadConfig("crnn", (int(rng.integers(16, 120) if rng.integers(0, 4) else rng.integers(120, 260)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
+                             crnn_rnn_type=str(rng.choice(["gru", "lstm"])), layer_dim=int(rng.choice([20, 32, 48, 64, 96, 100, 128, 160])), crnn_cnn_channels=chans)
         elif kind == "bcresnet":
             cfg = HeadConfig("bcresnet", (int(rng.integers(16, 110)), int(rng.choice([32, 40, 64]))), embedding_dim=16, activation=act)
         elif kind == "cnn":
@@ -36,7 +40,7 @@ def run(n_cases=40, seed=0, log=print, kinds=("conformer", "crnn", "bcresnet", "
                              layer_dim=int(rng.choice([8, 20, 32, 128])), n_blocks=int(rng.integers(0, 3)), embedding_dim=int(rng.choice([8, 16, 64])))
         elif kind == "gru":
             cfg = HeadConfig("gru", (int(rng.integers(4, 110)), int(rng.choice([32, 40, 64, 96]))), embedding_dim=16, activation=act,
-                             layer_dim=int(rng.choice([32, 48, 64, 128])), n_blocks=int(rng.integers(1, 3)))
+                             layer_dim=int(rng.choice([20, 32, 48, 64, 96, 100, 128, 160])), n_blocks=int(rng.integers(1, 3)))
         else:
             cfg = HeadConfig("e2e_dnn", (int(rng.choice([32, 40, 64])), int(rng.integers(32, 130))), embedding_dim=16, activation=act)
         B = int(rng.choice([1, 2, 5, 17, 33, 130]))

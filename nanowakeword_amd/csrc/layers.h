@@ -171,6 +171,9 @@ struct GruArgs {
     // round trip of gate pre-activations through HBM)
     const float* x_in = nullptr; const float* w_ih = nullptr; const float* b_ih = nullptr;
     int fin = 0; float x_scale = 1.0f, x_clamp = 0.0f, wi_scale = 1.0f;
+    // rnn_stream (128 < H <= 256, products = 3): W_hh x w_scale as two binary16 terms in MFMA fragment order (launch_rnn_stream_pack), read every step
+    const void* w_packed = nullptr;
+    int dbg = 0;           // NWW_ABLATION builds only (rnn_stream: phase-skipping for timing; results are garbage)
 };
 size_t rnn_wide_weight_bytes(int gates, int H);
 hipError_t launch_rnn_pad_weights(const float* w_hh, float* out, int gates, int H, hipStream_t s);
@@ -182,6 +185,11 @@ hipError_t launch_transpose_planes(const float* in, float* out, int B, int R, in
 bool rnn_x3_usable(const GruArgs& a);
 bool rnn_x3_enabled(const GruArgs& a);   // ... and not switched off (NWW_GRU16 = 0)
 hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s);
+// rnn_stream.hip: 128 < H <= 256 (H % 4 == 0), two-term form, W_hh streamed from L2 each step
+bool rnn_stream_usable(const GruArgs& a);
+size_t rnn_stream_packed_bytes(int gates, int H);
+hipError_t launch_rnn_stream_pack(const float* w_hh, void* packed, int gates, int H, float w_scale, hipStream_t s);
+hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s);
 // LSTM recurrence for one direction, same arguments (xg is [B][T][4H], gate order i, f, g, o)
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s);
 

@@ -1618,6 +1618,7 @@ bool rnn_x3_enabled(const GruArgs& a) {
 }
 
 hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
+    if (a.w_packed) return launch_rnn_stream(a, 4, s);
     if (a.ldw) return launch_rnn_wide(a, 4, s);                      // padded weights: the any-width kernel (planned for H % 4 != 0 or H > 256)
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
@@ -1644,6 +1645,7 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
+    if (a.w_packed) return launch_rnn_stream(a, 3, s);
     if (a.ldw) return launch_rnn_wide(a, 3, s);
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
     static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();

@@ -540,8 +540,10 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
     const int products = (p.h->f16 && rnn_h2) ? 3 : p.h->conv_products;
     GruArgs probe; probe.H = H; probe.products = products;
     probe.w_hh = p.W(prefix + ".weight_hh_l" + std::to_string(layers - 1));       // the pointer the fused launch will really get (alignment test)
-    bool x3 = probe.w_hh != nullptr && rnn_x3_enabled(probe);
-    if (x3 && H != 32 && H != 64 && H != 128) {              // zero-padded instance (rnn_x3.hip): two-term form only, so the last layer's W_hh must scale
+    static const int gru16_on = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    const bool streamed = gru16_on && rnn_stream_usable(probe);      // 128 < H <= 256: W_hh streamed from L2 (rnn_stream.hip)
+    bool x3 = probe.w_hh != nullptr && (rnn_x3_enabled(probe) || streamed);
+    if (x3 && H != 32 && H != 64 && H != 128) {              // zero-padded / streamed instances: two-term form only, so the last layer's W_hh must scale
         const float* wl = probe.w_hh;
         if (!(f16_wscale(f16_fetch(p.h, wl, (size_t)G * H * H)) > 0.0f)) x3 = false;
     }
@@ -607,12 +609,20 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                                         : (G == 4 ? "lstm:" : "gru:") + prefix + sfx;
             const float w_scale = products == 3 ? f16_wscale(f16_fetch(p.h, whh_f, (size_t)G * H * H)) : 1.0f;
             const int products_l = (products == 3 && !(w_scale > 0.0f)) ? p.h->conv_products : products;
+            const void* w_packed = nullptr;
+            if (streamed && products_l == 3 && ldw == 0) {
+                void* pk = nullptr;
+                if (hipMalloc(&pk, rnn_stream_packed_bytes(G, H)) == hipSuccess && launch_rnn_stream_pack(whh_f, pk, G, H, w_scale, p.h->own_stream) == hipSuccess) {
+                    p.h->packed_weights.push_back(pk);
+                    w_packed = pk;
+                } else if (pk) (void)hipFree(pk);
+            }
             const bool fused_here = fuse_ih && fold && products_l == 3 && ldw == 0;
             const float* bih_f = p.W(prefix + ".bias_ih_l" + std::to_string(l));
             const int fin = cur_I;
-            p.add(nm + (fused_here ? " + input projection" : "") + (products_l == 3 && x3 && ldw == 0 ? " [f16x3]" : ""), [=](Run& r) {
+            p.add(nm + (fused_here ? " + input projection" : "") + (products_l == 3 && x3 && ldw == 0 ? (w_packed ? " [f16x3, W_hh streamed]" : " [f16x3]") : ""), [=](Run& r) {
                 GruArgs a;
-                a.products = products_l; a.w_scale = w_scale;
+                a.products = products_l; a.w_scale = w_scale; a.w_packed = w_packed;
                 if (fused_here) {
                     a.x_in = r.x; a.w_ih = wih_f; a.b_ih = bih_f; a.fin = fin;
                     a.x_scale = f16_scale(F16_FEATURES.bound); a.x_clamp = (float)F16_FEATURES.bound; a.wi_scale = wi_scale;

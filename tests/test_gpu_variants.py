@@ -150,6 +150,13 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
      ["+ first reverse step [f16x3]"], [], False),                                    # (default) recurrent widths between the register-resident ones: zero-padded instances
     ({"NWW_RNN_PAD": "0"}, [dict(model_type="gru", input_shape=(30, 64), layer_dim=96), dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm", layer_dim=48)],
      [], ["+ first reverse step"], False),                                               # ... and on the 32-clips-per-workgroup kernels
+    ({}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=256), dict(model_type="gru", input_shape=(10, 40), layer_dim=160, n_blocks=2),
+          dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=200)],
+     ["+ first reverse step [f16x3, W_hh streamed]"], [], False),                        # (default) recurrent widths above 128: W_hh streamed from L2 every step (rnn_stream.hip)
+    ({"NWW_RNN_STREAM_TILES": "2"}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=192), dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=256)],
+     ["W_hh streamed]"], [], False),                                                     # ... two 16-clip tiles per workgroup (large batches take them by themselves)
+    ({"NWW_RNN_STREAM": "0"}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=256), dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=200)],
+     [], ["streamed", "+ first reverse step"], False),                                   # ... and on the 32-clips-per-workgroup kernels
     ({"NWW_MHA_H2": "0"}, [_CONF], ["mha_mfma"], ["mha_h2"], False),                    # float32-MFMA attention core under the default arithmetic
     ({"TEST_CONV_ARITH": "bf16x6"}, [_CONF], ["mha_mfma", "ffn_x3"], ["[f16x3]"], False),   # Conformer on three bf16 terms
     ({"NWW_LIN_X3": "0"}, [_CONF], ["glu:", "gemm:input_proj"], ["lin_x3"], False),     # short-K Linears on the general GEMM

@@ -31,6 +31,8 @@ CASES = [
     ("gru L=200", dict(model_type="gru", input_shape=(101, 64), layer_dim=200)),
     ("gru L=96", dict(model_type="gru", input_shape=(101, 64), layer_dim=96)),
     ("gru L=256", dict(model_type="gru", input_shape=(101, 64), layer_dim=256)),
+    ("gru L=160 2 layers", dict(model_type="gru", input_shape=(101, 64), layer_dim=160, n_blocks=2)),
+    ("crnn lstm L=256", dict(model_type="crnn", input_shape=(101, 64), crnn_rnn_type="lstm", layer_dim=256)),
     ("crnn lstm L=100", dict(model_type="crnn", input_shape=(101, 64), crnn_rnn_type="lstm", layer_dim=100)),
     ("crnn [32,64,64]", dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[32, 64, 64])),
     ("bcresnet default", dict(model_type="bcresnet", input_shape=(101, 64))),

@@ -294,13 +294,14 @@ hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s) {
     { const char* e = getenv("NWW_RNN_DBG"); ad.dbg = e ? atoi(e) : 0; }
 #define a ad
 #endif
-#define RS_GO(GV, HV, RV)                                                                                \
-    if (mt == 1) hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, 2 * RV, 1>), grid, block, lds, s, a);     \
-    else hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, RV, 2>), grid, block, lds, s, a);
+    // ring depths: what fits the 256 registers of a wave (two per SIMD) without scratch beside 24 / 48 (GRU) or 32 / 64 (LSTM) accumulators
+#define RS_GO(GV, HV, R1, R2)                                                                            \
+    if (mt == 1) hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R1, 1>), grid, block, lds, s, a);         \
+    else hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R2, 2>), grid, block, lds, s, a);
     if (gates == 3) {
-        if (HP == 192) { RS_GO(3, 192, 6) } else { RS_GO(3, 256, 6) }
+        if (HP == 192) { RS_GO(3, 192, 12, 4) } else { RS_GO(3, 256, 12, 4) }
     } else {
-        if (HP == 192) { RS_GO(4, 192, 4) } else { RS_GO(4, 256, 4) }
+        if (HP == 192) { RS_GO(4, 192, 8, 2) } else { RS_GO(4, 256, 8, 2) }
     }
 #undef RS_GO
 #ifdef NWW_ABLATION

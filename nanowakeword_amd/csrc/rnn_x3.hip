@@ -75,9 +75,12 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
             for (int ks = 0; ks < KS; ++ks) {
                 float4 v0, v1;
                 if (PAD) {
-                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    v0 = (jok && 32 * ks + 8 * g < HR) ? *reinterpret_cast<const float4*>(src + 32 * ks) : z;
-                    v1 = (jok && 32 * ks + 8 * g + 4 < HR) ? *reinterpret_cast<const float4*>(src + 32 * ks + 4) : z;
+                    // (in-bounds addresses for every lane, then a select: a conditional 16-byte load puts its result on the stack)
+                    const bool ok0 = jok && 32 * ks + 8 * g < HR, ok1 = jok && 32 * ks + 8 * g + 4 < HR;
+                    v0 = *reinterpret_cast<const float4*>(ok0 ? src + 32 * ks : a.w_hh);
+                    v1 = *reinterpret_cast<const float4*>(ok1 ? src + 32 * ks + 4 : a.w_hh);
+                    v0.x = ok0 ? v0.x : 0.0f; v0.y = ok0 ? v0.y : 0.0f; v0.z = ok0 ? v0.z : 0.0f; v0.w = ok0 ? v0.w : 0.0f;
+                    v1.x = ok1 ? v1.x : 0.0f; v1.y = ok1 ? v1.y : 0.0f; v1.z = ok1 ? v1.z : 0.0f; v1.w = ok1 ? v1.w : 0.0f;
                 } else {
                     v0 = *reinterpret_cast<const float4*>(src + 32 * ks); v1 = *reinterpret_cast<const float4*>(src + 32 * ks + 4);
                 }

@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     constexpr int PLANE = 16 * LDP * 2;                                           // bytes per term plane
     // input-side pre-activations (independent of h) are requested PF steps ahead: with the products on the bf16 pipe a step is
     // shorter than the trip of a row per clip from HBM
-    constexpr int PF = (G == 4 && H == 128) ? 0 : 2;      // (the LSTM at H = 128 holds 384 registers of weight fragments: no room)
+    // (the four-wave LSTM at H = 128 holds 384 registers of weight fragments: no room; the eight-wave GRU with 64 fused input features keeps one step)
+    constexpr int PF = (G == 4 && H == 128 && NB == 2) ? 0 : (H == 128 && NB == 1 && (FIN == 64 || G == 4)) ? 1 : 2;
     float xpf[PF + 1][FIN ? 1 : G][FIN ? 1 : NB][4];           // [0]: this step's (precomputed xg form)
     auto fetch = [&](int step, float (&x)[FIN ? 1 : G][FIN ? 1 : NB][4]) {
         const int t = a.reverse ? a.T - 1 - step : step;
@@ -329,10 +330,15 @@ hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
     const int HP = a.H <= 32 ? 32 : a.H <= 64 ? 64 : 128;     // the instance's width
     const dim3 grid((a.B + 15) / 16), block(HP == 128 ? 256 : 64 * (HP / 16));
     const size_t lds = (size_t)(a.products == 3 ? 2 : 3) * 16 * (HP + 8) * sizeof(uint16_t);
+    // H = 128 in the two-term form: eight waves of 16 hidden units (two per SIMD, 144 fragment registers each) instead of four of 32 - a step's
+    // products and gate arithmetic per wave halve, and the step is a latency chain: 0.280 -> 0.243 ms (GRU head, B = 2048), 32 -> 23 us (CRNN, B = 16)
+    static const int nb1 = [] { const char* e = getenv("NWW_RNN_WAVES8"); return e ? atoi(e) : 1; }();
     if (pad) {
 #define RNN_PAD(GV, HV) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 3, (HV == 128 ? 2 : 1), 0, true>), grid, block, lds, s, a)
-        if (gates == 3) { if (HP == 32) RNN_PAD(3, 32); else if (HP == 64) RNN_PAD(3, 64); else RNN_PAD(3, 128); }
-        else { if (HP == 32) RNN_PAD(4, 32); else if (HP == 64) RNN_PAD(4, 64); else RNN_PAD(4, 128); }
+#define RNN_PAD8(GV) hipLaunchKernelGGL((rnn_x3_kernel<GV, 128, 3, 1, 0, true>), grid, dim3(512), lds, s, a)
+        if (gates == 3) { if (HP == 32) RNN_PAD(3, 32); else if (HP == 64) RNN_PAD(3, 64); else if (nb1) RNN_PAD8(3); else RNN_PAD(3, 128); }
+        else { if (HP == 32) RNN_PAD(4, 32); else if (HP == 64) RNN_PAD(4, 64); else RNN_PAD(4, 128); }      // (the padded eight-wave LSTM would need scratch)
+#undef RNN_PAD8
 #undef RNN_PAD
         return hipGetLastError();
     }
@@ -345,6 +351,16 @@ hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
         case 32: RNN_GO(GV, 32) break;                                                                                \
         case 64: RNN_GO(GV, 64) break;                                                                                \
         default: RNN_GO(GV, 128) break;                                                                               \
+    }
+    if (nb1 && a.H == 128 && a.products == 3 && !pad) {
+        const dim3 block8(512);
+        if (gates == 3 && a.fin > 0) {
+            if ((a.fin != 32 && a.fin != 64) || !a.x_in || !a.w_ih || !a.b_ih || a.reverse) return hipErrorInvalidValue;
+            if (a.fin == 32) hipLaunchKernelGGL((rnn_x3_kernel<3, 128, 3, 1, 32>), grid, block8, lds, s, a);
+            else hipLaunchKernelGGL((rnn_x3_kernel<3, 128, 3, 1, 64>), grid, block8, lds, s, a);
+        } else if (gates == 3) hipLaunchKernelGGL((rnn_x3_kernel<3, 128, 3, 1>), grid, block8, lds, s, a);
+        else hipLaunchKernelGGL((rnn_x3_kernel<4, 128, 3, 1>), grid, block8, lds, s, a);
+        return hipGetLastError();
     }
     if (gates == 3 && a.fin > 0) {                            // fused input projection (GRU, two-term form)
         if (a.products != 3 || (a.fin != 32 && a.fin != 64) || !a.x_in || !a.w_ih || !a.b_ih || a.reverse) return hipErrorInvalidValue;

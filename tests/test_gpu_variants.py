@@ -153,6 +153,8 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
     ({}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=256), dict(model_type="gru", input_shape=(10, 40), layer_dim=160, n_blocks=2),
           dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=200)],
      ["+ first reverse step [f16x3, W_hh streamed]"], [], False),                        # (default) recurrent widths above 128: W_hh streamed from L2 every step (rnn_stream.hip)
+    ({"NWW_RNN_WAVES8": "0"}, [_CRNN, dict(model_type="gru", input_shape=(101, 64)), dict(model_type="crnn", input_shape=(16, 96), crnn_rnn_type="lstm"), dict(model_type="gru", input_shape=(30, 64), layer_dim=96)],
+     ["[f16x3]"], [], False),                                                            # H = 128 recurrences on four waves of 32 hidden units instead of eight of 16
     ({"NWW_RNN_STREAM_TILES": "2"}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=192), dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=256)],
      ["W_hh streamed]"], [], False),                                                     # ... two 16-clip tiles per workgroup (large batches take them by themselves)
     ({"NWW_RNN_STREAM": "0"}, [dict(model_type="gru", input_shape=(12, 64), layer_dim=256), dict(model_type="crnn", input_shape=(32, 96), crnn_rnn_type="lstm", layer_dim=200)],

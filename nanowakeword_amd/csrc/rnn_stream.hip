@@ -71,13 +71,14 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
     const int HR = a.H;
     const float s_h = 16384.0f, un = 1.0f / (16384.0f * a.w_scale);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_s);       // [term 2][32 clips][LDP]
+    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_s);       // [2 sets][term 2][clips][LDP]: step t reads set t & 1 and writes the other (one barrier per step, as rnn_x3)
     constexpr int PLANE = 16 * RS_MT * LDP * 2;               // bytes per term plane
+    constexpr int SET = 2 * PLANE;                            // bytes per set
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * 16 * RS_MT;
     const int j0 = 32 * wave + n;                             // this lane's hidden units j0 + 16 bl
-    for (int idx = threadIdx.x; idx < 2 * 16 * RS_MT * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
+    for (int idx = threadIdx.x; idx < 2 * 2 * 16 * RS_MT * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
     float bh[G][RS_NB];
 #pragma unroll
     for (int q = 0; q < G; ++q)
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
     uint4 ring[RING][2];
 #pragma unroll
     for (int u = 0; u < RING; ++u) fetch_unit(u, ring[u][0], ring[u][1]);
-    const unsigned char* arow = smem_s + (size_t)(n * LDP + 8 * g) * 2;          // A fragment: clip n (+ 16 mt), k = 32 ks + 8 g .. + 7
+    const unsigned char* arow0 = smem_s + (size_t)(n * LDP + 8 * g) * 2;         // A fragment: clip n (+ 16 mt), k = 32 ks + 8 g .. + 7
     // gate pre-activations xg [B][T][G HR]: the workgroup's 32 clips from a uniform base, each of the lane's 8 rows by one 32-bit byte offset
     // that moves by a row per step (scalar base + lane offset loads again; rows beyond B repeat the last clip).  Lanes of padded units read a
     // few floats past their gate's columns - inside the buffer, whose clips carry one row more than T (nww_plan.hip: add_bigru_last) - and
@@ -147,6 +148,8 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
 #endif
                 xoff[mt][r] += (uint32_t)t_delta;
             }
+        const unsigned char* arow = arow0 + (step & 1) * SET;
+        uint16_t* hpw = hp + ((step & 1) ^ 1) * (SET / 2);
         f32x4 acc[RS_MT][G][RS_NB];
 #pragma unroll
         for (int mt = 0; mt < RS_MT; ++mt)
@@ -187,7 +190,6 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
                 __builtin_amdgcn_sched_barrier(0);            // keep the stream in order: no fetch rises above the ring's depth (registers)
             }
         }
-        __syncthreads();                                      // every wave has finished reading the h planes
 #pragma unroll
         for (int mt = 0; mt < RS_MT; ++mt)
 #pragma unroll
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
                     hprev[mt][bl][r] = hn; cprev[mt][bl][r] = cn;
                     uint32_t hh, ll;
                     nww_split2h(hn * s_h, 0.0f, hh, ll);
-                    uint16_t* d = hp + c * LDP + j;
+                    uint16_t* d = hpw + c * LDP + j;
                     d[0] = (uint16_t)hh; d[16 * RS_MT * LDP] = (uint16_t)ll;
                 }
             }
@@ -288,7 +290,7 @@ hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s) {
     static const int n_cu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
     const int mt = force_mt == 1 || force_mt == 2 ? force_mt : (a.B <= 16 * n_cu ? 1 : 2);
     const dim3 grid((a.B + 16 * mt - 1) / (16 * mt)), block(64 * (HP / 32));
-    const size_t lds = (size_t)2 * 16 * mt * (HP + 8) * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * 2 * 16 * mt * (HP + 8) * sizeof(uint16_t);      // two sets of two term planes
 #ifdef NWW_ABLATION
     GruArgs ad = a;
     { const char* e = getenv("NWW_RNN_DBG"); ad.dbg = e ? atoi(e) : 0; }

@@ -55,12 +55,13 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     constexpr int NTM = H2 ? 2 : 3;                           // terms per value
     const float s_h = 16384.0f, s_w = H2 ? a.w_scale : 1.0f, un = H2 ? 1.0f / (16384.0f * a.w_scale) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_r);       // [terms][16 clips][LDP]
+    uint16_t* hp = reinterpret_cast<uint16_t*>(smem_r);       // [2 sets][terms][16 clips][LDP]: step t reads set t & 1 and writes the other -
+                                                              // ONE barrier per step (a wave writes set s again only two barriers after the last read of it)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * 16;
     const int j0 = 16 * NB * wave + n;                        // this lane's hidden units j0 + 16 bl (B-operand column, C-layout column)
-    for (int idx = threadIdx.x; idx < NTM * 16 * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
+    for (int idx = threadIdx.x; idx < 2 * NTM * 16 * LDP / 2; idx += blockDim.x) reinterpret_cast<uint32_t*>(hp)[idx] = 0u;
 
     // W_hh rows q*H + j, k = 32 ks + 8 g .. + 7 -> B fragments, split once
     uint4 wf[G][NB][KS][NTM];
@@ -132,8 +133,9 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     for (int bl = 0; bl < NB; ++bl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { hprev[bl][r] = 0.0f; cprev[bl][r] = 0.0f; }
-    const unsigned char* arow = smem_r + (size_t)(n * LDP + 8 * g) * 2;          // A fragment: clip n, k = 32 ks + 8 g .. + 7
+    const unsigned char* arow0 = smem_r + (size_t)(n * LDP + 8 * g) * 2;         // A fragment: clip n, k = 32 ks + 8 g .. + 7
     constexpr int PLANE = 16 * LDP * 2;                                           // bytes per term plane
+    constexpr int SET = NTM * PLANE;                                              // bytes per set of planes
     // input-side pre-activations (independent of h) are requested PF steps ahead: with the products on the bf16 pipe a step is
     // shorter than the trip of a row per clip from HBM
     // (the four-wave LSTM at H = 128 holds 384 registers of weight fragments: no room; the eight-wave GRU with 64 fused input features keeps one step)
@@ -201,6 +203,8 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                     }
             }
         }
+        const unsigned char* arow = arow0 + (step & 1) * SET;
+        uint16_t* hpw = hp + ((step & 1) ^ 1) * (SET / 2);
         {                                                     // (first step: the planes hold zeros)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -224,7 +228,6 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 #undef RNN_PROD
             }
         }
-        __syncthreads();                                      // every wave has finished reading the h planes
 #pragma unroll
         for (int bl = 0; bl < NB; ++bl) {
             const int j = j0 + 16 * bl;
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                     }
                 }
                 hprev[bl][r] = hn; cprev[bl][r] = cn;
-                uint16_t* d = hp + c * LDP + j;
+                uint16_t* d = hpw + c * LDP + j;
                 if (H2) {
                     uint32_t hh, ll;
                     nww_split2h(hn * s_h, 0.0f, hh, ll);
@@ -329,7 +332,7 @@ hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
     const bool pad = rnn_x3_padded(a);
     const int HP = a.H <= 32 ? 32 : a.H <= 64 ? 64 : 128;     // the instance's width
     const dim3 grid((a.B + 15) / 16), block(HP == 128 ? 256 : 64 * (HP / 16));
-    const size_t lds = (size_t)(a.products == 3 ? 2 : 3) * 16 * (HP + 8) * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * (a.products == 3 ? 2 : 3) * 16 * (HP + 8) * sizeof(uint16_t);      // two sets of h planes
     // H = 128 in the two-term form: eight waves of 16 hidden units (two per SIMD, 144 fragment registers each) instead of four of 32 - a step's
     // products and gate arithmetic per wave halve, and the step is a latency chain: 0.280 -> 0.243 ms (GRU head, B = 2048), 32 -> 23 us (CRNN, B = 16)
     static const int nb1 = [] { const char* e = getenv("NWW_RNN_WAVES8"); return e ? atoi(e) : 1; }();

@@ -142,6 +142,8 @@ _CONF = dict(model_type="conformer", input_shape=(40, 32), embedding_dim=16, con
      ["conv3_x3+seq:model.cnn.8 (strips of"], ["conv3x3:"], False),                      # clips longer than ~1.3 s: the third stage's plane (> 512 pixels) in strips of rows
     ({}, [dict(model_type="crnn", input_shape=(101, 64), crnn_cnn_channels=[32, 64, 64]), dict(model_type="crnn", input_shape=(61, 40), crnn_cnn_channels=[32, 32])],
      ["conv3_x3", "(strips of"], ["conv3x3:model.cnn.4", "conv3x3:model.cnn.8"], False),   # stacks the fused trunk does not take (first stage not 16 channels): later stages in strips / k-split passes
+    ({}, [dict(model_type="crnn", input_shape=(201, 64), crnn_cnn_channels=[32, 64, 64], layer_dim=64), dict(model_type="crnn", input_shape=(151, 96), crnn_cnn_channels=[16, 32, 64, 64], crnn_rnn_type="lstm")],
+     ["raw sums)", "(strips of"], ["conv3x3:model.cnn.4", "conv3x3:model.cnn.8", "conv3x3:model.cnn.12"], False),   # k-split passes that also run in strips (a 64-channel stage on an 800-pixel plane)
     ({"NWW_F16_RANGE_LOG2": "40"}, [_CRNN4, dict(model_type="crnn", input_shape=(96, 64), crnn_cnn_channels=[16, 32, 64, 64], activation="silu")],
      ["conv3_x3+seq:model.cnn.12 [f16x3]"], ["raw sums", "conv3x3:"], False),            # ... the wide two-term instance (taken when the plan-time bound of the stage's input is tight enough)
     ({"NWW_CONV3_KSPLIT": "0"}, [_CRNN4], ["conv3x3:model.cnn.12"], ["raw sums"], False),   # ... and on the general kernel

@@ -130,24 +130,29 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
         for (int r = 0; r < 4; ++r) soff[mt][r] = (uint32_t)(((16 * mt + 4 * g + r) * a.T + t_first) * a.ld_seq * 4 + j0 * 4);
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
-        // input-side pre-activations of this step: requested now, used behind the products (a step is several microseconds long)
+        // input-side pre-activations of this step, used behind the products.  Requested inside the product loop, behind the last unit whose
+        // weights were fetched in the PREVIOUS step: hipcc waits for loads carried round the loop with s_waitcnt vmcnt(0), so a request ahead of
+        // those units made every step begin with a trip to HBM (the ablation's "no xq: -2 us per step")
         float xq[RS_MT][G][RS_NB][4];
+        auto fetch_xq = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int mt = 0; mt < RS_MT; ++mt)
+            for (int mt = 0; mt < RS_MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                asm volatile("" : "+v"(xoff[mt][r]));         // (opaque, like voff below: no hoisted lane address pairs)
+                for (int r = 0; r < 4; ++r) {
+                    asm volatile("" : "+v"(xoff[mt][r]));     // (opaque, like voff below: no hoisted lane address pairs)
 #pragma unroll
-                for (int q = 0; q < G; ++q)
+                    for (int q = 0; q < G; ++q)
 #pragma unroll
-                    for (int bl = 0; bl < RS_NB; ++bl)
+                        for (int bl = 0; bl < RS_NB; ++bl)
 #ifdef NWW_ABLATION
-                        xq[mt][q][bl][r] = (a.dbg & 4) ? 0.0f : *reinterpret_cast<const float*>(xg_wg + (size_t)(q * HR + 16 * bl) * 4 + xoff[mt][r]);
+                            xq[mt][q][bl][r] = (a.dbg & 4) ? 0.0f : *reinterpret_cast<const float*>(xg_wg + (size_t)(q * HR + 16 * bl) * 4 + xoff[mt][r]);
 #else
-                        xq[mt][q][bl][r] = *reinterpret_cast<const float*>(xg_wg + (size_t)(q * HR + 16 * bl) * 4 + xoff[mt][r]);
+                            xq[mt][q][bl][r] = *reinterpret_cast<const float*>(xg_wg + (size_t)(q * HR + 16 * bl) * 4 + xoff[mt][r]);
 #endif
-                xoff[mt][r] += (uint32_t)t_delta;
-            }
+                    xoff[mt][r] += (uint32_t)t_delta;
+                }
+        };
+        constexpr int XQ_UNIT = RING - 1;                     // the last unit of the step that was fetched in the previous one
         const unsigned char* arow = arow0 + (step & 1) * SET;
         uint16_t* hpw = hp + ((step & 1) ^ 1) * (SET / 2);
         f32x4 acc[RS_MT][G][RS_NB];
@@ -187,6 +192,7 @@ __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
                     acc[mt][q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wl, acc[mt][q][bl], 0, 0, 0);
                     acc[mt][q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wh, acc[mt][q][bl], 0, 0, 0);
                 }
+                if (u == XQ_UNIT) fetch_xq();
                 __builtin_amdgcn_sched_barrier(0);            // keep the stream in order: no fetch rises above the ring's depth (registers)
             }
         }

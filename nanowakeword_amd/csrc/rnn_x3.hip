@@ -25,6 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef NWW_TRACE      // tools/ubench/rnn_trace.hip: s_memtime of workgroup 0's waves at the phase boundaries of the first 128 steps
+__device__ unsigned long long g_rnn_trace[8 * 128 * 8];
+#define RNN_STAMP(k) if (blockIdx.x == 0 && step < 128 && lane == 0) g_rnn_trace[((threadIdx.x >> 6) * 128 + step) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define RNN_STAMP(k)
+#endif
+
 namespace {
 __device__ __forceinline__ void split3r(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     hi = __float_as_uint(x) & 0xffff0000u;
@@ -136,11 +143,14 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     const unsigned char* arow0 = smem_r + (size_t)(n * LDP + 8 * g) * 2;         // A fragment: clip n, k = 32 ks + 8 g .. + 7
     constexpr int PLANE = 16 * LDP * 2;                                           // bytes per term plane
     constexpr int SET = NTM * PLANE;                                              // bytes per set of planes
-    // input-side pre-activations (independent of h) are requested PF steps ahead: with the products on the bf16 pipe a step is
-    // shorter than the trip of a row per clip from HBM
-    // (the four-wave LSTM at H = 128 holds 384 registers of weight fragments: no room; the eight-wave GRU with 64 fused input features keeps one step)
-    constexpr int PF = (G == 4 && H == 128 && NB == 2) ? 0 : (H == 128 && NB == 1 && (FIN == 64 || G == 4)) ? 1 : 2;
-    float xpf[PF + 1][FIN ? 1 : G][FIN ? 1 : NB][4];           // [0]: this step's (precomputed xg form)
+    // input-side pre-activations (independent of h): the NEXT step's are requested right behind the last use of this step's, into the same
+    // registers.  hipcc waits for loads carried round the loop with s_waitcnt vmcnt(0): a request issued at the step's top, AHEAD of this
+    // step's first use (rounds 2-5: "two steps ahead"), made that wait cover the new loads as well - a trip to HBM on every step's critical
+    // path, 2000-3300 of the GRU head's 6400 clocks per step (tools/ubench/rnn_trace).  Issued behind the use, the wait finds them a step old.
+    // (the four-wave LSTM at H = 128 - 384 registers of weight fragments - has no room to carry a step's rows round the loop: it requests them at
+    // the step's top and uses them behind the products)
+    constexpr bool CARRY = !(G == 4 && H == 128 && NB == 2);
+    float xpf[1][FIN ? 1 : G][FIN ? 1 : NB][4];                // this step's (precomputed xg form)
     auto fetch = [&](int step, float (&x)[FIN ? 1 : G][FIN ? 1 : NB][4]) {
         const int t = a.reverse ? a.T - 1 - step : step;
 #pragma unroll
@@ -153,8 +163,8 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 for (int bl = 0; bl < (FIN ? 1 : NB); ++bl) x[q][bl][r] = (!PAD || j0 + 16 * bl < HR) ? xg[q * HR + 16 * bl] : 0.0f;
         }
     };
-    // fused form: the lane's 8 features per k-block of clip n's row of the step (the A fragment of the input product), raw, PF steps ahead
-    float4 xraw[PF + 1][KSI > 0 ? KSI : 1][2];
+    // fused form: the lane's 8 features per k-block of clip n's row of the step (the A fragment of the input product), raw
+    float4 xraw[1][KSI > 0 ? KSI : 1][2];
     auto fetch_x = [&](int step, float4 (&x)[KSI > 0 ? KSI : 1][2]) {
         const int t = a.reverse ? a.T - 1 - step : step;
         const float* row = a.x_in + ((size_t)min(b0 + n, a.B - 1) * a.T + t) * FIN + 8 * g;
@@ -164,18 +174,17 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
             x[ks][1] = *reinterpret_cast<const float4*>(row + 32 * ks + 4);
         }
     };
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-        if (d < a.steps) { if constexpr (FIN > 0) fetch_x(d, xraw[d]); else fetch(d, xpf[d]); }
+    if (a.steps > 0) { if constexpr (FIN > 0) fetch_x(0, xraw[0]); else if constexpr (CARRY) fetch(0, xpf[0]); }
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
+        RNN_STAMP(0)
         f32x4 acc[G][NB];
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
             for (int bl = 0; bl < NB; ++bl) acc[q][bl] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (step + PF < a.steps) { if constexpr (FIN > 0) fetch_x(step + PF, xraw[PF]); else fetch(step + PF, xpf[PF]); }
+        if constexpr (FIN == 0 && !CARRY) fetch(step, xpf[0]);
         // fused input projection of this step: independent of h - on the matrix pipe ahead of the recurrent product
         f32x4 accx[G][NB];
         if constexpr (FIN > 0) {
@@ -193,18 +202,21 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 for (int e = 0; e < 4; ++e)
                     nww_split2h(__builtin_amdgcn_fmed3f(xv[2 * e], -cl, cl) * sc, __builtin_amdgcn_fmed3f(xv[2 * e + 1], -cl, cl) * sc, hh[e], ll[e]);
                 const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3])), xl = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
-#pragma unroll
-                for (int q = 0; q < G; ++q)
-#pragma unroll
-                    for (int bl = 0; bl < NB; ++bl) {
-                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, __builtin_bit_cast(f16x8, wi[q][bl][ks][0]), accx[q][bl], 0, 0, 0);
-                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8, wi[q][bl][ks][1]), accx[q][bl], 0, 0, 0);
-                        accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8, wi[q][bl][ks][0]), accx[q][bl], 0, 0, 0);
-                    }
+                // term-major, like the recurrent product below: consecutive MFMAs go to DIFFERENT accumulators (three back-to-back products into
+                // one accumulator are a dependent chain of full MFMA latencies - tools/ubench/rnn_trace: this phase took 2000-3300 of a step's 6400 clocks)
+#define RNN_PROD_X(AF, WT)                                                                                            \
+    _Pragma("unroll") for (int q = 0; q < G; ++q)                                                                     \
+        _Pragma("unroll") for (int bl = 0; bl < NB; ++bl)                                                             \
+            accx[q][bl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF, __builtin_bit_cast(f16x8, wi[q][bl][ks][WT]), accx[q][bl], 0, 0, 0);
+                RNN_PROD_X(xl, 0) RNN_PROD_X(xh, 1) RNN_PROD_X(xh, 0)
+#undef RNN_PROD_X
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < a.steps) fetch_x(step + 1, xraw[0]);      // (behind the split of this step's row)
         }
         const unsigned char* arow = arow0 + (step & 1) * SET;
         uint16_t* hpw = hp + ((step & 1) ^ 1) * (SET / 2);
+        RNN_STAMP(1)
         {                                                     // (first step: the planes hold zeros)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -228,6 +240,7 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 #undef RNN_PROD
             }
         }
+        RNN_STAMP(2)
 #pragma unroll
         for (int bl = 0; bl < NB; ++bl) {
             const int j = j0 + 16 * bl;
@@ -297,22 +310,14 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
                 }
             }
         }
-        if constexpr (FIN > 0) {
-#pragma unroll
-            for (int d = 0; d < PF; ++d)
-#pragma unroll
-                for (int ks = 0; ks < KSI; ++ks) { xraw[d][ks][0] = xraw[d + 1][ks][0]; xraw[d][ks][1] = xraw[d + 1][ks][1]; }
-        } else {
-#pragma unroll
-            for (int d = 0; d < PF; ++d)
-#pragma unroll
-                for (int q = 0; q < G; ++q)
-#pragma unroll
-                    for (int bl = 0; bl < NB; ++bl)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xpf[d][q][bl][r] = xpf[d + 1][q][bl][r];
+        RNN_STAMP(3)
+        if constexpr (FIN == 0 && CARRY) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < a.steps) fetch(step + 1, xpf[0]);          // (behind the gates that used this step's)
         }
+        RNN_STAMP(4)
         __syncthreads();
+        RNN_STAMP(5)
     }
 }
 }  // namespace

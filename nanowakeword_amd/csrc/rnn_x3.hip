@@ -151,28 +151,36 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
     // the step's top and uses them behind the products)
     constexpr bool CARRY = !(G == 4 && H == 128 && NB == 2);
     float xpf[1][FIN ? 1 : G][FIN ? 1 : NB][4];                // this step's (precomputed xg form)
-    auto fetch = [&](int step, float (&x)[FIN ? 1 : G][FIN ? 1 : NB][4]) {
-        const int t = a.reverse ? a.T - 1 - step : step;
+    // (the lane's four row pointers walk the frames: forming them from (clip, frame) cost ~70 VALU instructions per step - tools/ubench/rnn_trace)
+    const float* xrow[4];
+    const ptrdiff_t xstep = (ptrdiff_t)(a.reverse ? -1 : 1) * G * HR;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        xrow[r] = FIN ? nullptr : a.xg + ((size_t)min(b0 + 4 * g + r, a.B - 1) * a.T + (a.reverse ? a.T - 1 : 0)) * G * HR + j0;
+    auto fetch = [&](int step, float (&x)[FIN ? 1 : G][FIN ? 1 : NB][4]) {      // steps in order: 0, 1, 2, ...
+        (void)step;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 4 * g + r;
-            const float* xg = a.xg + ((size_t)min(b, a.B - 1) * a.T + t) * G * HR + j0;
+            const float* xg = xrow[r];
 #pragma unroll
             for (int q = 0; q < (FIN ? 1 : G); ++q)
 #pragma unroll
                 for (int bl = 0; bl < (FIN ? 1 : NB); ++bl) x[q][bl][r] = (!PAD || j0 + 16 * bl < HR) ? xg[q * HR + 16 * bl] : 0.0f;
+            xrow[r] += xstep;
         }
     };
     // fused form: the lane's 8 features per k-block of clip n's row of the step (the A fragment of the input product), raw
     float4 xraw[1][KSI > 0 ? KSI : 1][2];
-    auto fetch_x = [&](int step, float4 (&x)[KSI > 0 ? KSI : 1][2]) {
-        const int t = a.reverse ? a.T - 1 - step : step;
-        const float* row = a.x_in + ((size_t)min(b0 + n, a.B - 1) * a.T + t) * FIN + 8 * g;
+    const float* xin_row = FIN ? a.x_in + ((size_t)min(b0 + n, a.B - 1) * a.T + (a.reverse ? a.T - 1 : 0)) * FIN + 8 * g : nullptr;
+    auto fetch_x = [&](int step, float4 (&x)[KSI > 0 ? KSI : 1][2]) {           // steps in order
+        (void)step;
+        const float* row = xin_row;
 #pragma unroll
         for (int ks = 0; ks < KSI; ++ks) {
             x[ks][0] = *reinterpret_cast<const float4*>(row + 32 * ks);
             x[ks][1] = *reinterpret_cast<const float4*>(row + 32 * ks + 4);
         }
+        xin_row += (a.reverse ? -1 : 1) * FIN;
     };
     if (a.steps > 0) { if constexpr (FIN > 0) fetch_x(0, xraw[0]); else if constexpr (CARRY) fetch(0, xpf[0]); }
     __syncthreads();

@@ -34,6 +34,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef NWW_TRACE      // tools/ubench/ffn_trace.hip: s_memtime of workgroup 0's waves at the phase boundaries of the main loop's hidden blocks
+__device__ unsigned long long g_ffn_trace[4 * 32 * 8];
+#define FFN_STAMP(blk, k) if (blockIdx.x == 0 && lane == 0) g_ffn_trace[(wave * 32 + (blk)) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define FFN_STAMP(blk, k)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void split3f(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
@@ -136,7 +143,12 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
 // epilogue - product in turn so that they cover each other's issue stalls - the lone in-order wave here spends a third of its
 // cycles in them, SQ_WAIT_INST_ANY 50 M of 146 M.  At D = 144 the 80 output accumulators + 72 X-fragment registers + the
 // epilogue's temporaries do not fit 256 registers: 59 spilled, 0.315 ms against 0.320.)
-template <int D16, bool H2>
+// LATE_A (round 5): the first stage of a block's epilogue - bias, 1 + 2^(-v log2 e): 16 of the 40 pieces, half the transcendentals - runs
+// between the MFMAs of the PREVIOUS block's second product, on the accumulator the first product has just finished; the rest stays between the
+// MFMAs of the next first product.  (tools/ubench/ffn_trace: with all 40 pieces behind the first product's 27 MFMAs that phase took 2200 clocks,
+// VALU-bound, and the second product's 30 MFMAs 1250 with the VALU idle.)  One accumulator instead of two; the next block's biases come from the
+// packed blob in global memory (its LDS copy is still in flight then).
+template <int D16, bool H2, bool LATE_A = true>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;
     constexpr int NT = H2 ? 2 : 3, NP = H2 ? 3 : 6;            // terms per value, partial products per operand pair
@@ -165,6 +177,17 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
         for (int j = 0; j < decltype(steps)::value; ++j)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sp + j * 4096),
                                              (void __attribute__((address_space(3)))*)(dst + j * 4096), 16, 0, 0);
+    };
+    // one 4 KB step of a part (the main loop issues a block's steps one at a time between the MFMAs of the first product: issued together
+    // at the block's top they held every wave for ~650 clocks - 44 KB through the CU's 64 B/clk path - with the matrix pipe idle: tools/ubench/ffn_trace)
+    auto fetch_step = [&](const unsigned char* src, unsigned char* buf, int j) {
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + tid * 16 + j * 4096),
+                                         (void __attribute__((address_space(3)))*)(buf + wave * 1024 + j * 4096), 16, 0, 0);
+    };
+    constexpr int NF1 = W1_PART / 4096, NF2 = W2_PART / 4096;
+    struct FetchPlan { const unsigned char* s1; unsigned char* d1; const unsigned char* s2; unsigned char* d2; };
+    auto plan_of = [&](int hb1, unsigned char* b1, int hb2, unsigned char* b2) {      // W1 part of block hb1 -> b1, W2 part of block hb2 -> b2 (-1: none)
+        return FetchPlan{hb1 >= 0 ? a.packed + (size_t)hb1 * BLK : nullptr, b1, hb2 >= 0 ? a.packed + (size_t)hb2 * BLK + W1_PART : nullptr, b2};
     };
     auto fetch_w1 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK, buf, std::integral_constant<int, W1_PART / 4096>{}); };
     auto fetch_w2 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK + W1_PART, buf, std::integral_constant<int, W2_PART / 4096>{}); };
@@ -226,7 +249,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     //   iteration hb:  fetch W1(hb + 2), W2(hb + 1);   Ht(hb + 1) = W1(hb + 1) . Xt  ||  hf = split(swish(Ht(hb) + b1(hb)));
     //                  Yt += W2(hb) . hf;               barrier
     auto gemm1_epi = [&](auto has_next, const unsigned char* w1buf, const unsigned char* w2buf, const f32x16& cur, f32x16& next,
-                         bf16x8 (&hf)[2][NT]) {
+                         bf16x8 (&hf)[2][NT], const FetchPlan fp) {
         constexpr bool NEXT = decltype(has_next)::value;
         constexpr int NSLOT = NEXT ? NP * D16 : 1;             // MFMAs of the first product = slots for epilogue pieces
         constexpr int NPIECE = H2 ? 40 : 48;                   // epilogue pieces (below)
@@ -299,6 +322,21 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 if (m < NT && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * NT + m) * 1024);
                 next = ffn_mma<H2>(cw[PW[m]], xf[kb][PX[m]], next);
                 asm volatile("" : "+a"(next));
+                // the fetches of the blocks ahead, one step behind every second MFMA (wave-uniform branches)
+                if constexpr (NF1 + NF2 <= (NSLOT + 1) / 2) {
+                    if ((q & 1) == 0) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int j = q >> 1;
+                        if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
+                        else if (j < NF1 + NF2) { if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1); }
+                    }
+                } else {
+                    const int j0 = q * (NF1 + NF2) / NSLOT, j1 = (q + 1) * (NF1 + NF2) / NSLOT;
+                    for (int j = j0; j < j1; ++j) {
+                        if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
+                        else if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1);
+                    }
+                }
             }
 #pragma unroll
             for (int p = q * PER; p < (q + 1) * PER && p < NPIECE; ++p) piece(p);
@@ -358,6 +396,145 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // ---- LATE_A schedule
+    float va[16], ua[16];                                      // stage-A results of the block whose fragments the next first product builds
+    auto load_bias = [&](int hb, float (&bias)[16]) {          // b1 of block hb, hidden units 8 g + 4 h + 0..3, from the packed blob
+        const float* b1p = reinterpret_cast<const float*>(a.packed + (size_t)hb * BLK + W1_PART + B1_OFF) + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 q = *reinterpret_cast<const float4*>(b1p + 8 * g);
+            bias[4 * g] = q.x; bias[4 * g + 1] = q.y; bias[4 * g + 2] = q.z; bias[4 * g + 3] = q.w;
+        }
+    };
+    auto piece_a = [&](int e, const f32x16& acc, const float (&bias)[16]) {
+        va[e] = H2 ? fmaf(acc[e], ik1, bias[e]) : acc[e] + bias[e];
+        ua[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * va[e]);
+        asm volatile("" : "+v"(va[e]), "+v"(ua[e]));
+    };
+    // first product of the NEXT block (acc = W1 . Xt) with the rest of THIS block's epilogue (va, ua -> hf) between its MFMAs
+    auto phase1 = [&](auto has_next, const unsigned char* w1buf, f32x16& acc, bf16x8 (&hf)[2][NT], const FetchPlan fp) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        constexpr int NSLOT = NEXT ? NP * D16 : 1;
+        constexpr int NPIECE = H2 ? 24 : 32;
+        constexpr int PER = (NPIECE + NSLOT - 1) / NSLOT;
+        const unsigned char* w1p = w1buf + lane * 16;
+        bf16x8 nw[NT], cw[NT];
+        if (NEXT) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t th[16], tm[16], tl[16];
+        auto piece = [&](int p) {
+            if constexpr (H2) {
+                const int j = p / 3, st = p - 3 * j;
+                if (st < 2) {
+                    const int e = 2 * j + st;
+                    va[e] = (va[e] * s_h) * __builtin_amdgcn_rcpf(ua[e]);
+                    asm volatile("" : "+v"(va[e]));
+                } else {
+                    nww_split2h(va[2 * j], va[2 * j + 1], th[j], tl[j]);
+                    asm volatile("" : "+v"(th[j]), "+v"(tl[j]));
+                }
+            } else {
+                const int e = p / 2, st = p - 2 * e;
+                if (st == 0) {
+                    const float y = va[e] * __builtin_amdgcn_rcpf(ua[e]);
+                    th[e] = __float_as_uint(y) & 0xffff0000u;
+                    ua[e] = y - __uint_as_float(th[e]);
+                    asm volatile("" : "+v"(th[e]), "+v"(ua[e]));
+                } else {
+                    tm[e] = __float_as_uint(ua[e]) & 0xffff0000u;
+                    tl[e] = __float_as_uint(ua[e] - __uint_as_float(tm[e]));
+                    asm volatile("" : "+v"(tm[e]), "+v"(tl[e]));
+                }
+            }
+        };
+        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            if (NEXT) {
+                const int kb = q / NP, m = q - NP * kb;
+                if (m == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) cw[t] = nw[t];
+                }
+                if (m < NT && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * NT + m) * 1024);
+                acc = ffn_mma<H2>(cw[PW[m]], xf[kb][PX[m]], acc);
+                asm volatile("" : "+a"(acc));
+                const int j0 = q * (NF1 + NF2) / NSLOT, j1 = (q + 1) * (NF1 + NF2) / NSLOT;      // the fetches of the blocks ahead, spread over the slots
+                for (int j = j0; j < j1; ++j) {
+                    if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
+                    else if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1);
+                }
+            }
+#pragma unroll
+            for (int p = q * PER; p < (q + 1) * PER && p < NPIECE; ++p) piece(p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+            if constexpr (H2) {
+                union { uint4 q; bf16x8 b; } ch, cl;
+                const int o = 4 * kb2;
+                ch.q = make_uint4(th[o], th[o + 1], th[o + 2], th[o + 3]);
+                cl.q = make_uint4(tl[o], tl[o + 1], tl[o + 2], tl[o + 3]);
+                hf[kb2][0] = ch.b; hf[kb2][1] = cl.b;
+            } else {
+                union { uint4 q; bf16x8 b; } ch, cm, cl;
+                const int o = 8 * kb2;
+                ch.q = make_uint4(pack16(th[o], th[o + 1]), pack16(th[o + 2], th[o + 3]), pack16(th[o + 4], th[o + 5]), pack16(th[o + 6], th[o + 7]));
+                cm.q = make_uint4(pack16(tm[o], tm[o + 1]), pack16(tm[o + 2], tm[o + 3]), pack16(tm[o + 4], tm[o + 5]), pack16(tm[o + 6], tm[o + 7]));
+                cl.q = make_uint4(pack16(tl[o], tl[o + 1]), pack16(tl[o + 2], tl[o + 3]), pack16(tl[o + 4], tl[o + 5]), pack16(tl[o + 6], tl[o + 7]));
+                hf[kb2][0] = ch.b; hf[kb2][1] = cm.b; hf[kb2][NT - 1] = cl.b;
+            }
+        }
+    };
+    // second product of this block (Yt += W2 . hf) with stage A of the NEXT block (its accumulator is complete) between its MFMAs
+    auto phase2 = [&](auto has_a, const unsigned char* w2buf, const bf16x8 (&hf)[2][NT], const f32x16& acc, const float (&bias)[16]) {
+        constexpr bool HAS_A = decltype(has_a)::value;
+        const unsigned char* w2p = w2buf + lane * 16;
+        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
+        constexpr int NG = 2 * ((NOB + 1) / 2);
+        constexpr int NS2 = NG * NP, PER_A = (16 + NS2 - 1) / NS2;      // slots of the second product, stage-A pieces per slot
+        auto frag = [&](int g, int which, int t) {
+            const int ob = 2 * (g >> 1) + which, kb2 = g & 1;
+            return *reinterpret_cast<const bf16x8*>(w2p + ((ob * 2 + kb2) * NT + t) * 1024);
+        };
+        bf16x8 na[NT], nb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { na[t] = frag(0, 0, t); if (NOB > 1) nb[t] = frag(0, 1, t); }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ob = 2 * (g >> 1), kb2 = g & 1;
+            const bool two = ob + 1 < NOB;
+            bf16x8 ca[NT], cb[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    na[t] = frag(g + 1, 0, t);
+                    if (2 * ((g + 1) >> 1) + 1 < NOB) nb[t] = frag(g + 1, 1, t);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                yacc[ob] = ffn_mma<H2>(ca[PW[m]], hf[kb2][PX[m]], yacc[ob]);
+                if (two) yacc[ob + 1] = ffn_mma<H2>(cb[PW[m]], hf[kb2][PX[m]], yacc[ob + 1]);
+                if constexpr (HAS_A) {
+                    const int sl = g * NP + m;
+#pragma unroll
+                    for (int e = sl * PER_A; e < (sl + 1) * PER_A && e < 16; ++e) piece_a(e, acc, bias);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     f32x16 accA, accB;
     bf16x8 hf[2][NT];
     float4 res[NOB][4];
@@ -385,44 +562,95 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (LATE_A) {
+        // Even block hb: W1(hb + 1) in w1b1, W2(hb) in w2b0; odd block: the other buffers.  accA holds Ht(hb + 1) from phase 1 to the end of phase 2.
+        float bias[16];
+        load_bias(0, bias);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) piece_a(e, accA, bias);  // stage A of block 0, not overlapped
+        for (int hb = 0; hb + 2 < NHB; hb += 2) {
+            FFN_STAMP(hb, 0)
+            load_bias(hb + 1, bias);
+            __builtin_amdgcn_sched_barrier(0);
+            FFN_STAMP(hb, 1)
+            phase1(std::true_type{}, w1b1, accA, hf, plan_of(hb + 2, w1b0, hb + 1, w2b1));
+            __builtin_amdgcn_sched_barrier(0);
+            FFN_STAMP(hb, 2)
+            phase2(std::true_type{}, w2b0, hf, accA, bias);
+            FFN_STAMP(hb, 3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FFN_STAMP(hb, 4)
+            __syncthreads();
+            FFN_STAMP(hb, 5)
+            load_bias(hb + 2, bias);
+            __builtin_amdgcn_sched_barrier(0);
+            phase1(std::true_type{}, w1b0, accA, hf, plan_of(hb + 3, w1b1, hb + 2, w2b0));
+            __builtin_amdgcn_sched_barrier(0);
+            phase2(std::true_type{}, w2b1, hf, accA, bias);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        {                                                      // the last two blocks
+            load_bias(NHB - 1, bias);
+            __builtin_amdgcn_sched_barrier(0);
+            phase1(std::true_type{}, w1b1, accA, hf, plan_of(-1, nullptr, NHB - 1, w2b1));
+            __builtin_amdgcn_sched_barrier(0);
+            phase2(std::true_type{}, w2b0, hf, accA, bias);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // the X fragments are dead now: their registers take the residual rows for the final update
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
+            phase1(std::false_type{}, w1b0, accA, hf, plan_of(-1, nullptr, -1, nullptr));
+            __builtin_amdgcn_sched_barrier(0);
+            phase2(std::false_type{}, w2b1, hf, accA, bias);
+        }
+    } else {
     // NHB = D / 8 is even.  Even block hb: cur = accA, W1(hb + 1) in w1b1, W2(hb) in w2b0; odd block: the other buffers.
-    for (int hb = 0; hb + 2 < NHB; hb += 2) {
-        fetch_w1(hb + 2, w1b0);
-        fetch_w2(hb + 1, w2b1);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm2(w2b0, hf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        fetch_w1(hb + 3, w1b1);
-        fetch_w2(hb + 2, w2b0);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm1_epi(std::true_type{}, w1b0, w2b1, accB, accA, hf);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm2(w2b1, hf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    {                                                          // the last two blocks
-        fetch_w2(NHB - 1, w2b1);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm2(w2b0, hf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // the X fragments are dead now: their registers take the residual rows for the final update, so that those
-        // loads are in flight under the last block's MFMAs
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm1_epi(std::false_type{}, w1b0, w2b1, accB, accA, hf);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm2(w2b1, hf);
+        for (int hb = 0; hb + 2 < NHB; hb += 2) {
+            FFN_STAMP(hb, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            FFN_STAMP(hb, 1)
+            gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf, plan_of(hb + 2, w1b0, hb + 1, w2b1));
+            __builtin_amdgcn_sched_barrier(0);
+            FFN_STAMP(hb, 2)
+            gemm2(w2b0, hf);
+            FFN_STAMP(hb, 3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FFN_STAMP(hb, 4)
+            __syncthreads();
+            FFN_STAMP(hb, 5)
+            __builtin_amdgcn_sched_barrier(0);
+            gemm1_epi(std::true_type{}, w1b0, w2b1, accB, accA, hf, plan_of(hb + 3, w1b1, hb + 2, w2b0));
+            __builtin_amdgcn_sched_barrier(0);
+            gemm2(w2b1, hf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        {                                                          // the last two blocks
+            __builtin_amdgcn_sched_barrier(0);
+            gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf, plan_of(-1, nullptr, NHB - 1, w2b1));
+            __builtin_amdgcn_sched_barrier(0);
+            gemm2(w2b0, hf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // the X fragments are dead now: their registers take the residual rows for the final update, so that those
+            // loads are in flight under the last block's MFMAs
+    #pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm1_epi(std::false_type{}, w1b0, w2b1, accB, accA, hf, plan_of(-1, nullptr, -1, nullptr));
+            __builtin_amdgcn_sched_barrier(0);
+            gemm2(w2b1, hf);
+        }
+    
     }
 
     // ---- h <- h + rscale * (Yt + b2): lane (row n, half h) holds out features 32 ob + 8 g + 4 h + 0..3
@@ -463,10 +691,14 @@ hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2,
 hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     const dim3 grid((a.M + 127) / 128);
+    static const int late_a = [] { const char* e = getenv("NWW_FFN_LATE_A"); return e ? atoi(e) : 1; }();
 #define FFN_GO(D16V)                                                                                               \
     {                                                                                                              \
-        if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);              \
-        else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false>), grid, dim3(256), 0, s, a);                           \
+        if (late_a) {                                                                                              \
+            if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true, true>), grid, dim3(256), 0, s, a);    \
+            else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false, true>), grid, dim3(256), 0, s, a);                 \
+        } else if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true, false>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false, false>), grid, dim3(256), 0, s, a);                    \
     }
     switch (D) {
         case 32: FFN_GO(2) break;

@@ -37,6 +37,13 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef NWW_TRACE      // tools/ubench/conv3_trace.hip: s_memtime of workgroup 0's waves at the phase boundaries of its first 16 items
+__device__ unsigned long long g_c3_trace[8 * 16 * 8];
+#define C3_STAMP(k) if (blockIdx.x == 0 && c3_item < 16 && lane == 0) g_c3_trace[(wave * 16 + c3_item) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define C3_STAMP(k)
+#endif
+
 namespace {
 // C1 input channels (32; 64 in the two-term form only): TS bytes per term of a pixel, KB sixteen-channel k-blocks
 template <bool H2, int C1 = 32> struct C3A { static constexpr int NT = H2 ? 2 : 3, TS = 2 * C1, PS3 = TS * NT + 16, KB = C1 / 16, WT_BYTES = 9 * KB * NT * 1024; };
@@ -172,6 +179,7 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             }
     };
 
+    float pre[32];                                            // the thread's 32 channel values of the next item's pixel
     // conv for tile t (and t + 1 when TWO): 9 taps x KB sixteen-channel blocks x 6 (3) products
     auto tiles = [&](int u, auto two_c, float* outb, float* wsum, AvgWin aw, const float* accb, int y0) {
         constexpr bool TWO = decltype(two_c)::value;
@@ -258,7 +266,6 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
     const int chunk = (C1 > 32 && stager) ? tid / HW : 0, pix = tid - chunk * HW;
     const int py = stager ? pix / W : 0, px = stager ? pix - py * W : 0;
     unsigned char* my_px = A3 + (STRIP ? py : py + 1) * rowB + (px + 1) * PS3 + 64 * chunk;
-    float pre[32];
     // dense planes [B][32][H][W], or (streaming hop) per-clip rings of rows written by the fused trunk: row py of the window at
     // ring row (in_row0 + py) % in_ring_rows
     const size_t in_clip = a.in_ring_rows ? a.in_clip_stride : (size_t)a.w_cin * HW;
@@ -289,9 +296,21 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
         return reinterpret_cast<float*>(t < npix ? A3 + (size_t)(t / (Wp - 1)) * rowB + (size_t)(t % (Wp - 1)) * PS3 + TS * NT : Wt + WT_BYTES + (size_t)(t - npix) * 16);
     };
     float* my_part = part_ptr(tid);
+    // the reducing lanes' 2 * NW partial addresses do not change from item to item (forming one costs an integer division: 16 of them per
+    // item were 3400 of the E2E stage's 16 700 clocks, on two waves with six waiting - tools/ubench/conv3_trace)
+    int red_off[AVG ? 2 * NW : 1];
+    if (AVG && tid < 32 * a.avg_ow) {
+        const int ci = tid / a.avg_ow, j = tid - ci * a.avg_ow;
+#pragma unroll
+        for (int k = 0; k < 2 * NW; ++k)
+            red_off[AVG ? k : 0] = (int)(reinterpret_cast<unsigned char*>(part_ptr((k >> 1) * 64 + (k & 1) * 32 + ci) + j) - lds3);
+    }
     prefetch(b_first);
     __syncthreads();
+    [[maybe_unused]] int c3_item = -1;
     for (int item = b_first; item < n_items; item += b_step) {
+        ++c3_item;
+        C3_STAMP(0)
         const int b = STRIP ? item / nS : item;
         const int y0 = STRIP ? (item - b * nS) * SH : 0;       // first plane row of the strip
         int tb = t_begin, te = t_end;
@@ -326,8 +345,11 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
                 }
             }
         }
+        C3_STAMP(1)
         __syncthreads();
+        C3_STAMP(2)
         prefetch(item + b_step);
+        C3_STAMP(3)
         // planes [Cout][Ho][Wo], or (seq_out, pooled mode) the clip's sequence rows [Wo][Cout * Ho] at channel 32 grp
         float* outb = seq_ch ? a.out + (size_t)b * Wo * seq_ch + (size_t)32 * grp * Ho
                              : a.out + ((size_t)b * a.Cout + 32 * grp) * Ho * Wo;
@@ -345,17 +367,19 @@ __global__ void __launch_bounds__(512) conv3_x3_kernel(ConvMfmaArgs a) {
             }
         }
         if (AVG) *reinterpret_cast<float4*>(my_part) = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+        C3_STAMP(4)
         __syncthreads();                                       // every wave is done reading A3; partials visible
+        C3_STAMP(5)
         if (AVG) {
             // fixed-order reduction: one lane per (channel, window) adds its channel's 2 * NW partials in (wave, half)
             // order.  The next clip's staging may start meanwhile: it touches neither pads nor the partial region, and
             // the barrier behind it separates these reads from the next partial writes.
             const float inv = 1.0f / (float)((a.avg_y ? W : H) * a.avg_kw);
-            for (int o = tid; o < 32 * a.avg_ow; o += NTHR) {
-                const int ci = o / a.avg_ow, j = o - ci * a.avg_ow;
+            if (tid < 32 * a.avg_ow) {                        // (32 * avg_ow <= 128 lanes)
+                const int ci = tid / a.avg_ow, j = tid - ci * a.avg_ow;
                 float sum = 0.0f;
-                for (int w2 = 0; w2 < NW; ++w2)
-                    for (int h2 = 0; h2 < 2; ++h2) sum += part_ptr(w2 * 64 + h2 * 32 + ci)[j];
+#pragma unroll
+                for (int k = 0; k < 2 * NW; ++k) sum += *reinterpret_cast<const float*>(lds3 + red_off[AVG ? k : 0]);      // (wave, half) order
                 a.out[((size_t)b * a.Cout + 32 * grp + ci) * a.avg_ow + j] = sum * inv;
             }
         }

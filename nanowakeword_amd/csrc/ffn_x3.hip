@@ -325,7 +325,6 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 // the fetches of the blocks ahead, one step behind every second MFMA (wave-uniform branches)
                 if constexpr (NF1 + NF2 <= (NSLOT + 1) / 2) {
                     if ((q & 1) == 0) {
-                        constexpr int dummy = 0; (void)dummy;
                         const int j = q >> 1;
                         if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
                         else if (j < NF1 + NF2) { if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1); }

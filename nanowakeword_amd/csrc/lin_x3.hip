@@ -23,6 +23,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef NWW_TRACE      // tools/ubench/lin_trace.hip: s_memtime of workgroup 0's waves at the phase boundaries of its first 16 output blocks
+__device__ unsigned long long g_lin_trace[8 * 16 * 8];
+#define LIN_STAMP(blk, k) if (blockIdx.x == 0 && (blk) < 16 && lane == 0) g_lin_trace[(wave * 16 + (blk)) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define LIN_STAMP(blk, k)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void split3l(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
@@ -209,7 +216,35 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
         orow = a.out + ((size_t)b * NH * T + t) * dh;
     }
     const float* rrow = EPI == 1 ? a.res + rr * a.ldres : nullptr;
+    // Plain / residual epilogues store through a per-wave LDS transpose: as the accumulator holds them, a store instruction writes 16-byte
+    // pieces of 64 different rows (64 cache lines per instruction - tools/ubench/lin_trace: issuing a block's four stores took 2450 of its 7700
+    // clocks, the residual's loads likewise); transposed, lane l of store j owns 16 bytes of row 8 j + l / 8 and eight lanes cover a row's 128
+    // contiguous bytes.  Same arithmetic per element: bit-identical results.
+    constexpr bool TR = EPI != 2;
+    constexpr int TP = 36;                                     // floats per row of the transpose tile (16-byte writes of 16 lanes: conflict-free)
+    __shared__ __attribute__((aligned(16))) float tbuf[TR ? NWV * 32 * TP : 4];
+    float* tb = tbuf + (TR ? wave * 32 * TP : 0);
+    const int tq = lane & 7;                                   // the lane's 16-byte chunk of a 32-feature block
+    bool t_ok[4];
+    float* t_orow[4];
+    const float* t_rrow[4];
+    if constexpr (TR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rj = (int)blockIdx.x * (32 * NWV) + wave * 32 + 8 * j + (lane >> 3);
+            t_ok[j] = rj < a.M;
+            const size_t rrj = (size_t)(t_ok[j] ? rj : a.M - 1);
+            t_orow[j] = a.out + rrj * a.ldc;
+            if (EPI == 0 && a.qkv_T > 0) {
+                const int T = a.qkv_T, dh = a.qkv_dh, NH = (a.N / 3) / dh;
+                const int b = (int)(rrj / T), t = (int)(rrj - (size_t)b * T);
+                t_orow[j] = a.out + ((size_t)b * NH * T + t) * dh;
+            }
+            t_rrow[j] = EPI == 1 ? a.res + rrj * a.ldres : nullptr;
+        }
+    }
     auto block = [&](int blk, const unsigned char* wbuf) {
+        LIN_STAMP(blk, 1)
         const unsigned char* wp = wbuf + lane * 16;
         f32x16 acc[PARTS];
 #pragma unroll
@@ -220,9 +255,9 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
         float4 rres[4];
         if (EPI == 1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = 32 * blk + 8 * g + 4 * h;
-                rres[g] = (row_ok && col < a.N) ? *reinterpret_cast<const float4*>(rrow + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 4; ++j) {
+                const int col = 32 * blk + 4 * tq;
+                rres[j] = (t_ok[j] && col < a.N) ? *reinterpret_cast<const float4*>(t_rrow[j] + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         bf16x8 nw[PARTS][3];
@@ -254,7 +289,9 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
         // The next weight block's LDS-DMA (issued before this block's products) and the residual loads must have landed before
         // the barrier behind this block - waited for HERE, before the stores: vmcnt counts stores too, and waiting for it after
         // them made every block sit out the write latency of its own outputs (out_proj 0.117 -> see DESIGN 7)
+        LIN_STAMP(blk, 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LIN_STAMP(blk, 3)
         if constexpr (H2) {
 #pragma unroll
             for (int p = 0; p < PARTS; ++p)
@@ -262,6 +299,29 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
                 for (int r = 0; r < 16; ++r) acc[p][r] *= pin;
         }
         // lane (row n, half h), register 4g + q = output feature 32 blk + 8g + 4h + q
+        if constexpr (TR) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(tb + n * TP + 8 * g + 4 * h) = make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]);
+            __builtin_amdgcn_wave_barrier();                   // (one wave: its LDS operations execute in order)
+            const int col = 32 * blk + 4 * tq;
+            const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * tq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 y = *reinterpret_cast<const float4*>(tb + (8 * j + (lane >> 3)) * TP + 4 * tq);
+                float4 o = make_float4(y.x + b0.x, y.y + b0.y, y.z + b0.z, y.w + b0.w);
+                if (EPI == 1) {
+                    const float4 r4 = rres[j];
+                    o.x = r4.x + a.rscale * o.x; o.y = r4.y + a.rscale * o.y; o.z = r4.z + a.rscale * o.z; o.w = r4.w + a.rscale * o.w;
+                }
+                if (t_ok[j] && col < a.N) {                    // N % 4 == 0: the four features are in or out together
+                    if (EPI == 0 && a.qkv_T > 0) *reinterpret_cast<float4*>(t_orow[j] + (size_t)qkv_which[col >> 2] * per_which + qkv_lut[col >> 2]) = o;
+                    else *reinterpret_cast<float4*>(t_orow[j] + col) = o;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         if (!row_ok) return;
         const float* bp = reinterpret_cast<const float*>(wbuf + FRAG_BYTES) + 4 * h;
 #pragma unroll
@@ -290,13 +350,19 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
     __syncthreads();
     const int nblk = a.nblk;
     for (int blk = 0; blk < nblk; blk += 2) {
+        LIN_STAMP(blk, 0)
         if (blk + 1 < nblk) fetch(blk + 1, wb1);               // buffer 1 was last read in block blk - 1, behind a barrier
         block(blk, wb0);
+        LIN_STAMP(blk, 4)
         __syncthreads();
+        LIN_STAMP(blk, 5)
         if (blk + 1 < nblk) {
+            LIN_STAMP(blk + 1, 0)
             if (blk + 2 < nblk) fetch(blk + 2, wb0);
             block(blk + 1, wb1);
+            LIN_STAMP(blk + 1, 4)
             __syncthreads();
+            LIN_STAMP(blk + 1, 5)
         }
     }
 }

@@ -27,6 +27,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef NWW_TRACE      // tools/ubench/mha_trace.hip: s_memtime of workgroup 0's waves at the phase boundaries of its first 16 units
+__device__ unsigned long long g_mha_trace[4 * 16 * 8];
+#define MHA_STAMP(k) if (blockIdx.x == 0 && mha_unit < 16 && lane == 0) g_mha_trace[(wave * 16 + mha_unit) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define MHA_STAMP(k)
+#endif
+
 namespace {
 
 // largest power of two s with m s <= 2^14 (m > 0; a unit of zeros gets 1)
@@ -102,7 +109,10 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
         }
     };
     if ((int)blockIdx.x < units) { fetch_kv((int)blockIdx.x); local_max(); }
+    [[maybe_unused]] int mha_unit = -1;
     for (int unit = (int)blockIdx.x; unit < units; unit += (int)gridDim.x) {
+        ++mha_unit;
+        MHA_STAMP(0)
         const int b = unit / n_head, head = unit - b * n_head;
         const float *qb, *kb, *vb;
         unit_ptrs(unit, qb, kb, vb);
@@ -129,6 +139,7 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
         __syncthreads();
         const float sK = pow2_scale_to_2p14(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
         const float sV = pow2_scale_to_2p14(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        MHA_STAMP(1)
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int i = tid + 256 * j;
@@ -155,7 +166,9 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
                 *reinterpret_cast<uint16_t*>(vl + 3 * VROW) = (uint16_t)(l1 >> 16);
             }
         }
+        MHA_STAMP(2)
         __syncthreads();
+        MHA_STAMP(3)
         const bool has_next = unit + (int)gridDim.x < units;
         if (qt >= NTq && has_next) { fetch_kv(unit + (int)gridDim.x); local_max(); }
         if (qt < NTq) {
@@ -201,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
             // accumulators are sK sQ times the scores: the maximum is taken on them (the factor is positive), and one fma per score
             // brings it to the true scale, subtracts the maximum and adds 14 - the probabilities leave exp2 already times 2^14, the
             // scale of their binary16 split (the denominator carries the same factor: exact, undone at the end).
+            MHA_STAMP(4)
             const float unS = 1.4426950408889634f / (sK * sQ);
             float mx = -INFINITY;
 #pragma unroll
@@ -255,8 +269,10 @@ __global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict_
                         }
                     }
                 }
+            MHA_STAMP(5)
             if (has_next) local_max();
             asm volatile("" ::: "memory");
+            MHA_STAMP(6)
             // ---- out[query][head dims 32 mt + 8 g + 4 half + 0..3]
             if (query < T) {
                 const float inv = 1.0f / (den * sV);             // (den and the products both carry the probabilities' 2^14)

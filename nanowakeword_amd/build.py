@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "libnwwhip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
 EMU_LIB = os.path.join(EMU_DIR, "libfe_emu.so")
 
-HIP_SOURCES = ["nww_api.hip", "nww_plan.hip", "nww_stream.hip", "nww_comm.hip", "nww_emb.hip", "frontend2.hip", "frontend3.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_b.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "bc_chain.hip", "rnn_x3.hip", "rnn_stream.hip", "mha_mfma.hip", "mha_h2.hip", "emb_stream.hip", "fe_tables.cpp"]
+HIP_SOURCES = ["nww_api.hip", "nww_plan.hip", "nww_stream.hip", "nww_comm.hip", "nww_emb.hip", "frontend2.hip", "frontend3.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_b.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "bc_chain.hip", "rnn_x3.hip", "rnn_stream.hip", "mha_mfma.hip", "mha_h2.hip", "attn_x3.hip", "emb_stream.hip", "fe_tables.cpp"]
 
 
 def _hipcc() -> str:

@@ -22,6 +22,7 @@
 #include "trunk.h"
 #include "ffn_x3.h"
 #include "lin_x3.h"
+#include "attn_x3.h"
 #include "dual_x3.h"
 #include "emb_stream.h"
 

@@ -1220,6 +1220,45 @@ extern "C" int nww_finalize(nww_handle* h) {
                     add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
                 };
                 ffn(".ff1");
+                // the whole attention module (in_proj, per-head softmax(q k^T) v, out_proj, residual) in one launch per clip-resident
+                // workgroup (attn_x3.hip) under the default arithmetic at the compiled shape; NWW_ATTN_FUSED=0: the three launches below
+                static const int attn_fused = [] { const char* e = getenv("NWW_ATTN_FUSED"); return e ? atoi(e) : 1; }();
+                bool attn_done = false;
+                if (attn_fused && p.h->f16 && p.h->conv_products == 6 && attn_x3_supported(T, D, NH)) {
+                    const float *iw = p.W(q + ".attention.in_proj_weight"), *ib = p.W(q + ".attention.in_proj_bias");
+                    const float *ow = p.W(q + ".attention.out_proj.weight"), *ob = p.W(q + ".attention.out_proj.bias");
+                    const auto hiw = f16_fetch(p.h, iw, (size_t)3 * D * D), how = f16_fetch(p.h, ow, (size_t)D * D);
+                    const float ws_in = f16_wscale(hiw), ws_out = f16_wscale(how);
+                    // |raw k / v accumulator| <= 2^15 (the clip-scaled rows) x the L1 norm of the scaled weight row: powers of two that keep them below 2^15
+                    auto l1max = [&](int r0) {
+                        double worst = 0;
+                        for (int r = r0; r < r0 + D; ++r) {
+                            double t = 0;
+                            for (int k = 0; k < D; ++k) t += std::fabs((double)hiw[(size_t)r * D + k]);
+                            worst = std::fmax(worst, t);
+                        }
+                        return worst;
+                    };
+                    const double lk = l1max(D) * ws_in * 1.02, lv = l1max(2 * D) * ws_in * 1.02;
+                    void *packed = nullptr, *bc = nullptr;
+                    if (ws_in > 0.0f && ws_out > 0.0f && lk < 1e30 && lv < 1e30 &&
+                        hipMalloc(&packed, attn_x3_packed_bytes(D, NH)) == hipSuccess && hipMalloc(&bc, (size_t)D * sizeof(float)) == hipSuccess &&
+                        launch_attn_x3_pack(iw, ib, ow, ob, packed, static_cast<float*>(bc), D, NH, ws_in, ws_out, p.h->own_stream) == hipSuccess) {
+                        p.h->packed_weights.push_back(packed);
+                        p.h->packed_weights.push_back(bc);
+                        const float cK = lk > 1e-30 ? (float)f16_pow2_floor(1.0 / lk) : 1.0f, cV = lv > 1e-30 ? (float)f16_pow2_floor(1.0 / lv) : 1.0f;
+                        const float w_un = 1.0f / ws_in, o_un = 1.0f / (ws_out * ws_in * cV), qs = 1.0f / std::sqrt((float)(D / NH));
+                        p.add("attn_x3:" + q + ".attention (in_proj+softmax(qk)v+out_proj+res) [f16x3]", [=](Run& r) {
+                            AttnArgs a{r.buf[hb], r.buf[hb], static_cast<const unsigned char*>(packed), static_cast<const float*>(bc), r.B, T, w_un, cK, cV, o_un, qs};
+                            return launch_attn_x3(a, D, NH, r.stream);
+                        });
+                        attn_done = true;
+                    } else {
+                        if (packed) (void)hipFree(packed);
+                        if (bc) (void)hipFree(bc);
+                    }
+                }
+                if (!attn_done) {
                 // in_proj writes q, k, v head-major when the matrix-core attention consumes them: every (clip, head) block is then
                 // one contiguous run for its LDS-DMA (NWW_QKV_HEAD_MAJOR=0: nn.Linear's [B][T][3 D] rows)
                 static const int mha_mfma0 = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
@@ -1240,6 +1279,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     p.add("mha_core:" + q, [=](Run& r) { return launch_mha_core(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream); });
                 if (!add_lin_x3(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), 1, hb, 1.0f))
                     add_gemm(p, q + ".attention.out_proj+res", t1, hb, T, D, D, p.W(q + ".attention.out_proj.weight"), p.W(q + ".attention.out_proj.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                }
                 {
                     const std::string m = q + ".conv_module";
                     const float *lw = p.W(m + ".layer_norm.weight"), *lb = p.W(m + ".layer_norm.bias");

@@ -161,10 +161,19 @@ __global__ void __launch_bounds__(256) attn_x3_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char KLl[L > 0 ? KL_BYTES : 16];
     __shared__ __attribute__((aligned(16))) float QL[L > 0 ? NH * 128 * 4 : 4];           // q left-overs [head][query][4], true scale
     __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 31, h = lane >> 5;
     const int T = a.T;
-    const int tok = 32 * wave + n, tokc = min(tok, T - 1);
+    // thread coordinates are re-derived from an OPAQUE copy of threadIdx at the top of every clip (convmod_x3.hip: derived from the plain
+    // value, the lane addresses of the whole clip are loop-invariant and get hoisted out of the clip loop into registers the phases need)
+    int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int n = lane & 31, h = lane >> 5;
+    int tok = 32 * wave + n, tokc = min(tok, T - 1);
+    auto rederive = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        tid = t; lane = t & 63; wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        n = lane & 31; h = lane >> 5;
+        tok = 32 * wave + n; tokc = min(tok, T - 1);
+    };
     const int NT16 = NT16C > 0 ? NT16C : (T + 15) / 16, NTk = (NT16 + 1) / 2;      // 16-key blocks, 32-key tiles with keys below T
 
     auto fetch = [&](const unsigned char* src, unsigned char* slot, auto steps) {
@@ -222,6 +231,7 @@ __global__ void __launch_bounds__(256) attn_x3_kernel(AttnArgs a) {
     [[maybe_unused]] int att_it = 0;
     for (int clip = (int)blockIdx.x; clip < a.B; clip += (int)gridDim.x) {
         ATT_STAMP(0)
+        rederive();
         f16x8 xf[D16][2];
         float isx;                                             // 1 / the clip's scale
         {
@@ -520,7 +530,7 @@ __global__ void __launch_bounds__(256) attn_x3_kernel(AttnArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) rnxt[jj] = *reinterpret_cast<const float4*>(rrow[jj] + 32 * (ob + 1));
                 }
-                if (ob == 0 && clip + (int)gridDim.x < a.B) load_rows(clip + (int)gridDim.x);
+                if (ob == 0) load_rows(min(clip + (int)gridDim.x, a.B - 1));     // (unconditional: a conditionally assigned array keeps its old value live)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(tb + n * TP + 8 * g + 4 * h) = make_float4(yacc[ob][4 * g], yacc[ob][4 * g + 1], yacc[ob][4 * g + 2], yacc[ob][4 * g + 3]);

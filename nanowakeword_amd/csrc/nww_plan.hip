@@ -1283,17 +1283,21 @@ extern "C" int nww_finalize(nww_handle* h) {
                 {
                     const std::string m = q + ".conv_module";
                     const float *lw = p.W(m + ".layer_norm.weight"), *lb = p.W(m + ".layer_norm.bias");
+                    const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
+                    const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
+                    // (the whole module as ONE clip-resident launch was built and measured: bit-identical, 0.27 ms against 0.25 for the three launches
+                    // below - tools/ubench/convmod_x3.hip)
+                    {
                     // LayerNorm + pointwise conv1 + GLU in one launch (lin_x3.hip), else the three separate ones
                     if (!add_lin_x3(p, m + ".layer_norm+conv1(pw)+glu", hb, t1, T, D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), 2, 99, 1.f, lw, lb)) {
                         p.add("layernorm:" + m, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
                         add_gemm(p, m + ".conv1(pw)", t1, big, T, 2 * D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), ACT_NONE);
                         p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
                     }
-                    const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
-                    const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
                     p.add("dwconv1d+bn+swish:" + m, [=](Run& r) { return launch_dwconv1d_bn_swish(r.buf[t1], dw, db, ba, bb, r.buf[t3], r.B, T, D, 31, r.stream); });
                     if (!add_lin_x3(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), 1, hb, 1.0f))
                         add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                    }
                 }
                 ffn(".ff2");
                 const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");

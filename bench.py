@@ -185,6 +185,87 @@ def sustained_leg(a, torch, dev, model, pcm, logits, B, N):
     return {"value": round(B * n / dt, 1), "unit": "clips/s", "seconds": round(dt, 2), "steps": n}
 
 
+def step_work(cfg, fe, name, N=16000, act_bytes=4):
+    """Algorithmic work per CLIP of one plan step of a BASELINE-config head (DESIGN.md 4 "Kernels"): ("mfma", flops) for the matrix-pipe
+    kernels - float32-equivalent flops, priced against the dense 16-bit MFMA peak / 3 partial products under the default arithmetic -
+    or ("hbm", bytes) for the ones that only move data.  None: no figure for this step (small / latency-bound)."""
+    import re
+    T, F = (cfg.input_shape[1], cfg.input_shape[0]) if cfg.model_type == "e2e_dnn" else cfg.input_shape
+    frames = 1 + (N - (0 if fe.center else fe.n_fft)) // fe.hop_length
+    if name.startswith("frontend"):
+        return "hbm", 2 * N + 4 * fe.n_mels * frames
+    mt = cfg.model_type
+    if mt == "conformer":
+        D, NH = cfg.conformer_d_model, cfg.conformer_n_head
+        if name.startswith("ffn_x3"):
+            return "mfma", 2 * T * 2 * D * 4 * D                       # linear1 + linear2
+        if name.startswith("attn_x3"):
+            return "mfma", 2 * T * D * 3 * D + 4 * T * T * D + 2 * T * D * D      # in_proj + q k^T + p v + out_proj
+        if name.startswith("mha"):
+            return "mfma", 4 * T * T * D
+        if "in_proj" in name:
+            return "mfma", 2 * T * D * 3 * D
+        if "glu" in name:
+            return "mfma", 2 * T * D * 2 * D
+        if "out_proj" in name or "conv2(pw)" in name:
+            return "mfma", 2 * T * D * D
+        if "input_proj" in name:
+            return "mfma", 2 * T * F * D
+        if name.startswith("dwconv1d"):
+            return "hbm", 2 * T * D * 4
+        if name.startswith("layernorm+mean"):
+            return "hbm", T * D * 4
+    if mt == "bcresnet":
+        # depthwise outputs d1, d2, d3 (channels, rows, columns): with the blocks chained only these (and as many strided shortcut samples) reach HBM
+        h, w, d = T // 2, F // 2, []
+        for ci, sh, sw in ((32, 2, 2), (64, 2, 2), (128, 2, 1)):
+            h, w = (h - 1) // sh + 1, (w - 1) // sw + 1
+            d.append((ci, h, w))
+        if name.startswith("conv1_dw"):
+            return "mfma", 2 * 9 * 32 * T * F + 2 * 9 * 32 * d[0][1] * d[0][2]
+        m = re.search(r"model\.block(\d)\.pointwise", name)
+        if m:
+            i = int(m.group(1)) - 1
+            c, h, w = d[i]
+            nbytes = 2 * c * h * w * act_bytes                           # the depthwise output + the strided shortcut samples
+            if i + 1 < 3 and "->" in name:
+                c2, h2, w2 = d[i + 1]
+                nbytes += 2 * c2 * h2 * w2 * act_bytes
+            return "hbm", nbytes
+    if mt == "cnn":
+        H1, W1 = T // 2, F // 2
+        if name.startswith("trunk"):
+            return "mfma", 2 * 9 * 16 * (2 * H1) * (2 * W1) + 2 * 9 * 16 * 32 * (2 * (H1 // 2)) * (2 * (W1 // 2))
+        if name.startswith("gemm:fc1"):
+            return "mfma", 2 * 32 * (T // 4) * (F // 4) * 128
+    if mt == "dnn" and name.startswith("gemm:layer1"):
+        return "mfma", 2 * T * F * cfg.layer_dim
+    return None
+
+
+def leg_roofline(cfg, fe, B, prof, act_bytes=4):
+    """roofline block of a config leg from its live per-launch profile: the step with the largest share of device time"""
+    per = [(n, ms / max(c, 1)) for (n, ms, c) in prof if c > 0]
+    if not per:
+        return None
+    name, ms = max(per, key=lambda r: r[1])
+    w = step_work(cfg, fe, name, act_bytes=act_bytes)
+    out = {"kernel": name.split(" [")[0], "avg_launch_ms": round(ms, 4), "share_of_step": round(ms / sum(r[1] for r in per), 3)}
+    if w is None:
+        out["bound"] = None
+        return out
+    bound, amount = w
+    if bound == "hbm":
+        ach, peak, unit = B * amount / 1e9 / (ms * 1e-3), PEAK_HBM_GBS, "GB/s"
+        out["algorithmic_gb"] = round(B * amount / 1e9, 4)
+    else:
+        ach, peak, unit = B * amount / 1e12 / (ms * 1e-3), round(PEAK_BF16_TFLOPS / 3, 1), "TFLOP/s"
+        out["algorithmic_gflop"] = round(B * amount / 1e9, 2)
+        out["peak_definition"] = "dense 16-bit MFMA peak / 3 partial products per float32 product (default arithmetic f16x3)"
+    out.update({"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)})
+    return out
+
+
 def config_legs(torch, dev):
     """The other BASELINE.json configs on this one GPU (the multi-GPU ones at their per-GPU batch), driver-observed:
     10 timed steps each with PCM resident in HBM, and max |dlogit| of 8 clips against the oracle.  Never part of `value`."""
@@ -222,6 +303,16 @@ def config_legs(torch, dev):
         ref = oracle.model_forward(np.ascontiguousarray(lm), sd, cfg).ravel()
         legs[key] = {"workload": name, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "clips_per_s": round(B * steps / dt, 1),
                      "max_abs_dlogit": float(np.abs(logits[:8].cpu().numpy() - ref).max())}
+        # the leg's own roofline: a separate profiled pass (per-launch HIP events on the launch stream) behind the timed one
+        m.set_profiling(True)
+        for _ in range(5):
+            m.forward_pcm_dev(pcm.data_ptr(), B, 16000, logits.data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        prof = m.get_profile()
+        m.set_profiling(False)
+        legs[key]["kernel_ms"] = {n.split(" [")[0]: round(ms / max(c, 1), 4) for (n, ms, c) in prof if c > 0}
+        legs[key]["launches_per_step"] = sum(1 for (n, ms, c) in prof if c > 0)
+        legs[key]["roofline"] = leg_roofline(cfg, fe, B, prof, act_bytes=2 if act_dtype else 4)
         m.close()
     # C4: CRNN-GRU head, 1024 lock-step 10 s streams, one 80 ms hop per step.  Per hop the library computes what the hop invalidates
     # (12 of 101 log-mel frames, 5 of 25 pooled conv rows: per-stream rings, nww_stream.hip) - bit-identical to re-scoring the window
@@ -365,8 +456,10 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
         torch.cuda.synchronize(dev)
     for e in done:
         e.record(comp_s)
-    run(4)
-    k = max(20, a.steps)
+    run(8)
+    # long enough for the steady state to be what is measured: a batch is ~2.3 ms of upload, so the pipeline's fill and drain (one upload
+    # that overlaps nothing, the last step and its copy back) were 6 % of a 20-batch run (r05: 50.9 GB/s of the link's 56-57)
+    k = max(150, a.steps)
     t0 = time.perf_counter()
     run(k)
     dt = time.perf_counter() - t0
@@ -425,6 +518,9 @@ def main():
         B, scaling = a.global_batch // world, "strong"
     pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
     pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
+    # the timed loop walks THREE copies of the batch (same clips, distinct addresses: 3 x 131 MB at the headline batch > the 256 MiB Infinity
+    # Cache), so the frontend's reads come from HBM every step
+    pcm_ring = [pcm] + [pcm.clone() for _ in range(2)]
     logits = torch.empty(B, dtype=torch.float32, device=dev)
     gdev = torch.device("cpu") if a.debug_single_gpu else dev
     gathered = torch.empty(B * world, dtype=torch.float32, device=gdev) if world > 1 else None
@@ -452,9 +548,11 @@ def main():
     if gather_via == "capi":
         logits = gathered[rank * B:(rank + 1) * B]                  # this rank's slot of the gathered vector
         gathered2 = [gathered, torch.empty_like(gathered)]          # two steps in flight: the gather runs on the handle's own stream
-    step_no = [0]
+    step_no = [0, 0]
 
     def step():
+        pcm = pcm_ring[step_no[1] % 3]
+        step_no[1] += 1
         if gather_via == "capi":
             # kernels on `stream`, the RCCL all-gather of step k on the library's side stream behind an event: step k + 1's kernels do
             # not wait for it (nww_forward_pcm_gather_async_dev); the fence below closes the timed region
@@ -617,6 +715,7 @@ def main():
                     extra["stft_stage"]["valu_issue_source"] = (f"SQ_INSTS_VALU {ent['sq_insts_valu']:.4g} per launch (profiles/traffic.json, rocprofv3 --pmc) "
                                                                 "x 4 clocks / (1024 SIMDs x avg_launch_ms x 2.4 GHz)")
                     extra["stft_stage"]["binding"] = "valu_issue"
+                    extra["stft_stage"]["binding_frac"] = extra["stft_stage"]["valu_issue_frac"]      # the stage's fraction of its REAL roof
             except Exception:
                 pass
         out = {
@@ -625,6 +724,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.model_type} head on (101,64) log-mel, batch={B}/GPU, 1 s 16 kHz mono int16 "
                                    "clips, 64-mel 25 ms/10 ms center frontend, fused STFT+mel HIP kernel, fp32",
+                       "pcm_buffers": "the timed loop rotates three device copies of the batch (3 x 131 MB > the 256 MiB Infinity Cache)",
                        "clips_per_gpu": B, "n_samples": N,
                        "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",

@@ -49,11 +49,18 @@ SYMBOLS = [
 ]
 
 
+HIP_RUNTIME = "system"      # which libamdhip64 this process runs on (set by load_library; for logs and bug reports)
+
+
 def _share_torch_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 under the system library's soname, and whichever
     copy is loaded first serves every later user of that soname: loaded after this library, torch would run on the system runtime it was not
     built against (seen: `RuntimeError: No HIP GPUs are available` from torch.cuda on a ROCm 7.2 image with a rocm7.0 wheel), while this library
     runs on either.  So when a torch installation is present, its copy is loaded first - located without importing torch."""
+    global HIP_RUNTIME
+    if os.environ.get("NWW_SHARE_TORCH_HIP", "1") == "0":      # opt-out: a process that never imports torch may want the system runtime
+        HIP_RUNTIME = "system (NWW_SHARE_TORCH_HIP=0)"
+        return
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -64,8 +71,9 @@ def _share_torch_hip_runtime():
         if os.path.exists(cand):
             try:
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass
+                HIP_RUNTIME = cand
+            except OSError as e:
+                HIP_RUNTIME = f"system (loading {cand} failed: {e})"
             return
 
 

@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "libnwwhip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
 EMU_LIB = os.path.join(EMU_DIR, "libfe_emu.so")
 
-HIP_SOURCES = ["nww_api.hip", "nww_plan.hip", "nww_stream.hip", "nww_comm.hip", "nww_emb.hip", "frontend2.hip", "frontend3.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_b.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "bc_chain.hip", "rnn_x3.hip", "rnn_stream.hip", "mha_mfma.hip", "mha_h2.hip", "attn_x3.hip", "emb_stream.hip", "fe_tables.cpp"]
+HIP_SOURCES = ["nww_api.hip", "nww_plan.hip", "nww_stream.hip", "nww_comm.hip", "nww_emb.hip", "frontend2.hip", "layers.hip", "gemm_x3.hip", "trunk.hip", "trunk_b.hip", "conv3_x3.hip", "ffn_x3.hip", "lin_x3.hip", "dual_x3.hip", "bc_chain.hip", "rnn_x3.hip", "rnn_stream.hip", "mha_mfma.hip", "mha_h2.hip", "attn_x3.hip", "emb_stream.hip", "fe_tables.cpp"]
 
 
 def _hipcc() -> str:
@@ -40,7 +40,7 @@ def _newer(target: str, deps) -> bool:
 # Round 3: a packed f32 instruction is also starved by any matrix-pipe wave on its SIMD (DESIGN 4.2a iii); A/B over every file
 # (NWW_SLP=none against the default, tools/bench_configs.py): BcResNet front 0.534 -> 0.515, its depthwise kernels 0.118 /
 # 0.102 -> 0.114 / 0.094, dual_x3 0.172 / 0.242 -> 0.163 / 0.236, ffn_x3 -1 %; mha_mfma 0.318 -> 0.366 and conv3_x3 +1 % (they keep SLP).
-NO_SLP = {"frontend2.hip", "frontend3.hip", "trunk_b.hip", "dual_x3.hip", "bc_chain.hip", "layers.hip", "ffn_x3.hip"}
+NO_SLP = {"frontend2.hip", "trunk_b.hip", "dual_x3.hip", "bc_chain.hip", "layers.hip", "ffn_x3.hip"}
 
 
 def build_hip(force: bool = False, verbose: bool = False, out: str = LIB) -> str:
@@ -78,7 +78,7 @@ def build_hip(force: bool = False, verbose: bool = False, out: str = LIB) -> str
 
 def build_emu(force: bool = False) -> str:
     srcs = [os.path.join(EMU_DIR, "fe_emu.cpp"), os.path.join(CSRC, "fe_tables.cpp")]
-    deps = srcs + [os.path.join(CSRC, "fe_steps.h"), os.path.join(CSRC, "fe_tables.h"), os.path.join(CSRC, "fe3.h")]
+    deps = srcs + [os.path.join(CSRC, "fe_steps.h"), os.path.join(CSRC, "fe_tables.h")]
     if not force and not _newer(EMU_LIB, deps):
         return EMU_LIB
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", CSRC, "-o", EMU_LIB] + srcs, check=True)

@@ -59,7 +59,7 @@ constexpr int PS3_MAX = 208, WT_BYTES_MAX = 9 * 2 * 3 * 1024;
 static int conv3_row_pitch(int H, int W, int avg_ow, bool h2, int C1 = 32) {
     const int NT = h2 ? 2 : 3, PS3 = 2 * C1 * NT + 16, WT_BYTES = 9 * (C1 / 16) * NT * 1024;
     const int dense = (W + 2) * PS3;
-    static const int padded = [] { const char* e = getenv("NWW_CONV3_PITCH"); return e ? atoi(e) : 1; }();      // 0: dense rows (round 3), for A/B runs
+    static const int padded = 1;      // 0: dense rows (round 3), for A/B runs
     if (!padded) return dense;
     int pad = (128 - dense % 256 + 256) % 256;               // multiple of 16
     if (pad > 128 && pad - 256 >= -32) pad -= 256;

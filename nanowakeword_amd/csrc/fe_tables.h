@@ -3,7 +3,6 @@
 #include <string>
 #include <vector>
 #include "fe_steps.h"
-#include "fe3.h"
 
 struct FeParams {
     int sample_rate = 16000, n_fft = 400, win_length = 400, hop = 160, n_mels = 64, center = 1;
@@ -20,10 +19,6 @@ std::string fe_build_tables(const FeParams& p, const float* window, const float*
 
 // MFMA mel-contraction plan of the wave-private kernel (frontend2.hip) from the same filterbank
 std::string fe2_build_mel_plan(const FeParams& p, const float* fb, Fe2MelPlan* out);
-
-// Plan of the matrix-pipe frontend (frontend3.hip / fe3.h): the window-folded stage-1 matrices, the 16-point matrix and the bin map
-// as the register images the kernel's MFMAs consume.  "" or why this configuration has no such plan (the caller keeps frontend2).
-std::string fe3_build_plan(const FeParams& p, const float* window, Fe3Plan* out);
 
 // frame law; -1 if the clip is too short
 int fe_num_frames(const FeParams& p, int n_samples);

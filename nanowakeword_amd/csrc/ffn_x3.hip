@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
 // MFMAs of the next first product.  (tools/ubench/ffn_trace: with all 40 pieces behind the first product's 27 MFMAs that phase took 2200 clocks,
 // VALU-bound, and the second product's 30 MFMAs 1250 with the VALU idle.)  One accumulator instead of two; the next block's biases come from the
 // packed blob in global memory (its LDS copy is still in flight then).
-template <int D16, bool H2, bool LATE_A = true>
+template <int D16, bool H2>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;
     constexpr int NT = H2 ? 2 : 3, NP = H2 ? 3 : 6;            // terms per value, partial products per operand pair
@@ -241,160 +241,11 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.0f;
 
-    // Software pipeline over the hidden blocks: while the matrix pipe runs block hb + 1's first product, the VALU turns
-    // block hb's accumulator into operand fragments (bias, swish, three-way split) - a lone wave issues in order, and each
-    // MFMA of the dependent chain holds the wave for its 32 clocks, so the scheduler is told to put ~5 VALU instructions
-    // behind every MFMA (sched_group_barrier); then block hb's second product.  W1 parts and W2 parts are double
-    // buffered separately, each fetched a full iteration before its first use:
-    //   iteration hb:  fetch W1(hb + 2), W2(hb + 1);   Ht(hb + 1) = W1(hb + 1) . Xt  ||  hf = split(swish(Ht(hb) + b1(hb)));
-    //                  Yt += W2(hb) . hf;               barrier
-    auto gemm1_epi = [&](auto has_next, const unsigned char* w1buf, const unsigned char* w2buf, const f32x16& cur, f32x16& next,
-                         bf16x8 (&hf)[2][NT], const FetchPlan fp) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        constexpr int NSLOT = NEXT ? NP * D16 : 1;             // MFMAs of the first product = slots for epilogue pieces
-        constexpr int NPIECE = H2 ? 40 : 48;                   // epilogue pieces (below)
-        constexpr int PER = (NPIECE + NSLOT - 1) / NSLOT;      // ... per slot
-        const unsigned char* w1p = w1buf + lane * 16;
-        const float* b1p = reinterpret_cast<const float*>(w2buf + B1_OFF) + 4 * h;
-        float4 bq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(b1p + 8 * g);     // biases of hidden 8g + 4h + 0..3
-        const float bias[16] = {bq[0].x, bq[0].y, bq[0].z, bq[0].w, bq[1].x, bq[1].y, bq[1].z, bq[1].w,
-                                bq[2].x, bq[2].y, bq[2].z, bq[2].w, bq[3].x, bq[3].y, bq[3].z, bq[3].w};
-        bf16x8 nw[NT], cw[NT];
-        if (NEXT) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(w1p + t * 1024);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) next[r] = 0.0f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // Three-term form, element e of the accumulator in three pieces: (A) v = acc + bias, u = 1 + 2^(-v log2 e);  (B) y = v / u,
-        // hi, rest;  (C) mid, lo.  Two-term form, per PAIR of elements five pieces: (A) (A) as above with the accumulator scaled
-        // back, (B) (B) y = s_h v / u, (C) the pair's two binary16 dwords.  Registers 8 kb2 .. 8 kb2 + 7 are the eight k slots of
-        // 16-block kb2 of the second product.
-        float v[16], u[16];
-        uint32_t th[16], tm[16], tl[16];
-        auto piece = [&](int p) {
-            if constexpr (H2) {
-                const int j = p / 5, st = p - 5 * j;
-                if (st < 2) {
-                    const int e = 2 * j + st;
-                    v[e] = fmaf(cur[e], ik1, bias[e]);
-                    u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
-                    asm volatile("" : "+v"(v[e]), "+v"(u[e]));
-                } else if (st < 4) {
-                    const int e = 2 * j + st - 2;
-                    v[e] = (v[e] * s_h) * __builtin_amdgcn_rcpf(u[e]);
-                    asm volatile("" : "+v"(v[e]));
-                } else {
-                    nww_split2h(v[2 * j], v[2 * j + 1], th[j], tl[j]);
-                    asm volatile("" : "+v"(th[j]), "+v"(tl[j]));
-                }
-            } else {
-                const int e = p / 3, st = p - 3 * e;
-                if (st == 0) {
-                    v[e] = cur[e] + bias[e];
-                    u[e] = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]);
-                    asm volatile("" : "+v"(v[e]), "+v"(u[e]));     // pins the piece behind its MFMA (pure arithmetic floats freely otherwise)
-                } else if (st == 1) {
-                    const float y = v[e] * __builtin_amdgcn_rcpf(u[e]);
-                    th[e] = __float_as_uint(y) & 0xffff0000u;
-                    u[e] = y - __uint_as_float(th[e]);
-                    asm volatile("" : "+v"(th[e]), "+v"(u[e]));
-                } else {
-                    tm[e] = __float_as_uint(u[e]) & 0xffff0000u;
-                    tl[e] = __float_as_uint(u[e] - __uint_as_float(tm[e]));
-                    asm volatile("" : "+v"(tm[e]), "+v"(tl[e]));
-                }
-            }
-        };
-        // the partial products, small terms first (mfma6; two-term form: lo hi, hi lo, hi hi)
-        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
-#pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
-            if (NEXT) {
-                const int kb = q / NP, m = q - NP * kb;
-                if (m == 0) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) cw[t] = nw[t];
-                }
-                if (m < NT && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * NT + m) * 1024);
-                next = ffn_mma<H2>(cw[PW[m]], xf[kb][PX[m]], next);
-                asm volatile("" : "+a"(next));
-                // the fetches of the blocks ahead, one step behind every second MFMA (wave-uniform branches)
-                if constexpr (NF1 + NF2 <= (NSLOT + 1) / 2) {
-                    if ((q & 1) == 0) {
-                        const int j = q >> 1;
-                        if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
-                        else if (j < NF1 + NF2) { if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1); }
-                    }
-                } else {
-                    const int j0 = q * (NF1 + NF2) / NSLOT, j1 = (q + 1) * (NF1 + NF2) / NSLOT;
-                    for (int j = j0; j < j1; ++j) {
-                        if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
-                        else if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1);
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = q * PER; p < (q + 1) * PER && p < NPIECE; ++p) piece(p);
-            __builtin_amdgcn_sched_barrier(0);                 // each MFMA keeps its pieces: a lone wave issues in order, and the
-        }                                                      // next MFMA of the chain waits 32 clocks for this one anyway
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2) {
-            if constexpr (H2) {
-                union { uint4 q; bf16x8 b; } ch, cl;
-                const int o = 4 * kb2;
-                ch.q = make_uint4(th[o], th[o + 1], th[o + 2], th[o + 3]);
-                cl.q = make_uint4(tl[o], tl[o + 1], tl[o + 2], tl[o + 3]);
-                hf[kb2][0] = ch.b; hf[kb2][1] = cl.b;
-            } else {
-                union { uint4 q; bf16x8 b; } ch, cm, cl;
-                const int o = 8 * kb2;
-                ch.q = make_uint4(pack16(th[o], th[o + 1]), pack16(th[o + 2], th[o + 3]), pack16(th[o + 4], th[o + 5]), pack16(th[o + 6], th[o + 7]));
-                cm.q = make_uint4(pack16(tm[o], tm[o + 1]), pack16(tm[o + 2], tm[o + 3]), pack16(tm[o + 4], tm[o + 5]), pack16(tm[o + 6], tm[o + 7]));
-                cl.q = make_uint4(pack16(tl[o], tl[o + 1]), pack16(tl[o + 2], tl[o + 3]), pack16(tl[o + 4], tl[o + 5]), pack16(tl[o + 6], tl[o + 7]));
-                hf[kb2][0] = ch.b; hf[kb2][1] = cm.b; hf[kb2][NT - 1] = cl.b;
-            }
-        }
-    };
-    // second product: two output blocks at a time, their MFMAs alternating (a chain on one accumulator issues every 36
-    // clocks, two interleaved chains every 32: tools/ubench/mfma_valu_samewave.hip)
-    auto gemm2 = [&](const unsigned char* w2buf, const bf16x8 (&hf)[2][NT]) {
-        const unsigned char* w2p = w2buf + lane * 16;
-        constexpr int PW[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PX[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};   // as in gemm1_epi
-        constexpr int NG = 2 * ((NOB + 1) / 2);                // groups: (pair of output blocks, kb2)
-        auto frag = [&](int g, int which, int t) {             // group g = 2 * pair + kb2; which = 0 / 1: block 2 pair + which
-            const int ob = 2 * (g >> 1) + which, kb2 = g & 1;
-            return *reinterpret_cast<const bf16x8*>(w2p + ((ob * 2 + kb2) * NT + t) * 1024);
-        };
-        bf16x8 na[NT], nb[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { na[t] = frag(0, 0, t); if (NOB > 1) nb[t] = frag(0, 1, t); }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int ob = 2 * (g >> 1), kb2 = g & 1;
-            const bool two = ob + 1 < NOB;
-            bf16x8 ca[NT], cb[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    na[t] = frag(g + 1, 0, t);
-                    if (2 * ((g + 1) >> 1) + 1 < NOB) nb[t] = frag(g + 1, 1, t);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < NP; ++m) {
-                yacc[ob] = ffn_mma<H2>(ca[PW[m]], hf[kb2][PX[m]], yacc[ob]);
-                if (two) yacc[ob + 1] = ffn_mma<H2>(cb[PW[m]], hf[kb2][PX[m]], yacc[ob + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
+    // Software pipeline over the hidden blocks (W1 parts and W2 parts double buffered separately, each fetched a full iteration before its
+    // first use): the first product of block hb + 1 runs with the SECOND half of block hb's epilogue (y = v / u, split) between its MFMAs,
+    // the second product of block hb with the FIRST half of block hb + 1's (bias, 1 + 2^(-v log2 e)) between its own - a lone wave issues in
+    // order, and each MFMA of a dependent chain holds it for 32 clocks.  (The round-4 schedule - the whole epilogue behind the first product -
+    // was removed in round 6: tools/ubench/ffn_trace, 4130 -> 3450 clocks per block.)
     // ---- LATE_A schedule
     float va[16], ua[16];                                      // stage-A results of the block whose fragments the next first product builds
     auto load_bias = [&](int hb, float (&bias)[16]) {          // b1 of block hb, hidden units 8 g + 4 h + 0..3, from the packed blob
@@ -534,7 +385,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    f32x16 accA, accB;
+    f32x16 accA;
     bf16x8 hf[2][NT];
     float4 res[NOB][4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -561,7 +412,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (LATE_A) {
+    {
         // Even block hb: W1(hb + 1) in w1b1, W2(hb) in w2b0; odd block: the other buffers.  accA holds Ht(hb + 1) from phase 1 to the end of phase 2.
         float bias[16];
         load_bias(0, bias);
@@ -608,48 +459,6 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             phase2(std::false_type{}, w2b1, hf, accA, bias);
         }
-    } else {
-    // NHB = D / 8 is even.  Even block hb: cur = accA, W1(hb + 1) in w1b1, W2(hb) in w2b0; odd block: the other buffers.
-        for (int hb = 0; hb + 2 < NHB; hb += 2) {
-            FFN_STAMP(hb, 0)
-            __builtin_amdgcn_sched_barrier(0);
-            FFN_STAMP(hb, 1)
-            gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf, plan_of(hb + 2, w1b0, hb + 1, w2b1));
-            __builtin_amdgcn_sched_barrier(0);
-            FFN_STAMP(hb, 2)
-            gemm2(w2b0, hf);
-            FFN_STAMP(hb, 3)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FFN_STAMP(hb, 4)
-            __syncthreads();
-            FFN_STAMP(hb, 5)
-            __builtin_amdgcn_sched_barrier(0);
-            gemm1_epi(std::true_type{}, w1b0, w2b1, accB, accA, hf, plan_of(hb + 3, w1b1, hb + 2, w2b0));
-            __builtin_amdgcn_sched_barrier(0);
-            gemm2(w2b1, hf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        {                                                          // the last two blocks
-            __builtin_amdgcn_sched_barrier(0);
-            gemm1_epi(std::true_type{}, w1b1, w2b0, accA, accB, hf, plan_of(-1, nullptr, NHB - 1, w2b1));
-            __builtin_amdgcn_sched_barrier(0);
-            gemm2(w2b0, hf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // the X fragments are dead now: their registers take the residual rows for the final update, so that those
-            // loads are in flight under the last block's MFMAs
-    #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob)
-    #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
-            __builtin_amdgcn_sched_barrier(0);
-            gemm1_epi(std::false_type{}, w1b0, w2b1, accB, accA, hf, plan_of(-1, nullptr, -1, nullptr));
-            __builtin_amdgcn_sched_barrier(0);
-            gemm2(w2b1, hf);
-        }
-    
     }
 
     // ---- h <- h + rscale * (Yt + b2): lane (row n, half h) holds out features 32 ob + 8 g + 4 h + 0..3
@@ -690,14 +499,10 @@ hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2,
 hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     const dim3 grid((a.M + 127) / 128);
-    static const int late_a = [] { const char* e = getenv("NWW_FFN_LATE_A"); return e ? atoi(e) : 1; }();
 #define FFN_GO(D16V)                                                                                               \
     {                                                                                                              \
-        if (late_a) {                                                                                              \
-            if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true, true>), grid, dim3(256), 0, s, a);    \
-            else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false, true>), grid, dim3(256), 0, s, a);                 \
-        } else if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true, false>), grid, dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false, false>), grid, dim3(256), 0, s, a);                    \
+        if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);              \
+        else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false>), grid, dim3(256), 0, s, a);                           \
     }
     switch (D) {
         case 32: FFN_GO(2) break;

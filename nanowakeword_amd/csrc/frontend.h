@@ -25,10 +25,3 @@ hipError_t fe2_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int
                       const FeTables* d_tables, const Fe2MelPlan* d_plan, float* d_db, float* d_mel, int frames_major,
                       int mel_mode, int max_taps, int block, int max_grid, hipStream_t stream, const Fe2Sub* subset = nullptr);
 
-// Matrix-pipe kernel (frontend3.hip; fe3.h): the same contract for hop_length = 160, n_mels <= 64, filters of <= 25 taps.  d_plan from
-// fe3_build_plan.  Frame subsets and ring output as above.  The choice between the two kernels depends on the CONFIGURATION only, never
-// on the batch: a clip's log-mel is the same bits alone, in a batch, or on a streaming hop.
-bool fe3_supported(const FeParams& p, int max_taps);
-hipError_t fe3_launch(const int16_t* d_pcm, size_t row_stride, int B, int N, int T, const FeParams& p, const FeTables* d_tables,
-                      const Fe3Plan* d_plan, float* d_db, float* d_mel, int frames_major, int max_taps, int max_grid,
-                      hipStream_t stream, const Fe2Sub* subset = nullptr);

@@ -1613,7 +1613,7 @@ static hipError_t launch_rnn_wide(const GruArgs& a, int gates, hipStream_t s) {
 }
 
 bool rnn_x3_enabled(const GruArgs& a) {
-    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    static const int use16 = 1;
     return use16 && rnn_x3_usable(a);
 }
 
@@ -1621,7 +1621,7 @@ hipError_t launch_lstm(const GruArgs& a, hipStream_t s) {
     if (a.w_packed) return launch_rnn_stream(a, 4, s);
     if (a.ldw) return launch_rnn_wide(a, 4, s);                      // padded weights: the any-width kernel (planned for H % 4 != 0 or H > 256)
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
-    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    static const int use16 = 1;
     if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 4, s);
     if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
@@ -1648,7 +1648,7 @@ hipError_t launch_gru(const GruArgs& a, hipStream_t s) {
     if (a.w_packed) return launch_rnn_stream(a, 3, s);
     if (a.ldw) return launch_rnn_wide(a, 3, s);
     if (a.H % 4 != 0 || a.H > 256) return hipErrorInvalidValue;      // a wave per 32 hidden units, 512 threads
-    static const int use16 = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    static const int use16 = 1;
     if (rnn_x3_enabled(a)) return launch_rnn_x3(a, 3, s);
     if (a.xg2) return hipErrorInvalidValue;                           // only rnn_x3 folds the opposite direction's step
     if (use16 && (a.H == 32 || a.H == 64 || a.H == 128) && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0) {
@@ -1833,7 +1833,7 @@ hipError_t launch_classifier_tail(const TailArgs& a, hipStream_t s) {
     // small batches: four clips per workgroup (64 threads per clip instead of 16; measured at B = 32 / 1024 / 4096: DNN body + tail
     // 0.035 -> 0.021 ms, CRNN tail 0.0255 -> 0.022, CNN tail 0.020 -> 0.029).  B = 5 .. 16 keep ONE 16-clip workgroup: the
     // completion word of the interpreter's zero-copy calls is written by a launch of a single workgroup only
-    static const int ct4_max = [] { const char* e = getenv("NWW_TAIL_CT4_MAX"); return e ? atoi(e) : 1024; }();
+    static const int ct4_max = 1024;
     const bool small = a.B <= 4 || (a.B > 16 && a.B <= ct4_max);
     const int ct = small ? 4 : 16;
     int grid = (a.B + ct - 1) / ct;

@@ -304,7 +304,7 @@ bool mha_h2_supported(int T, int D, int n_head) {
     if (n_head <= 0 || D % n_head || T > 128 || T < 1 || D % 4) return false;
     // head dims above 48 stay on the float32-MFMA kernel (mha_mfma.hip: 250 registers, no scratch): the 64-wide instance of this one
     // spills 68 registers (tools/kernel_regs.sh), a silent 2-3 x cliff; NWW_MHA_H2 = 2 still selects it for A/B runs
-    static const int force = [] { const char* e = getenv("NWW_MHA_H2"); return e ? atoi(e) : 1; }();
+    static const int force = 1;
     if (D / n_head > 48 && force < 2) return false;
     switch (D / n_head) {
 #define MHA_OK(DHV) case DHV: return mha_h2_lds(DHV) <= 80 * 1024;

@@ -152,7 +152,6 @@ extern "C" int nww_destroy(nww_handle* h) {
     for (void* d : h->packed_weights) (void)hipFree(d);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_melplan) (void)hipFree(h->d_melplan);
-    if (h->d_fe3plan) (void)hipFree(h->d_fe3plan);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (auto& run : h->prof_runs) for (auto e : run) (void)hipEventDestroy(e);
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -243,14 +242,14 @@ extern "C" int nww_get_profile(nww_handle* h, float* ms_total, int32_t* launches
 
 extern "C" float nww_feature_clamp(const nww_handle* h) {
     if (!h || !h->finalized) return 0.0f;
-    bool any = false;                                          // a step marked [f16x3], or 16-bit activation storage
-    for (const auto& st : h->plan) any = any || st.name.find("[f16x3]") != std::string::npos;
-    return (any || h->cfg.act_dtype != 0) ? NWW_F16_FEATURE_BOUND : 0.0f;
+    // set at plan time by the steps that clamp the head input themselves (fused trunk, DNN layer1, fused recurrent input projection,
+    // BcResNet front), or 16-bit activation storage; per-row-scaled consumers (lin_x3, ffn_x3, attn_x3) clamp nothing
+    return (h->clamps_features || h->cfg.act_dtype != 0) ? NWW_F16_FEATURE_BOUND : 0.0f;
 }
 
 extern "C" int nww_describe_plan(const nww_handle* h, char* buf, int32_t buflen) {
     if (!h || !buf || buflen <= 0) return NWW_ERR_INVALID;
-    std::string s = h->d_fe3plan ? "frontend:fe_stft_mel_db_kernel [frontend3: matrix pipe]\n" : "frontend:fe_stft_mel_db_kernel\n";
+    std::string s = "frontend:fe_stft_mel_db_kernel\n";
     for (const auto& st : h->plan) s += st.name + "\n";
     s += "unary:sigmoid\n";
     std::snprintf(buf, (size_t)buflen, "%s", s.c_str());
@@ -348,14 +347,7 @@ int nww_frontend_on_dev(nww_handle* h, const int16_t* d_pcm, int B, int N, float
     const int T = fe_num_frames(h->fe, N);
     if (T <= 0) return fail(h, NWW_ERR_INVALID, "clip of %d samples is too short for n_fft=%d (center=%d)", N, h->fe.n_fft, h->fe.center);
     if (frames_out) *frames_out = T;
-    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();    // 2: register filters, 1: MFMA tiles, 0: sparse LDS loop
-    // the matrix-pipe kernel wherever the configuration has a plan for it (decided at nww_finalize, never by the batch size): three
-    // 4-wave workgroups per CU; frontend2.hip otherwise
-    if (h->d_fe3plan) {
-        hipError_t e3 = fe3_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_fe3plan, d_db, d_mel, frames_major, h->mel_max_taps, h->cu_count * 3, s, sub);
-        if (e3 != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e3));
-        return NWW_OK;
-    }
+    static const int mel_env = 2;    // 2: register filters, 1: MFMA tiles, 0: sparse LDS loop
     hipError_t e = fe2_launch(d_pcm, row_stride ? row_stride : (size_t)N, B, N, T, h->fe, h->d_tables, h->d_melplan, d_db, d_mel, frames_major, mel_env, h->mel_max_taps, 256, h->cu_count * 3, s, sub);
     if (e != hipSuccess) return fail(h, NWW_ERR_HIP, "frontend launch failed: %s", hipGetErrorString(e));
     return NWW_OK;

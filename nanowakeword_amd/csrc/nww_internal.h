@@ -83,7 +83,6 @@ struct nww_handle {
     float* d_weights = nullptr;
     FeTables* d_tables = nullptr;
     Fe2MelPlan* d_melplan = nullptr;
-    Fe3Plan* d_fe3plan = nullptr;       // matrix-pipe frontend (frontend3.hip); null: this configuration runs frontend2
     int mel_max_taps = 0;          // longest filter support of the mel filterbank
     hipStream_t own_stream = nullptr;
     std::vector<Step> plan;
@@ -105,6 +104,8 @@ struct nww_handle {
     int16_t* d_ring = nullptr; int16_t* d_chunk = nullptr;
     // incremental hops (nww_stream.hip): log-mel ring [S][2 * lm_rows][n_mels] (frame t of the current window at row lm_pos + t and
     // lm_rows away), pooled conv rows [S][32][a2_rows][W / 4] (row R at (a2_pos + R) % a2_rows); a hop shifts them by lm_shift / a2_shift
+    std::string plan_error;        // plan time: a step that cannot be planned in ANY form (nww_finalize fails with it)
+    bool clamps_features = false;  // plan time: a step that reads the head input clamps it to +-NWW_F16_FEATURE_BOUND (nww_feature_clamp)
     bool x_stride_ok = false;      // plan time: the first step takes Run::x_stride (fused split-operand trunk, DNN layer1)
     bool stream_conv = false;      // plan time: fused trunk -> conv3_x3 pair that takes Run::stream_mode (CRNN)
     int stream_H = 0, stream_W = 0;   // the plane that pair works on
@@ -127,6 +128,8 @@ struct nww_handle {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}, ev_start[2] = {nullptr, nullptr};
     unsigned long long gather_seq = 0;
+    const float* gather_buf[2] = {nullptr, nullptr};   // the d_all_logits each slot's gather last wrote
+    long long gather_test_delay_us = 0;                // test hook, read ONCE at nww_comm_init (NWW_GATHER_TEST_DELAY_US)
     int ring_S = 0, ring_W = 0, ring_hop = 0, ring_pos = 0; long long ring_filled = 0;
     size_t splitk_per_clip = 0;    // floats per clip (max over the plan's split GEMMs)
     std::map<X3Key, void*> x3_weights;             // GEMM weights pre-split into bf16 terms / scaled binary16 terms (gemm_x3.hip)

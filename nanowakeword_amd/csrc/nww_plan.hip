@@ -260,6 +260,7 @@ void add_gemm(PlanCtx& p, const std::string& name, int in_id, int out_id, int ro
         if (it != p.h->x3_weights.end()) wx3 = it->second;
     }
     const bool h2 = h2_req && wx3 != nullptr;                  // the two-term epilogue only with its image
+    if (h2 && a_bound_assumed && in_id == -1) p.h->clamps_features = true;
     // the producer may write A directly as this kernel's [128][32] tiles (the fused trunk feeding fc1)
     const int a_blocked = (a_blocked_inout && *a_blocked_inout && wx3 && K % 32 == 0 && rows_per_clip == 1) ? K / 32 : 0;
     if (a_blocked_inout) *a_blocked_inout = a_blocked != 0;
@@ -311,7 +312,7 @@ bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int 
     const int parts = epi == 2 ? 2 : 1;
     // under NWW_ARITH_F16X3: two binary16 terms per operand, the input rows scaled per row in the kernel (LinArgs::h2: no bound on the
     // tensor needed); NWW_LIN_H2 = 0 keeps the three-term bf16 form
-    static const int h2_on = [] { const char* e = getenv("NWW_LIN_H2"); return e ? atoi(e) : 1; }();
+    static const int h2_on = 1;
     float ws = 0.0f;
     if (h2_on && p.h->f16) ws = f16_wscale(f16_fetch(p.h, W, (size_t)parts * N * K));
     const bool h2 = ws > 0.0f;
@@ -387,6 +388,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
         if (f16 && out_range) *out_range = F16Range{bound2, typ2};
         const int products = f16 ? 3 : x3;
         if (in_id == -1 && !p.h->e2e_transposed) p.h->x_stride_ok = true;                   // this step reads the head input with any clip stride
+        if (f16 && in_id == -1) p.h->clamps_features = true;
         p.add("trunk_x3:" + name + (f16 ? " [f16x3]" : ""), [=](Run& r) {
             TrunkArgs a{src(r, in_id), w1, b1, al1, be1, w2, b2, al2, be2, dst(r, out_id), r.B, H, W, act};
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
@@ -429,7 +431,7 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
     // more than 32 input channels without a usable bound (the worst-case bound of a fourth stage is usually too loose for two terms): the
     // 32-channel three-term instance once per 32 input channels - every pass but the last leaves raw, un-pooled sums in a scratch buffer, the
     // next one starts its accumulators from them (k-split; the planes of such stages are a few hundred pixels)
-    static const int ksplit_on = [] { const char* e = getenv("NWW_CONV3_KSPLIT"); return e ? atoi(e) : 1; }();
+    static const int ksplit_on = 1;
     if (!wide && Cin > 32) {
         if (!ksplit_on || !enabled || !x3_enabled || Cin % 32 != 0 || Cin > 256 || !pool || avg_ow > 0 || avg_y || p.h->conv_products != 6 || scratch_id < 0 ||
             Cout % 32 != 0) return false;
@@ -519,7 +521,7 @@ bool add_conv_mfma(PlanCtx& p, const std::string& name, int in_id, int out_id, i
 // conv1 groups and 16-column conv2 tiles waste 28 % on a 101-wide plane and nothing on a 64-wide one, conv3's 2 x 16 tiles 22 %
 // against 4 %, and the frontend's frames-major output is its fast path.  Needs the split-operand kernels (default arithmetic).
 bool e2e_transposed_ok(PlanCtx& p, int n_mels, int frames) {
-    static const int on = [] { const char* e = getenv("NWW_E2E_TRANSPOSED"); return e ? atoi(e) : 1; }();
+    static const int on = 1;
     static const int trunk_on = [] { const char* e = getenv("NWW_TRUNK"); return e ? atoi(e) : 1; }();
     static const int mfma_on = [] { const char* e = getenv("NWW_CONV_MFMA"); return e ? atoi(e) : 1; }();
     static const int c3_on = [] { const char* e = getenv("NWW_CONV3_X3"); return e ? atoi(e) : 1; }();
@@ -536,11 +538,11 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
     p.need(last_id, (size_t)2 * H);
     // the recurrent product follows the handle's arithmetic switch; NWW_ARITH_F16X3: two binary16 terms (|h| <= 1 bounds the one
     // operand, W_hh's scale comes from the weights)
-    static const int rnn_h2 = [] { const char* e = getenv("NWW_RNN_H2"); return e ? atoi(e) : 1; }();
+    static const int rnn_h2 = 1;
     const int products = (p.h->f16 && rnn_h2) ? 3 : p.h->conv_products;
     GruArgs probe; probe.H = H; probe.products = products;
     probe.w_hh = p.W(prefix + ".weight_hh_l" + std::to_string(layers - 1));       // the pointer the fused launch will really get (alignment test)
-    static const int gru16_on = [] { const char* e = getenv("NWW_GRU16"); return e ? atoi(e) : 1; }();
+    static const int gru16_on = 1;
     const bool streamed = gru16_on && rnn_stream_usable(probe);      // 128 < H <= 256: W_hh streamed from L2 (rnn_stream.hip)
     bool x3 = probe.w_hh != nullptr && (rnn_x3_enabled(probe) || streamed);
     if (x3 && H != 32 && H != 64 && H != 128) {              // zero-padded / streamed instances: two-term form only, so the last layer's W_hh must scale
@@ -560,7 +562,7 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
         // projection is computed inside the recurrence kernel - x_t W_ih^T on the matrix pipe beside h W_hh^T - instead of a GEMM that
         // writes T x 3H gate pre-activations per clip to HBM for the recurrence to read back (635 MB each way at B = 4096, T = 101, H = 128).
         // NWW_RNN_FUSE_IH = 0 keeps the separate projection.
-        static const int fuse_env = [] { const char* e = getenv("NWW_RNN_FUSE_IH"); return e ? atoi(e) : 1; }();
+        static const int fuse_env = 1;
         const float* wih_f = p.W(prefix + ".weight_ih_l" + std::to_string(l));
         const float wi_scale = (fuse_env && fold && l == 0 && in_id == -1 && G == 3 && products == 3 && (cur_I == 32 || cur_I == 64) && (H == 32 || H == 64 || H == 128) &&
                                 wih_f && (reinterpret_cast<uintptr_t>(wih_f) & 15) == 0)
@@ -615,11 +617,17 @@ void add_bigru_last(PlanCtx& p, const std::string& prefix, int in_id, int T, int
                 if (hipMalloc(&pk, rnn_stream_packed_bytes(G, H)) == hipSuccess && launch_rnn_stream_pack(whh_f, pk, G, H, w_scale, p.h->own_stream) == hipSuccess) {
                     p.h->packed_weights.push_back(pk);
                     w_packed = pk;
-                } else if (pk) (void)hipFree(pk);
+                } else {
+                    // the folded form (reverse step inside the forward launch) exists only on the streamed kernel for these widths: without its
+                    // packed W_hh every forward would fail at run time - fail the finalize instead
+                    if (pk) (void)hipFree(pk);
+                    if (fold) p.h->plan_error = "out of device memory for the streamed W_hh image of " + prefix;
+                }
             }
             const bool fused_here = fuse_ih && fold && products_l == 3 && ldw == 0;
             const float* bih_f = p.W(prefix + ".bias_ih_l" + std::to_string(l));
             const int fin = cur_I;
+            if (fused_here) p.h->clamps_features = true;       // the fused input projection clamps the features it splits
             p.add(nm + (fused_here ? " + input projection" : "") + (products_l == 3 && x3 && ldw == 0 ? (w_packed ? " [f16x3, W_hh streamed]" : " [f16x3]") : ""), [=](Run& r) {
                 GruArgs a;
                 a.products = products_l; a.w_scale = w_scale; a.w_packed = w_packed;
@@ -725,17 +733,7 @@ extern "C" int nww_finalize(nww_handle* h) {
         if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
         HIP_TRY(h, hipMalloc(&h->d_melplan, sizeof(Fe2MelPlan)));
         HIP_TRY(h, hipMemcpy(h->d_melplan, plan.data(), sizeof(Fe2MelPlan), hipMemcpyHostToDevice));
-        // matrix-pipe frontend (frontend3.hip): hop 160, <= 64 filters of <= 25 taps.  Opt-in (NWW_FE3 = 1, read at every nww_finalize
-        // so that one process can hold both): parity-green, but at 0.21 ms per 4096 clips against the FFT kernel's 0.155
-        const char* fe3_env = getenv("NWW_FE3");
-        const int fe3_on = fe3_env ? atoi(fe3_env) : 0;
-        if (fe3_on && fe3_supported(h->fe, h->mel_max_taps)) {
-            std::vector<Fe3Plan> p3(1);
-            if (fe3_build_plan(h->fe, win.data(), p3.data()).empty()) {
-                HIP_TRY(h, hipMalloc(&h->d_fe3plan, sizeof(Fe3Plan)));
-                HIP_TRY(h, hipMemcpy(h->d_fe3plan, p3.data(), sizeof(Fe3Plan), hipMemcpyHostToDevice));
-            }
-        }
+        // (the DFT on the matrix pipe - frontend3 - was built in round 5, parity-green and slower: tools/ubench/fe3/)
     }
     // ---- plan
     PlanCtx p{h};
@@ -745,7 +743,7 @@ extern "C" int nww_finalize(nww_handle* h) {
             // Everything behind layer1 runs inside the tail's launch (layers.hip: TailArgs::ln0_w) when the widths allow: LayerNorm1 on
             // layer1's split-K partials, the blocks' Linear + LayerNorm, last_layer, classifier - two launches per forward instead of six
             static const int tail_on = [] { const char* e = getenv("NWW_TAIL"); return e ? atoi(e) : 1; }();
-            static const int body_on = [] { const char* e = getenv("NWW_DNN_BODY"); return e ? atoi(e) : 1; }();
+            static const int body_on = 1;
             if (tail_on && body_on && L <= 256 && nb <= 4 && tail_supported(L, E)) {
                 add_gemm(p, "layer1", -1, 0, 1, L, T * F, p.W("model.layer1.weight"), p.W("model.layer1.bias"), ACT_NONE, nullptr, nullptr, 99, 1.f, nullptr, false, true, F16_FEATURES, true);
                 p.dnn_body = true;
@@ -1014,7 +1012,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 int fprod = p.h->conv_products;
                 // under NWW_ARITH_F16X3 (BN present): two binary16 terms per operand, features clamped to +-NWW_F16_FEATURE_BOUND as in the
                 // CNN trunk; NWW_BC_FRONT_H2 = 0 keeps the three-term bf16 form
-                static const int front_h2_on = [] { const char* e = getenv("NWW_BC_FRONT_H2"); return e ? atoi(e) : 1; }();
+                static const int front_h2_on = 1;
                 float fin = 0.0f, fws = 1.0f;
                 if (front_h2_on && p.h->f16 && fprod == 6 && a0 && bc_front != 2) {
                     fin = f16_scale(F16_FEATURES.bound); fws = f16_wscale(f16_fetch(p.h, w0, 32 * 9));
@@ -1034,6 +1032,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     bn_pos = 1;
                     for (float v : f16_fetch(p.h, a0, 32)) if (!(v >= 0.0f)) bn_pos = 0;
                 }
+                if (fpack) p.h->clamps_features = true;
                 p.add(std::string(fpack ? "conv1_dw_x3" : "conv1_dw_mfma") + ":init_conv + block1.depthwise (nhwc" + (act_f16 ? ", f16 out)" : act_bf16 ? ", bf16 out)" : ")") + (fpack && fprod == 3 ? " [f16x3]" : ""), [=](Run& r) {
                     Conv1DwArgs a{src(r, -1), w0, nullptr, a0, b0, dwt1, r.buf[2], r.buf[3], r.B, T, F, act, 2, 2};
                     a.bf16_out = act16; a.d_scale = s_d[1]; a.xs_scale = s_h[0];
@@ -1084,11 +1083,11 @@ extern "C" int nww_finalize(nww_handle* h) {
                     const int rows = ho * wo;
                     p.need(outb, (size_t)rows * co);
                     // both products from split operands on the bf16 matrix cores (dual_x3.hip) under the same arithmetic switch
-                    static const int dual_x3 = [] { const char* e = getenv("NWW_BC_DUAL_X3"); return e ? atoi(e) : 1; }();
+                    static const int dual_x3 = 1;
                     void* packed = nullptr;
                     // float32 activations under NWW_ARITH_F16X3: two binary16 terms per operand, the activation rows scaled per pixel in
                     // the kernel (DualArgs::h2) - no tensor bound needed; NWW_BC_DUAL_H2 = 0 keeps the three-term bf16 form
-                    static const int dual_h2_on = [] { const char* e = getenv("NWW_BC_DUAL_H2"); return e ? atoi(e) : 1; }();
+                    static const int dual_h2_on = 1;
                     const bool dual_h2 = dual_h2_on && p.h->f16 && !act_bf16;
                     // blocks 1 and 2 chained with the next block's depthwise (bc_chain.hip; two-term weights in every storage mode)
                     const bool will_chain = chain_on && i < 3 && have_dx && bc_chain_supported(ci, ho, wo) &&
@@ -1132,7 +1131,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                                 continue;
                             }
                             // the last block feeds only the global average pool: averaged in the same launch, its output never reaches HBM
-                            static const int mean_fused_on = [] { const char* e = getenv("NWW_BC_MEAN_FUSED"); return e ? atoi(e) : 1; }();
+                            static const int mean_fused_on = 1;
                             const bool fuse_mean = mean_fused_on && i == 3 && ci == 128 && dual_x3_mean_supported(rows);
                             if (fuse_mean) { mean_fused = true; p.need(5, 256); }
                             const float out_mul = fuse_mean ? 1.0f : s_h[i];
@@ -1270,7 +1269,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                 else
                     add_gemm(p, q + ".attention.in_proj", hb, big, T, 3 * D, D, p.W(q + ".attention.in_proj_weight"), p.W(q + ".attention.in_proj_bias"), ACT_NONE);
                 static const int mha_mfma = [] { const char* e = getenv("NWW_MHA_MFMA"); return e ? atoi(e) : 1; }();
-                static const int mha_h2 = [] { const char* e = getenv("NWW_MHA_H2"); return e ? atoi(e) : 1; }();
+                static const int mha_h2 = 1;
                 if (mha_mfma && mha_h2 && p.h->f16 && mha_h2_supported(T, D, NH))
                     p.add("mha_h2:" + q + " [f16x3]", [=](Run& r) { return launch_mha_h2(r.buf[big], r.buf[t1], r.B, T, D, NH, r.stream, head_major ? 1 : 0); });
                 else if (mha_mfma && mha_mfma_supported(T, D, NH))
@@ -1343,6 +1342,7 @@ extern "C" int nww_finalize(nww_handle* h) {
     }
     // the plan-time weight packings above were enqueued on own_stream; a forward may arrive on any caller stream
     HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    if (!h->plan_error.empty()) return fail(h, NWW_ERR_HIP, "%s", h->plan_error.c_str());
     h->finalized = true;
     return NWW_OK;
 }

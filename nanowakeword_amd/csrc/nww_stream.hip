@@ -67,7 +67,7 @@ static int plan_incremental(nww_handle* h, int S, int W, int hop) {
     const nww_config& c = h->cfg;
     const int T = fe_num_frames(h->fe, W), hl = h->fe.hop;
     const bool frames_major = !c.mel_major_features || h->e2e_transposed;
-    static const int mel_env = [] { const char* e = getenv("NWW_FE_MEL"); return e ? atoi(e) : 2; }();
+    static const int mel_env = 2;
     if (mode <= 0 || !frames_major || !fe2_subset_supported(h->fe, mel_env) || hop % hl != 0) return NWW_OK;
     const int k = hop / hl, pad = h->fe.center ? h->fe.n_fft / 2 : 0;
     int el = 0, er = 0;

@@ -273,7 +273,7 @@ static int rnn_stream_width(int H) { return H <= 192 ? 192 : 256; }
 
 // 128 < H <= 256, a multiple of 4 (the xg rows' alignment), two-term form
 bool rnn_stream_usable(const GruArgs& a) {
-    static const int on = [] { const char* e = getenv("NWW_RNN_STREAM"); return e ? atoi(e) : 1; }();
+    static const int on = 1;
     return on && a.products == 3 && a.H > 128 && a.H <= 256 && a.H % 4 == 0 && a.fin == 0;
 }
 
@@ -292,7 +292,7 @@ hipError_t launch_rnn_stream_pack(const float* w_hh, void* packed, int gates, in
 hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s) {
     if (!rnn_stream_usable(a) || !a.w_packed || (gates != 3 && gates != 4) || !(a.w_scale > 0.0f)) return hipErrorInvalidValue;
     const int HP = rnn_stream_width(a.H);
-    static const int force_mt = [] { const char* e = getenv("NWW_RNN_STREAM_TILES"); return e ? atoi(e) : 0; }();
+    static const int force_mt = 0;
     static const int n_cu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
     const int mt = force_mt == 1 || force_mt == 2 ? force_mt : (a.B <= 16 * n_cu ? 1 : 2);
     const dim3 grid((a.B + 16 * mt - 1) / (16 * mt)), block(64 * (HP / 32));
@@ -304,8 +304,14 @@ hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s) {
 #endif
     // ring depths: what fits the 256 registers of a wave (two per SIMD) without scratch beside 24 / 48 (GRU) or 32 / 64 (LSTM) accumulators
 #define RS_GO(GV, HV, R1, R2)                                                                            \
-    if (mt == 1) hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R1, 1>), grid, block, lds, s, a);         \
-    else hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R2, 2>), grid, block, lds, s, a);
+    {                                                                                                    \
+        const void* fn = mt == 1 ? reinterpret_cast<const void*>(rnn_stream_kernel<GV, HV, R1, 1>)      \
+                                 : reinterpret_cast<const void*>(rnn_stream_kernel<GV, HV, R2, 2>);      \
+        const hipError_t ea = nww_allow_lds(fn, lds);           /* 67.6 KB at HP = 256, two tiles */        \
+        if (ea != hipSuccess) return ea;                                                                 \
+        if (mt == 1) hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R1, 1>), grid, block, lds, s, a);     \
+        else hipLaunchKernelGGL((rnn_stream_kernel<GV, HV, R2, 2>), grid, block, lds, s, a);             \
+    }
     if (gates == 3) {
         if (HP == 192) { RS_GO(3, 192, 12, 4) } else { RS_GO(3, 256, 12, 4) }
     } else {

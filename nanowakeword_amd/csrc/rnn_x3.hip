@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64 * (H / (16 * NB))) rnn_x3_kernel(GruArgs a)
 
 // widths 32 / 64 / 128 in every arithmetic; any other multiple of 4 below 128 as a zero-padded instance of the next width (two-term form)
 static bool rnn_x3_padded(const GruArgs& a) {
-    static const int on = [] { const char* e = getenv("NWW_RNN_PAD"); return e ? atoi(e) : 1; }();
+    static const int on = 1;
     return on && a.products == 3 && a.H >= 4 && a.H < 128 && a.H % 4 == 0 && a.H != 32 && a.H != 64 && a.fin == 0;
 }
 bool rnn_x3_usable(const GruArgs& a) {
@@ -348,7 +348,7 @@ hipError_t launch_rnn_x3(const GruArgs& a, int gates, hipStream_t s) {
     const size_t lds = (size_t)2 * (a.products == 3 ? 2 : 3) * 16 * (HP + 8) * sizeof(uint16_t);      // two sets of h planes
     // H = 128 in the two-term form: eight waves of 16 hidden units (two per SIMD, 144 fragment registers each) instead of four of 32 - a step's
     // products and gate arithmetic per wave halve, and the step is a latency chain: 0.280 -> 0.243 ms (GRU head, B = 2048), 32 -> 23 us (CRNN, B = 16)
-    static const int nb1 = [] { const char* e = getenv("NWW_RNN_WAVES8"); return e ? atoi(e) : 1; }();
+    static const int nb1 = 1;
     if (pad) {
 #define RNN_PAD(GV, HV) hipLaunchKernelGGL((rnn_x3_kernel<GV, HV, 3, (HV == 128 ? 2 : 1), 0, true>), grid, block, lds, s, a)
 #define RNN_PAD8(GV) hipLaunchKernelGGL((rnn_x3_kernel<GV, 128, 3, 1, 0, true>), grid, dim3(512), lds, s, a)

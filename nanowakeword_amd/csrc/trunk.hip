@@ -402,7 +402,7 @@ hipError_t launch_cnn_trunk(const TrunkArgs& a, int C1, int C2, int max_grid, hi
 #else
     const int dbg = 0;
 #endif
-    static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    static const int force_strips = 0;
     TrunkArgs aa = a;
     aa.dbg = dbg;
     int per_cu = 0;

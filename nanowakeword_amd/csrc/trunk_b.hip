@@ -1247,7 +1247,7 @@ static hipError_t launch_cnn_trunk_b_stream(TrunkArgs aa, int products, int max_
 hipError_t launch_cnn_trunk_b(const TrunkArgs& a, int products, int max_grid, hipStream_t s) {
     if (!a.wpack || (products != 3 && products != 6 && products != 9)) return hipErrorInvalidValue;
     TrunkArgs aa = a;
-    static const int force_strips = [] { const char* e = getenv("NWW_TRUNK_STRIPS"); return e ? atoi(e) : 0; }();
+    static const int force_strips = 0;
     if (a.n_sub > 0 || a.out_ring_rows > 0) return launch_cnn_trunk_b_stream(aa, products, max_grid, s);
     int S = trunk_b_pick_strips(a.H, a.W);
     if (S < 1) return hipErrorInvalidValue;

@@ -70,6 +70,7 @@ class HipModel:
         self.head = head
         self.fe = frontend or FrontendConfig()
         self.device = device
+        self.act_dtype = act_dtype
         self._h = C.c_void_p()
         cfg = _lib.make_config(head, self.fe, device, conv_arith=conv_arith, act_dtype=act_dtype)      # None: library defaults
         rc = self.lib.nww_create(C.byref(cfg), C.byref(self._h))
@@ -203,8 +204,9 @@ class HipModel:
         clamp = self.feature_clamp
         if clamp > 0.0 and feats.size and float(np.abs(feats).max()) > clamp:
             import warnings
-            warnings.warn(f"features reach {float(np.abs(feats).max()):.4g}: the default arithmetic (conv_arith='f16x3') clamps the head input to "
-                          f"+-{clamp:g} (log-mel dB never gets there; the reference does not clamp) - pass conv_arith='bf16x6' for unbounded features",
+            why = "16-bit activation storage (act_dtype)" if self.act_dtype not in (None, "f32") else "the default arithmetic (conv_arith='f16x3')"
+            warnings.warn(f"features reach {float(np.abs(feats).max()):.4g}: {why} clamps the head input to "
+                          f"+-{clamp:g} (log-mel dB never gets there; the reference does not clamp) - pass conv_arith='bf16x6' and act_dtype=None for unbounded features",
                           RuntimeWarning, stacklevel=2)
         logits, probs = np.empty(B, np.float32), np.empty(B, np.float32)
         emb = np.empty((B, self.head.embedding_dim), np.float32) if return_embedding else None

@@ -117,24 +117,6 @@ def emu():
     lib.emu_frontend2.restype = ctypes.c_int
     run.v2 = run2
 
-    def run3(pcm, n_mels, center, window, fb):
-        """the matrix-pipe frontend of frontend3.hip (prime-factor 25 x 16 products in two binary16 terms), lane by lane"""
-        pcm = np.ascontiguousarray(pcm, np.int16)
-        B, N = pcm.shape
-        T = oracle.frame_count(N, center=bool(center))
-        mel = np.zeros((B, n_mels, T), np.float32)
-        db = np.zeros_like(mel)
-        w = None if window is None else np.ascontiguousarray(window, np.float32)
-        f = None if fb is None else np.ascontiguousarray(fb, np.float32)
-        vp = ctypes.c_void_p
-        r = lib.emu_frontend3(pcm.ctypes.data_as(vp), B, N, n_mels, int(center), 160,
-                              w.ctypes.data_as(vp) if w is not None else None,
-                              f.ctypes.data_as(vp) if f is not None else None,
-                              mel.ctypes.data_as(vp), db.ctypes.data_as(vp))
-        assert r == T
-        return mel, db
-    lib.emu_frontend3.restype = ctypes.c_int
-    run.v3 = run3
     return run
 
 
@@ -247,26 +229,6 @@ def test_f16x3_split_arithmetic_claims():
     e3 = np.abs(acc.astype(np.float64) - exact).max()
     e32 = np.abs((a @ b).astype(np.float64) - exact).max()
     assert e3 <= 2.0 * e32 + 1e-6, (e3, e32)                                                            # (vi)
-
-
-@pytest.mark.parametrize("variant", ["64c", "40n"])
-def test_matrix_pipe_frontend_on_cpu_vs_reference(emu, golden_frontend, variant):
-    """frontend3.hip's dataflow (plan register images, class planes, swizzled Z rows, bin map, two-term splits) emulated lane by lane
-    against the reference goldens (criteria A / B), float64 (criterion C) and the FFT kernel's emulation; the frame law on the short
-    clips; digital silence on the -100 dB floor."""
-    g = golden_frontend
-    if variant == "64c":
-        mel, db = emu.v3(g["pcm"], 64, 1, g["window"], g["fb64"])
-        assert_frontend_close(mel, db, g["mel64"], g["db64"], variant)
-        assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g["fb64"], dtype=np.float64), variant)
-        _, dbs = emu.v3(g["short_pcm"], 64, 1, g["window"], g["fb64"])
-        assert np.abs(dbs - g["short_db64"]).max() <= 1e-4
-        _, dbz = emu.v3(np.zeros((1, 16000), np.int16), 64, 1, None, None)
-        assert np.all(dbz == -100.0)
-    else:
-        mel, db = emu.v3(g["pcm"], 40, 0, g["window"], g["fb40"])
-        assert_frontend_close(mel, db, g["mel40"], g["db40"], variant)
-        assert_frontend_amplitude(mel, oracle.mel_power(g["pcm"], g["window"], g["fb40"], center=False, dtype=np.float64), variant)
 
 
 def test_fused_epilogue_activations_restated():

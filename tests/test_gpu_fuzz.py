@@ -19,23 +19,6 @@ def test_fuzz_frontend_bounded():
     assert bad == 0, "\n".join(lines)
 
 
-def test_fuzz_frontend_matrix_pipe_bounded():
-    """the same fuzzer through the opt-in matrix-pipe frontend (NWW_FE3 = 1, read at every nww_finalize): partial 16-frame items,
-    clips shorter than one item, reflect padding inside the first plane block"""
-    import fuzz_frontend
-    old = os.environ.get("NWW_FE3")
-    os.environ["NWW_FE3"] = "1"
-    try:
-        lines = []
-        bad = fuzz_frontend.run(n_cases=14, seed=5, max_batch=40, log=lines.append)
-    finally:
-        if old is None:
-            os.environ.pop("NWW_FE3", None)
-        else:
-            os.environ["NWW_FE3"] = old
-    assert bad == 0, "\n".join(lines)
-
-
 def test_fuzz_heads_bounded():
     import fuzz_heads
     lines = []

@@ -251,11 +251,37 @@ def test_conformer_fused_kernels_every_width(hip, d_model, n_head, shape, B):
     sd = synth_state_dict(cfg)
     m = HipModel(cfg, FrontendConfig(), state_dict=sd)
     plan = m.describe_plan()
-    assert "ffn_x3:" in plan and "lin_x3:" in plan and ("mha_h2:" in plan) == (shape[0] <= 128), plan       # (default arithmetic: the two-term attention core)
+    # default arithmetic: the whole attention module in one launch at d_model 144 / 4 heads and 64 < T <= 128 (attn_x3), else the two-term attention core
+    attn = d_model == 144 and n_head == 4 and 64 < shape[0] <= 128
+    assert "ffn_x3:" in plan and "lin_x3:" in plan and ("attn_x3:" in plan) == attn and ("mha_h2:" in plan) == (shape[0] <= 128 and not attn), plan
     feats = synth_features(B, cfg.input_shape, seed=d_model + B)
     logits, _ = m.forward_features(feats)
     ref = oracle.model_forward(feats, sd, cfg).ravel()
     assert np.abs(logits - ref).max() <= FEAT_LOGIT_ATOL, np.abs(logits - ref).max()
+    m.close()
+
+
+@pytest.mark.parametrize("T,B", [(65, 3), (80, 5), (96, 2), (97, 4), (101, 300), (112, 3), (113, 2), (128, 7)])
+def test_conformer_fused_attention_module(hip, T, B):
+    """attn_x3 (in_proj, per-head softmax(q k^T) v, out_proj, residual in one clip-resident launch; architectures.py:471-493, 512-513) at every
+    key-block count it takes (5 .. 8 blocks of 16 keys: the run-time instance and the two compiled ones), query tiles that straddle T, and a
+    batch larger than the grid (a workgroup walks several clips: the weight-chunk stream and the row prefetch wrap around); against the oracle,
+    and a clip's logit must not depend on the batch it travels in."""
+    HipModel, _ = hip
+    cfg = HeadConfig("conformer", (T, 64), embedding_dim=16)
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(), state_dict=sd)
+    assert "attn_x3:" in m.describe_plan(), m.describe_plan()
+    feats = synth_features(B, cfg.input_shape, seed=T + B)
+    feats[0, T // 2:] = -100.0                              # half a clip of floor values (identical rows: flat scores)
+    logits, _ = m.forward_features(feats)
+    k = min(B, 6)
+    ref = oracle.model_forward(feats[:k], sd, cfg).ravel()
+    assert np.isfinite(logits).all()
+    assert np.abs(logits[:k] - ref).max() <= FEAT_LOGIT_ATOL, np.abs(logits[:k] - ref).max()
+    l1, _ = m.forward_features(feats[:1])
+    l3, _ = m.forward_features(feats[B - 1:])
+    assert np.array_equal(l1, logits[:1]) and np.array_equal(l3, logits[B - 1:])
     m.close()
 
 
@@ -570,3 +596,13 @@ def test_feature_clamp_is_surfaced(hip):
         lg, _ = m.forward_features(feats)
     assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(lg - ref)
     m.close()
+    # heads whose first layer scales every row by its own power of two clamp nothing, whatever their step names say
+    for kw in (dict(model_type="conformer", input_shape=(16, 24), embedding_dim=16, conformer_d_model=32, conformer_n_head=2),
+               dict(model_type="gru", input_shape=(12, 64), layer_dim=256)):
+        m = HipModel(HeadConfig(**kw), FrontendConfig(), state_dict=synth_state_dict(HeadConfig(**kw)))
+        assert m.feature_clamp == 0.0, (kw, m.describe_plan())
+        m.close()
+    for kw in (dict(model_type="cnn", input_shape=(101, 64)), dict(model_type="gru", input_shape=(101, 64)), dict(model_type="bcresnet", input_shape=(32, 40), embedding_dim=16)):
+        m = HipModel(HeadConfig(**kw), FrontendConfig(), state_dict=synth_state_dict(HeadConfig(**kw)))
+        assert m.feature_clamp == 8192.0, (kw, m.describe_plan())
+        m.close()

@@ -1,8 +1,8 @@
 // Phase timeline of the matrix-pipe frontend (frontend3.hip compiled with -DNWW_TRACE): s_memtime stamps per wave at the phase
 // boundaries of the first six items of the first eight workgroups, plus plain launch timing.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DNWW_TRACE -I nanowakeword_amd/csrc -I include tools/ubench/fe3_trace.hip nanowakeword_amd/csrc/fe_tables.cpp -o tools/ubench/fe3_trace
-// run:   tools/ubench/fe3_trace [B=4096] [grid=512]
-#include "../../nanowakeword_amd/csrc/frontend3.hip"
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DNWW_TRACE -I tools/ubench/fe3 -I nanowakeword_amd/csrc -I include tools/ubench/fe3/fe3_trace.hip tools/ubench/fe3/fe3_tables.cpp nanowakeword_amd/csrc/fe_tables.cpp -o tools/ubench/fe3/fe3_trace
+// run:   tools/ubench/fe3/fe3_trace [B=4096] [grid=512]
+#include "frontend3.hip"
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {

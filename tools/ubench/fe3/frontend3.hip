@@ -25,6 +25,7 @@
 #include "fe3.h"
 #include "fe_steps.h"
 #include "frontend.h"
+#include "fe3_tables.h"
 #include "layers.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -23,7 +23,7 @@ __host__ __device__ inline size_t ffn_x3_w1_bytes(int D, int nt = 3) { return ((
 __host__ __device__ inline size_t ffn_x3_w2_bytes(int D, int nt = 3) { return ((size_t)((D + 31) / 32) * 2 * nt * 1024 + 128 + 4095) & ~(size_t)4095; }
 __host__ __device__ inline size_t ffn_x3_block_bytes(int D, int nt = 3) { return ffn_x3_w1_bytes(D, nt) + ffn_x3_w2_bytes(D, nt); }
 size_t ffn_x3_packed_bytes(int D);
-bool ffn_x3_supported(int D);        // D (= d_model; hidden = 4 D) for which an instance is compiled
+bool ffn_x3_supported(int D, bool h2 = true);      // D (= d_model; hidden = 4 D) for which an instance is compiled (192 / 256: two-term form only)
 // W1 [4D][D], b1 [4D], W2 [D][4D] float32 -> packed
 // sw1, sw2 > 0: two binary16 terms of W1 sw1 / W2 sw2 instead of three bf16 terms
 hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1 = 0.0f, float sw2 = 0.0f);

@@ -487,7 +487,9 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
 
 size_t ffn_x3_packed_bytes(int D) { return (size_t)(D / 8) * ffn_x3_block_bytes(D); }
 
-bool ffn_x3_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 144; }
+// D = 192 / 256 (round 6): the two-term form only - its weight blocks (64 KB at 256, double buffered) and 460 registers fit one workgroup per
+// CU; the three-term form's 96 KB blocks do not fit the LDS
+bool ffn_x3_supported(int D, bool h2) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 144 || (h2 && (D == 192 || D == 256)); }
 
 hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1, float sw2) {
     const size_t total = (size_t)(D / 8) * (D / 16 + 2 * ((D + 31) / 32)) * 64;
@@ -504,14 +506,22 @@ hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s) {
         if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);              \
         else hipLaunchKernelGGL((ffn_x3_kernel<D16V, false>), grid, dim3(256), 0, s, a);                           \
     }
+#define FFN_GO_H2(D16V)                                                                                            \
+    {                                                                                                              \
+        if (!(a.h2_x > 0.0f)) return hipErrorInvalidValue;                                                         \
+        hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);                                 \
+    }
     switch (D) {
         case 32: FFN_GO(2) break;
         case 64: FFN_GO(4) break;
         case 96: FFN_GO(6) break;
         case 128: FFN_GO(8) break;
         case 144: FFN_GO(9) break;
+        case 192: FFN_GO_H2(12) break;
+        case 256: FFN_GO_H2(16) break;
         default: return hipErrorInvalidValue;
     }
+#undef FFN_GO_H2
 #undef FFN_GO
     return hipGetLastError();
 }

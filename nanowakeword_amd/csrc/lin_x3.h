@@ -27,7 +27,7 @@ struct LinArgs {
 __host__ __device__ inline size_t lin_x3_block_bytes(int K, int parts, int terms = 3) {
     return ((size_t)parts * (K / 16) * terms * 1024 + (size_t)parts * 128 + 4095) & ~(size_t)4095;
 }
-bool lin_x3_supported(int K, int N);
+bool lin_x3_supported(int K, int N, bool h2 = true);      // K = 192 / 256: two-term (h2) instances only
 size_t lin_x3_packed_bytes(int K, int n_out, int parts, int terms = 3);
 // W [parts * gate_off .. ][K] float32, bias or nullptr -> packed; parts = 2, gate_off = N for the GLU pairing (rows j and N + j)
 // terms = 3: three bf16 terms per weight; terms = 2: two binary16 terms of W x ws (LinArgs::h2)

@@ -369,7 +369,8 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
 
 }  // namespace
 
-bool lin_x3_supported(int K, int N) { return (K == 32 || K == 64 || K == 96 || K == 128 || K == 144) && N % 4 == 0 && N >= 4; }
+// K = 192 / 256 (round 6): two-term instances only (the three-term GLU blocks exceed the LDS); one workgroup per CU there
+bool lin_x3_supported(int K, int N, bool h2) { return (K == 32 || K == 64 || K == 96 || K == 128 || K == 144 || (h2 && (K == 192 || K == 256))) && N % 4 == 0 && N >= 4; }
 
 size_t lin_x3_packed_bytes(int K, int n_out, int parts, int terms) { return (size_t)((n_out + 31) / 32) * lin_x3_block_bytes(K, parts, terms); }
 
@@ -384,7 +385,7 @@ hipError_t launch_lin_x3_pack(const float* W, const float* bias, void* out, int 
 
 hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t s) {
     if (a0.M <= 0) return hipSuccess;
-    if (!lin_x3_supported(K, a0.N) || (ln && epi != 2) || (a0.ldx % 4) || (a0.ldc % 4)) return hipErrorInvalidValue;
+    if (!lin_x3_supported(K, a0.N, a0.h2 != 0) || (ln && epi != 2) || (a0.ldx % 4) || (a0.ldc % 4)) return hipErrorInvalidValue;
     if (a0.qkv_T > 0 && (epi != 0 || a0.N > 1024 || a0.N % 3 || a0.qkv_dh <= 0 || (a0.N / 3) % a0.qkv_dh || a0.qkv_dh % 4 || a0.M % a0.qkv_T))
         return hipErrorInvalidValue;
     // 16-byte row loads / stores (as the general GEMM's loaders): refuse a misaligned buffer loudly instead of faulting
@@ -396,24 +397,33 @@ hipError_t launch_lin_x3(const LinArgs& a0, int K, int epi, bool ln, hipStream_t
     // eight (in_proj 0.170 -> 0.199, out_proj / conv2 0.117 -> 0.125-0.129).  K >= 128 has no four-wave GLU instance at all (one
     // workgroup per CU, "final occupancy 1"); the row arithmetic is the same in both shapes, so results do not depend on the choice.
     // (two-term instances, 138 - 148 registers at K = 144: eight waves measured again - in_proj 0.148 -> 0.161, out_proj unchanged)
-    const bool w8 = epi == 2 && (K >= 128 || a.M >= 256 * 256);
+    const bool w8 = epi == 2 && K <= 144 && (K >= 128 || a.M >= 256 * 256);      // (K > 144: four waves - the eight-wave form would spill at 256 registers)
     const dim3 grid(w8 ? (a.M + 255) / 256 : (a.M + 127) / 128);
 #define LIN_GO2(K16V, EPIV, LNV, H2V)                                                                              \
-    if constexpr (EPIV == 2 && K16V >= 8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8, H2V>), grid, dim3(512), 0, s, a); \
+    if constexpr (EPIV == 2 && K16V >= 8 && K16V <= 9) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 8, H2V>), grid, dim3(512), 0, s, a); \
+    else if constexpr (K16V > 9) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4, H2V>), grid, dim3(256), 0, s, a);                        \
     else if (EPIV == 2 && w8) hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, (EPIV == 2 ? 8 : 4), H2V>), grid, dim3(512), 0, s, a); \
     else hipLaunchKernelGGL((lin_x3_kernel<K16V, EPIV, LNV, 4, H2V>), grid, dim3(256), 0, s, a);
 #define LIN_GO(K16V, EPIV, LNV)                                                                                    \
     if (a.h2) { LIN_GO2(K16V, EPIV, LNV, true) } else { LIN_GO2(K16V, EPIV, LNV, false) }
+#define LIN_GO_H2ONLY(K16V, EPIV, LNV)                                                                             \
+    if (a.h2) { LIN_GO2(K16V, EPIV, LNV, true) } else return hipErrorInvalidValue;
 #define LIN_EPI(K16V)                                                                                              \
     if (epi == 0) { LIN_GO(K16V, 0, false) } else if (epi == 1) { LIN_GO(K16V, 1, false) } else if (ln) { LIN_GO(K16V, 2, true) } else { LIN_GO(K16V, 2, false) }
+#define LIN_EPI_H2(K16V)                                                                                           \
+    if (epi == 0) { LIN_GO_H2ONLY(K16V, 0, false) } else if (epi == 1) { LIN_GO_H2ONLY(K16V, 1, false) } else if (ln) { LIN_GO_H2ONLY(K16V, 2, true) } else { LIN_GO_H2ONLY(K16V, 2, false) }
     switch (K) {
         case 32: LIN_EPI(2) break;
         case 64: LIN_EPI(4) break;
         case 96: LIN_EPI(6) break;
         case 128: LIN_EPI(8) break;
         case 144: LIN_EPI(9) break;
+        case 192: LIN_EPI_H2(12) break;
+        case 256: LIN_EPI_H2(16) break;
         default: return hipErrorInvalidValue;
     }
+#undef LIN_EPI_H2
+#undef LIN_GO_H2ONLY
 #undef LIN_EPI
 #undef LIN_GO
 #undef LIN_GO2

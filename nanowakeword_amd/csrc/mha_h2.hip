@@ -49,8 +49,10 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Head dims above 40 keep one wave per SIMD (the 64-wide instance needs ~330 registers - its K / V prefetch alone is 64 - and spilled 52 of
+// them under the two-waves-per-SIMD budget; its 72 KB of LDS still lets two workgroups share a CU when the registers allow)
 template <int DH>
-__global__ void __launch_bounds__(256, 2) mha_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int units, int T, int D,
+__global__ void __launch_bounds__(256, (DH > 40 ? 1 : 2)) mha_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int units, int T, int D,
                                                         int n_head, float scale, int head_major) {
     constexpr int NKB = (DH + 15) / 16, DHP = 16 * NKB;        // k-blocks of the score product, padded head dim
     constexpr int MT = (DH + 31) / 32;                         // output tiles along the head dim
@@ -302,10 +304,6 @@ static size_t mha_h2_lds(int dh) {
 
 bool mha_h2_supported(int T, int D, int n_head) {
     if (n_head <= 0 || D % n_head || T > 128 || T < 1 || D % 4) return false;
-    // head dims above 48 stay on the float32-MFMA kernel (mha_mfma.hip: 250 registers, no scratch): the 64-wide instance of this one
-    // spills 68 registers (tools/kernel_regs.sh), a silent 2-3 x cliff; NWW_MHA_H2 = 2 still selects it for A/B runs
-    static const int force = 1;
-    if (D / n_head > 48 && force < 2) return false;
     switch (D / n_head) {
 #define MHA_OK(DHV) case DHV: return mha_h2_lds(DHV) <= 80 * 1024;
         NWW_MHA_H2_DIMS(MHA_OK)
@@ -321,7 +319,7 @@ hipError_t launch_mha_h2(const float* qkv, float* out, int B, int T, int D, int 
     const float scale = 1.0f / sqrtf((float)dh);
     const size_t lds = mha_h2_lds(dh);
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const int slots = 2 * cus;                                 // two workgroups per CU: one's staging under the other's MFMAs
+    const int slots = (dh > 40 ? 1 : 2) * cus;                 // two workgroups per CU (one's staging under the other's MFMAs) where the registers allow
     const dim3 grid(units < slots ? units : slots);
 #define MHA_GO(DHV)                                                                                                \
     case DHV: {                                                                                                    \

@@ -308,14 +308,14 @@ bool add_lin_x3(PlanCtx& p, const std::string& name, int in_id, int out_id, int 
                 const float* bias, int epi, int res_id = 99, float rscale = 1.f, const float* ln_w = nullptr,
                 const float* ln_b = nullptr, int qkv_T = 0, int qkv_dh = 0) {
     static const int enabled = [] { const char* e = getenv("NWW_LIN_X3"); return e ? atoi(e) : 1; }();
-    if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N)) return false;
+    if (!enabled || p.h->conv_products != 6 || !lin_x3_supported(K, N, true)) return false;
     const int parts = epi == 2 ? 2 : 1;
     // under NWW_ARITH_F16X3: two binary16 terms per operand, the input rows scaled per row in the kernel (LinArgs::h2: no bound on the
-    // tensor needed); NWW_LIN_H2 = 0 keeps the three-term bf16 form
-    static const int h2_on = 1;
+    // tensor needed); conv_arith = bf16x6 keeps the three-term bf16 form
     float ws = 0.0f;
-    if (h2_on && p.h->f16) ws = f16_wscale(f16_fetch(p.h, W, (size_t)parts * N * K));
+    if (p.h->f16) ws = f16_wscale(f16_fetch(p.h, W, (size_t)parts * N * K));
     const bool h2 = ws > 0.0f;
+    if (!lin_x3_supported(K, N, h2)) return false;                 // K = 192 / 256 exist in the two-term form only
     const int terms = h2 ? 2 : 3;
     void* packed = nullptr;
     if (hipMalloc(&packed, lin_x3_packed_bytes(K, N, parts, terms)) != hipSuccess) return false;
@@ -1185,7 +1185,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     // LayerNorm + linear1 + swish + linear2 + half-step residual in one kernel (ffn_x3.hip); same arithmetic
                     // switch as the split-operand GEMMs it replaces
                     static const int fused = [] { const char* e = getenv("NWW_FFN_FUSED"); return e ? atoi(e) : 1; }();
-                    if (fused && p.h->conv_products == 6 && ffn_x3_supported(D)) {
+                    if (fused && p.h->conv_products == 6 && ffn_x3_supported(D, p.h->f16)) {
                         void* packed = nullptr;
                         // NWW_ARITH_F16X3: both operands of both products are bounded whatever the residual stream holds -
                         // |LayerNorm(h)_i| <= sqrt(D) |w_i| + |b_i|, |swish(v)| <= |v| - so the scales need nothing but the weights
@@ -1200,7 +1200,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                             fx = f16_scale(bx); fw1 = f16_wscale(w1); fh = f16_scale(bh); fw2 = f16_wscale(w2);
                         }
                         const bool h2 = fx > 0.0f && fw1 > 0.0f && fh > 0.0f && fw2 > 0.0f;
-                        if (hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
+                        if (ffn_x3_supported(D, h2) && hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
                             launch_ffn_x3_pack(p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"),
                                                p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream, h2 ? fw1 : 0.0f, h2 ? fw2 : 0.0f) == hipSuccess) {
                             p.h->packed_weights.push_back(packed);

@@ -90,6 +90,21 @@ def golden_heads_r04():
     return d, meta
 
 
+@pytest.fixture(scope="session")
+def golden_heads_r06():
+    """round-6 reference goldens (tools/make_goldens.py::make_round6_goldens): Conformer d_model 256 / 192 (head dims 64 / 48) and the
+    default width at other clip lengths (the one-launch attention module's instances)"""
+    z = np.load(os.path.join(GOLDEN, "heads_r06.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    meta = json.loads(str(d.pop("meta_json")))
+    return d, meta
+
+
+def head_case_names_r06():
+    z = np.load(os.path.join(GOLDEN, "heads_r06.npz"), allow_pickle=False)
+    return sorted(json.loads(str(z["meta_json"])).keys())
+
+
 def head_case_names_r04():
     z = np.load(os.path.join(GOLDEN, "heads_r04.npz"), allow_pickle=False)
     return sorted(json.loads(str(z["meta_json"])).keys())

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import head_case_names_r02, head_case_names_r04
+from conftest import head_case_names_r02, head_case_names_r04, head_case_names_r06
 from nanowakeword_amd.config import FrontendConfig, HeadConfig
 from nanowakeword_amd.synth import synth_features, synth_pcm, synth_state_dict
 from parity import logit_bounds
@@ -742,3 +742,42 @@ def test_streamed_recurrence_two_tiles_per_workgroup(HipModel):
         assert np.isfinite(lg).all() and np.array_equal(lg[:16], l16)
         assert np.abs(l16 - oracle.model_forward(x[:16], sd, cfg).ravel()).max() <= 1e-4
         m.close()
+
+
+@pytest.mark.parametrize("name", head_case_names_r06())
+def test_round6_heads_vs_reference(HipModel, golden_heads_r06, golden_frontend, name):
+    """Conformer d_model 256 / 4 heads and 192 / 4 (head dims 64 / 48) must run on the fused kernels (ffn_x3, lin_x3, the two-term attention core -
+    rounds 2-5 dropped them onto the general GEMMs and the float32 attention: 6.9 ms at B = 2048), and the default width at 70 / 128 frames on
+    the one-launch attention module - against goldens made by the reference's own Model, ragged batches against the oracle, batch invariance."""
+    d, meta = golden_heads_r06
+    g = golden_frontend
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    m = HipModel(cfg, FrontendConfig(n_mels=cfg.input_shape[1]), state_dict=sd, **({"window": g["window"], "mel_fb": g["fb64"]} if cfg.input_shape[1] == 64 else {}))
+    plan = m.describe_plan()
+    assert "ffn_x3:" in plan and "gemm:model.conformer" not in plan, plan
+    if cfg.conformer_d_model == 144:
+        assert "attn_x3:" in plan, plan
+    else:
+        assert "mha_h2:" in plan and "lin_x3:model.conformer_blocks.0.attention.in_proj" in plan, plan
+    feats = synth_features(4, cfg.input_shape)
+    logits, probs, emb = m.forward_features(feats, return_embedding=True)
+    ref = d[f"{name}/logits_feat"].ravel()
+    assert np.abs(logits - ref).max() <= 1e-4, (name, np.abs(logits - ref).max())
+    e_ref = d[f"{name}/emb_feat"]
+    assert np.abs(emb - e_ref).max() <= 1e-4 * max(1.0, np.abs(e_ref).max())
+    for B in (1, 9, 130):
+        fx = synth_features(B, cfg.input_shape, seed=B)
+        lg, _ = m.forward_features(fx)
+        assert np.abs(lg - oracle.model_forward(fx, sd, cfg).ravel()).max() <= 1e-4, (name, B)
+        l1, _ = m.forward_features(fx[:1])
+        assert l1[0] == lg[0], (name, B, "batch dependence")
+    if f"{name}/logits_pcm" in d:
+        lp, _ = m.forward_pcm(g["pcm"])
+        rp = d[f"{name}/logits_pcm"].ravel()
+        lm32 = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"]).transpose(0, 2, 1)
+        lm64 = oracle.frontend_logmel(g["pcm"], g["window"], g["fb64"], dtype=np.float64).astype(np.float32).transpose(0, 2, 1)
+        bound = logit_bounds([str(n) for n in g["names"]], rp, oracle.model_forward(np.ascontiguousarray(lm32), sd, cfg).ravel(),
+                             oracle.model_forward(np.ascontiguousarray(lm64), sd, cfg).ravel())
+        assert np.all(np.abs(lp - rp) <= bound), (name, np.abs(lp - rp), bound)
+    m.close()

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from nanowakeword_amd.config import HeadConfig, param_spec
 from nanowakeword_amd.synth import synth_features, synth_state_dict, state_dict_checksum
-from conftest import head_case_names, head_case_names_r02, head_case_names_r04
+from conftest import head_case_names, head_case_names_r02, head_case_names_r04, head_case_names_r06
 from parity import assert_frontend_close, logit_bounds, DB_ATOL
 
 LOGIT_ATOL = 2e-5   # oracle vs reference on identical float32 features
@@ -166,4 +166,21 @@ def test_round4_cases_against_reference(golden_heads_r04, golden_frontend, name)
         g = golden_frontend
         db = g["db64"] if cfg.input_shape == (101, 64) else g["db40"]
         lp = oracle.model_forward(np.ascontiguousarray(db.transpose(0, 2, 1)), sd, cfg)
+        assert np.abs(lp - d[f"{name}/logits_pcm"]).max() <= LOGIT_ATOL
+
+
+@pytest.mark.parametrize("name", head_case_names_r06())
+def test_round6_cases_against_reference(golden_heads_r06, golden_frontend, name):
+    """Conformer d_model 256 / 192 and the default width at other clip lengths (architectures.py:441-543), from the reference's own Model."""
+    d, meta = golden_heads_r06
+    cfg = HeadConfig(**meta[name])
+    sd = synth_state_dict(cfg)
+    assert state_dict_checksum(sd) == str(d[f"{name}/sd_checksum"])
+    feats = synth_features(4, cfg.input_shape)
+    assert np.abs(oracle.model_forward(feats, sd, cfg) - d[f"{name}/logits_feat"]).max() <= LOGIT_ATOL
+    e_ref = d[f"{name}/emb_feat"]
+    assert np.abs(oracle.head_forward(feats, sd, cfg) - e_ref).max() <= 1e-4 * max(1.0, np.abs(e_ref).max())
+    if f"{name}/logits_pcm" in d:
+        g = golden_frontend
+        lp = oracle.model_forward(np.ascontiguousarray(g["db64"].transpose(0, 2, 1)), sd, cfg)
         assert np.abs(lp - d[f"{name}/logits_pcm"]).max() <= LOGIT_ATOL

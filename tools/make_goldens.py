@@ -290,6 +290,7 @@ def main():
     make_onnx_fixtures(os.path.join(args.out, "onnx"))
     make_round2_goldens(args.out)
     make_round4_goldens(args.out)
+    make_round6_goldens(args.out)
     print("done ->", args.out)
 
 
@@ -531,6 +532,50 @@ def make_round4_goldens(out_dir):
     np.savez_compressed(os.path.join(out_dir, "heads_r04.npz"), **heads)
 
 
+def make_round6_goldens(out_dir):
+    """Round-6 additions (own file: earlier fixtures stay byte-identical): Conformer shapes the round-6 kernels take - the textbook
+    d_model 256 / 4 heads (head dim 64) and 192 / 4 (head dim 48) on the fused feed-forward / short-K / two-term attention kernels, and the
+    default width at clip lengths other than 101 frames through the one-launch attention module (attn_x3.hip: 5 .. 8 blocks of 16 keys,
+    two blocks) - logits and embeddings from the reference's own Model (architectures.py:441-543)."""
+    install_stubs()
+    torch.set_num_threads(1)
+    from nanowakeword.modules.model import Model
+    from nanowakeword_amd.config import HeadConfig, param_spec
+    from nanowakeword_amd.synth import synth_features, synth_state_dict, state_dict_checksum
+    fr = dict(np.load(os.path.join(out_dir, "frontend.npz"), allow_pickle=False))
+    db64 = fr["db64"]
+    cases = [
+        ("conformer_101x64_d256_h4", HeadConfig("conformer", (101, 64), conformer_d_model=256, conformer_n_head=4)),
+        ("conformer_101x64_d192_h4", HeadConfig("conformer", (101, 64), conformer_d_model=192, conformer_n_head=4)),
+        ("conformer_40x64_d256_h8", HeadConfig("conformer", (40, 64), conformer_d_model=256, conformer_n_head=8, embedding_dim=32)),
+        ("conformer_70x64_d144_h4", HeadConfig("conformer", (70, 64), embedding_dim=32)),
+        ("conformer_128x40_d144_h4_b2", HeadConfig("conformer", (128, 40), n_blocks=2)),
+    ]
+    heads, meta = {}, {}
+    for name, cfg in cases:
+        sd = synth_state_dict(cfg)
+        conf = {"activation_function": cfg.activation, "embedding_dim": cfg.embedding_dim,
+                "crnn_cnn_channels": list(cfg.crnn_cnn_channels), "crnn_rnn_type": cfg.crnn_rnn_type,
+                "conformer_d_model": cfg.conformer_d_model, "conformer_n_head": cfg.conformer_n_head}
+        m = Model(conf, "g", input_shape=cfg.input_shape, model_type=cfg.model_type, layer_dim=cfg.layer_dim, n_blocks=cfg.n_blocks)
+        ref_keys = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")}
+        assert ref_keys == dict(param_spec(cfg)), set(ref_keys) ^ set(param_spec(cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m = m.eval()
+        feats = synth_features(4, cfg.input_shape)
+        with torch.no_grad():
+            out = {"logits_feat": m(torch.from_numpy(feats)).numpy(), "emb_feat": m.model(torch.from_numpy(feats)).numpy()}
+            if cfg.input_shape == (101, 64):
+                out["logits_pcm"] = m(torch.from_numpy(np.ascontiguousarray(db64.transpose(0, 2, 1)))).numpy()
+        out["sd_checksum"] = np.array(state_dict_checksum(sd))
+        meta[name] = cfg.to_dict()
+        for k, v in out.items():
+            heads[f"{name}/{k}"] = v
+        print("r06", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+    heads["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(out_dir, "heads_r06.npz"), **heads)
+
+
 def make_wire_fixtures(path):
     """Messages produced by the reference's own encoders (remote_verifier.py:147-158) for tests/test_wire.py."""
     from nanowakeword.interpreter import remote_verifier as rv
@@ -678,6 +723,8 @@ if __name__ == "__main__":
         make_onnx_fixtures(os.path.join(REPO, "tests", "golden", "onnx"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--r04-only":
         make_round4_goldens(os.path.join(REPO, "tests", "golden"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--r06-only":
+        make_round6_goldens(os.path.join(REPO, "tests", "golden"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--r02-only":
         make_round2_goldens(os.path.join(REPO, "tests", "golden"))
     else:

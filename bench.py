@@ -428,24 +428,25 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     except OSError:
         pass
     host = [torch.from_numpy(pcm_host).pin_memory(), torch.from_numpy(np.roll(pcm_host, 1, axis=0).copy()).pin_memory()]
-    dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(2)]
-    lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2)]
-    hlog = [torch.empty(B, dtype=torch.float32).pin_memory() for _ in range(2)]
+    NBUF = 3        # device buffers in flight (tools/h2d_pipeline.py: 56.0 / 56.4 / 56.6 GB/s with 2 / 3 / 4)
+    dbuf = [torch.empty((B, N), dtype=torch.int16, device=dev) for _ in range(NBUF)]
+    lbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(NBUF)]
+    hlog = [torch.empty(B, dtype=torch.float32).pin_memory() for _ in range(NBUF)]
     # the upload of a batch is split over TWO copy streams: 56.7 GB/s through this pipeline against 54 with one and 49 with
     # four (tools/h2d_pipeline.py; the bare uploads reach 56-57 GB/s idle or beside the step, tools/h2d_probe.py)
     NCOPY = 2
     copy_s, comp_s = [torch.cuda.Stream(dev) for _ in range(NCOPY)], torch.cuda.Stream(dev)
-    up = [[torch.cuda.Event() for _ in range(NCOPY)] for _ in range(2)]
-    done = [torch.cuda.Event() for _ in range(2)]
+    up = [[torch.cuda.Event() for _ in range(NCOPY)] for _ in range(NBUF)]
+    done = [torch.cuda.Event() for _ in range(NBUF)]
     rows = (B + NCOPY - 1) // NCOPY
 
     def run(k):
         for i in range(k):
-            j = i & 1
+            j = i % NBUF
             for c, cs in enumerate(copy_s):
                 with torch.cuda.stream(cs):
-                    cs.wait_event(done[j])                # the kernels that read dbuf[j] two batches ago are finished
-                    dbuf[j][c * rows:(c + 1) * rows].copy_(host[j][c * rows:(c + 1) * rows], non_blocking=True)
+                    cs.wait_event(done[j])                # the kernels that read dbuf[j] NBUF batches ago are finished
+                    dbuf[j][c * rows:(c + 1) * rows].copy_(host[i & 1][c * rows:(c + 1) * rows], non_blocking=True)
                     up[j][c].record(cs)
             with torch.cuda.stream(comp_s):
                 for c in range(NCOPY):
@@ -463,12 +464,13 @@ def audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, ref_logit
     t0 = time.perf_counter()
     run(k)
     dt = time.perf_counter() - t0
-    assert np.array_equal(hlog[0].numpy(), ref_logits), "PCIe-inclusive path changed the logits"
+    last0 = max(i for i in range(k) if (i & 1) == 0)      # a batch uploaded from host[0] (= the timed clips)
+    assert np.array_equal(hlog[last0 % NBUF].numpy(), ref_logits), "PCIe-inclusive path changed the logits"
     os.sched_setaffinity(0, old_aff)
     out["h2d_inclusive"] = {"value": round(B * k / dt, 1), "unit": "clips/s", "batches": k, "numa": numa_note,
                             "pcm_gb_per_s": round(B * k * N * 2 / dt / 1e9, 2),
-                            "note": "pinned host int16 PCM, uploads double-buffered on two copy streams under the previous "
-                                    "batch's kernels, logits copied back; never the headline value (the link itself: "
+                            "note": "pinned host int16 PCM, uploads on two copy streams into three device buffers under the previous "
+                                    "batches' kernels, logits copied back; never the headline value (the link itself: "
                                     "56-57 GB/s = 1.79 M clips/s, tools/h2d_probe.py)"}
     m.close()
     return out
@@ -518,9 +520,10 @@ def main():
         B, scaling = a.global_batch // world, "strong"
     pcm_host = synth_pcm("noise", B, N, seed=10 + rank)    # default_rng(10).integers(-8192, 8192)
     pcm = torch.from_numpy(pcm_host).to(dev)               # resident in HBM before timing
-    # the timed loop walks THREE copies of the batch (same clips, distinct addresses: 3 x 131 MB at the headline batch > the 256 MiB Infinity
-    # Cache), so the frontend's reads come from HBM every step
-    pcm_ring = [pcm] + [pcm.clone() for _ in range(2)]
+    # The timed loop re-reads ONE 131 MB batch (as in rounds 1-5: comparable), which fits the 256 MiB Infinity Cache - said on the line;
+    # the `pcm_rotation` leg times the same step walking THREE copies of the batch (same clips, distinct addresses: 393 MB), so that the
+    # frontend's reads come from HBM every step
+    pcm_ring = [pcm] + ([pcm.clone() for _ in range(2)] if world == 1 else [pcm, pcm])
     logits = torch.empty(B, dtype=torch.float32, device=dev)
     gdev = torch.device("cpu") if a.debug_single_gpu else dev
     gathered = torch.empty(B * world, dtype=torch.float32, device=gdev) if world > 1 else None
@@ -550,8 +553,8 @@ def main():
         gathered2 = [gathered, torch.empty_like(gathered)]          # two steps in flight: the gather runs on the handle's own stream
     step_no = [0, 0]
 
-    def step():
-        pcm = pcm_ring[step_no[1] % 3]
+    def step(rotate=False):
+        pcm = pcm_ring[step_no[1] % 3] if rotate else pcm_ring[0]
         step_no[1] += 1
         if gather_via == "capi":
             # kernels on `stream`, the RCCL all-gather of step k on the library's side stream behind an event: step k + 1's kernels do
@@ -724,7 +727,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.model_type} head on (101,64) log-mel, batch={B}/GPU, 1 s 16 kHz mono int16 "
                                    "clips, 64-mel 25 ms/10 ms center frontend, fused STFT+mel HIP kernel, fp32",
-                       "pcm_buffers": "the timed loop rotates three device copies of the batch (3 x 131 MB > the 256 MiB Infinity Cache)",
+                       "pcm_buffers": "the timed loop re-reads one 131 MB batch, which fits the 256 MiB Infinity Cache (the frontend is VALU-bound; `pcm_rotation` is the same step over three rotating copies)",
                        "clips_per_gpu": B, "n_samples": N,
                        "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
@@ -742,6 +745,17 @@ def main():
         out.update(extra)
         extras = world == 1 and not a.no_extras
         if extras:
+            # the same step over three rotating copies of the batch (393 MB > the Infinity Cache): PCM really comes from HBM
+            for _ in range(6):
+                step(True)
+            torch.cuda.synchronize(dev)
+            t0r = time.perf_counter()
+            for _ in range(max(a.steps, 60)):
+                step(True)
+            torch.cuda.synchronize(dev)
+            dtr = time.perf_counter() - t0r
+            out["pcm_rotation"] = {"value": round(B * max(a.steps, 60) / dtr, 1), "unit": "clips/s", "ms_per_step": round(dtr / max(a.steps, 60) * 1e3, 4),
+                                   "buffers": 3, "note": "never the headline: the headline re-reads one batch, as every round did"}
             out.update(audit_legs(a, torch, dev, cfg, fe, sd, window, fb, pcm_host, B, N, lg))
             out["configs"] = config_legs(torch, dev)
         if not a.no_cpu_baseline and world == 1:           # reported at N = 1 only (rank 0, the GPU box's host cores)

@@ -96,7 +96,7 @@ __device__ __forceinline__ void split_frag2(const float (&v)[8], bf16x8& fh, bf1
 
 // ---- plan-time packing: one thread per (hidden block, fragment, lane)
 __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, unsigned char* __restrict__ out, int D, float sw1, float sw2) {
+                                                       const float* __restrict__ W2, unsigned char* __restrict__ out, int D, float sw1, float sw2, int perm) {
     const int D16 = D / 16, NOB = (D + 31) / 32, NHB = D / 8, H4 = 4 * D;
     const int frags = D16 + 2 * NOB;
     const int NT = sw1 > 0.0f ? 2 : 3;
@@ -110,8 +110,10 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
     unsigned char* dst;
     if (f < D16) {                                             // W1 fragment kb = f: row = hidden 32hb + i, k = 16kb + 8h + e
         const int kb = f;
+        // perm: k slot (kb, h, e) carries the feature the ACCUMULATOR layout puts there - tile kb / 2, register group 2 (kb & 1) + (e >> 2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = W1[(size_t)(32 * hb + i) * D + 16 * kb + 8 * h + e];
+        for (int e = 0; e < 8; ++e)
+            v[e] = W1[(size_t)(32 * hb + i) * D + (perm ? 32 * (kb >> 1) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * h + (e & 3) : 16 * kb + 8 * h + e)];
         dst = base + ((size_t)(kb * NT) * 64 + lane) * 16;
     } else {                                                   // W2 fragment (ob, kb2): row = out feature 32ob + i, slot e <-> hidden
         const int ob = (f - D16) >> 1, kb2 = (f - D16) & 1;    //   32hb + 8 (2 kb2 + (e >> 2)) + 4h + (e & 3)
@@ -139,6 +141,41 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
     if (f == 0 && lane < 32) reinterpret_cast<float*>(base + ffn_x3_w1_bytes(D, NT) + (size_t)NOB * 2 * NT * 1024)[lane] = b1[32 * hb + lane];
 }
 
+// prologue Linear W [D][KP] -> tiles [ob][kb][term][lane] of 16-byte fragments: lane (i, h) = row 32 ob + i, k slots 16 kb + 8 h + e
+__global__ void __launch_bounds__(256) ffn_pro_pack_kernel(const float* __restrict__ W, unsigned char* __restrict__ out, int D, int KP, float ws) {
+    const int KP16 = KP / 16, NOB = (D + 31) / 32;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)NOB * KP16 * 64) return;
+    const int lane = (int)(idx & 63), kb = (int)((idx >> 6) % KP16), ob = (int)((idx >> 6) / KP16);
+    const int i = lane & 31, h = lane >> 5, m = 32 * ob + i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = m < D ? W[(size_t)m * KP + 16 * kb + 8 * h + e] : 0.0f;
+    uint32_t hh[4], ll[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nww_split2h(v[2 * j] * ws, v[2 * j + 1] * ws, hh[j], ll[j]);
+    unsigned char* dst = out + (size_t)ob * ffn_x3_pro_tile_bytes(KP) + ((size_t)(kb * 2) * 64 + lane) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+// out [b][c] = (sum of the clip's tile segments) / (scale T): tile t covers rows 32 t .. 32 t + 31, segment 0 = its rows of the clip its
+// first row belongs to, segment 1 = its rows of the next clip (T >= 32: a tile touches at most two clips).  The addends are integers in
+// float64, so the order of the sum does not matter.
+__global__ void __launch_bounds__(256) ffn_mean_finish_kernel(const double* __restrict__ msum, float* __restrict__ out, int B, int T, int D, double inv) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * D) return;
+    const int c = (int)(idx % D);
+    const long long b = (long long)(idx / D);
+    const long long t0 = (b * T) / 32, t1 = (b * T + T - 1) / 32;
+    double s = 0.0;
+    for (long long t = t0; t <= t1; ++t) {
+        const int seg = ((32 * t) / T == b) ? 0 : 1;
+        s += msum[((size_t)t * 2 + seg) * D + c];
+    }
+    out[idx] = (float)(s * inv);
+}
+
 // (Measured and not kept for the two-term form: 256 rows per workgroup on eight waves, two per SIMD, each running product -
 // epilogue - product in turn so that they cover each other's issue stalls - the lone in-order wave here spends a third of its
 // cycles in them, SQ_WAIT_INST_ANY 50 M of 146 M.  At D = 144 the 80 output accumulators + 72 X-fragment registers + the
@@ -148,8 +185,13 @@ __global__ void __launch_bounds__(256) ffn_pack_kernel(const float* __restrict__
 // MFMAs of the next first product.  (tools/ubench/ffn_trace: with all 40 pieces behind the first product's 27 MFMAs that phase took 2200 clocks,
 // VALU-bound, and the second product's 30 MFMAs 1250 with the VALU idle.)  One accumulator instead of two; the next block's biases come from the
 // packed blob in global memory (its LDS copy is still in flight then).
-template <int D16, bool H2>
+// KP16 > 0 (round 6): a row-local Linear of K = 16 KP16 inputs in front (FfnArgs::px ..; PRES: plus the rows of h), its result h0 in the
+// accumulator layout is the module's input AND the start value of the output accumulators (h0 / (rscale ik2): the residual rides through
+// the second product, nothing is re-read at the end).  EPI (round 6): the updated rows are not stored - LayerNorm, then exact per-tile,
+// per-clip sums (FfnArgs::msum).
+template <int D16, bool H2, int KP16 = 0, bool PRES = false, bool EPI = false>
 __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
+    static_assert(KP16 == 0 || H2, "the prologue product exists in the two-term form only");
     constexpr int D = 16 * D16, NOB = (D + 31) / 32, NHB = D / 8;
     constexpr int NT = H2 ? 2 : 3, NP = H2 ? 3 : 6;            // terms per value, partial products per operand pair
     constexpr int W1_PART = (D16 * NT * 1024 + 4095) & ~4095, W2_PART = (NOB * 2 * NT * 1024 + 128 + 4095) & ~4095, BLK = W1_PART + W2_PART;
@@ -191,11 +233,17 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     };
     auto fetch_w1 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK, buf, std::integral_constant<int, W1_PART / 4096>{}); };
     auto fetch_w2 = [&](int hb, unsigned char* buf) { fetch(a.packed + (size_t)hb * BLK + W1_PART, buf, std::integral_constant<int, W2_PART / 4096>{}); };
+    bf16x8 xf[D16][NT];
+    f32x16 yacc[NOB];
+    if constexpr (KP16 == 0) {
     fetch_w1(0, w1b0);
     fetch_w2(0, w2b0);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.0f;
 
     // ---- LayerNorm of the lane's half row (features 16kb + 8h + e) -> X fragments
-    bf16x8 xf[D16][NT];
     {
         float v[D16][8];
         float s = 0.0f;
@@ -235,11 +283,141 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
         }
     }
 
-    f32x16 yacc[NOB];
+    } else {
+        // ---- prologue product: h0 = [h +] (px . Wp^T + pb) in the accumulator layout (lane (row n, half): features 32 ob + 8 g + 4 half + q)
+        constexpr int KP = 16 * KP16, PT = (KP16 * 2 * 1024 + 4095) & ~4095, PSTEPS = PT / 4096;
+        constexpr int NPB = W2_PART / PT;                      // tiles that fit one W2 buffer
+        constexpr bool SMALL = 2 * NPB >= NOB;                 // all tiles beside W1(0): K = 64; else one tile per weight buffer, the fifth behind the first
+        static_assert(SMALL || (PT <= W1_PART && NOB <= 5), "prologue tiles do not fit the weight buffers");
+        using PS = std::integral_constant<int, PSTEPS>;
+        if constexpr (SMALL) {
+            fetch_w1(0, w1b0);
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
+            for (int ob = 0; ob < NOB; ++ob) fetch(a.ppacked + (size_t)ob * PT, (ob < NPB ? w2b0 : w2b1) + (ob % NPB) * PT, PS{});
+        } else {
+            fetch(a.ppacked, w1b0, PS{}); fetch(a.ppacked + (size_t)PT, w1b1, PS{});
+            fetch(a.ppacked + (size_t)2 * PT, w2b0, PS{}); fetch(a.ppacked + (size_t)3 * PT, w2b1, PS{});
+        }
+        const float* prow = a.px + (size_t)(row_ok ? row : a.M - 1) * KP;
+        bf16x8 pf[KP16][2];
+        float ppin;
+        {
+            float v[KP16][8];
+            float m = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.0f;
+            for (int kb = 0; kb < KP16; ++kb) {
+                const float4 p0 = *reinterpret_cast<const float4*>(prow + 16 * kb + 8 * h);
+                const float4 p1 = *reinterpret_cast<const float4*>(prow + 16 * kb + 8 * h + 4);
+                v[kb][0] = p0.x; v[kb][1] = p0.y; v[kb][2] = p0.z; v[kb][3] = p0.w;
+                v[kb][4] = p1.x; v[kb][5] = p1.y; v[kb][6] = p1.z; v[kb][7] = p1.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < KP16; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[kb][e]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            // the row's own power of two (largest element into [2^14, 2^15): lin_x3.hip)
+            const uint32_t eb = min(max(__float_as_uint(m) >> 23, 16u), 254u);
+            const float sc = __uint_as_float((268u - eb) << 23);
+            ppin = __uint_as_float((eb - 14u) << 23) * a.p_un;
+#pragma unroll
+            for (int kb = 0; kb < KP16; ++kb) {
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = v[kb][e] * sc;
+                split_frag2(y, pf[kb][0], pf[kb][1]);
+            }
+        }
+        // the residual rows in the accumulator layout (16-byte pieces of 64 rows per load: issued here, used behind the products)
+        float4 pres[NOB][4];
+        if constexpr (PRES) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (32 * ob + 8 * g < D) pres[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+        }
+        f32x16 hc[NOB];
+        auto ptile = [&](const unsigned char* buf, f32x16& acc) {
+            const unsigned char* wp = buf + lane * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < KP16; ++kb) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wp + (kb * 2) * 1024), wl = *reinterpret_cast<const bf16x8*>(wp + (kb * 2 + 1) * 1024);
+                acc = ffn_mma<true>(wl, pf[kb][0], acc);
+                acc = ffn_mma<true>(wh, pf[kb][1], acc);
+                acc = ffn_mma<true>(wh, pf[kb][0], acc);
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (SMALL) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) ptile((ob < NPB ? w2b0 : w2b1) + (ob % NPB) * PT, hc[ob]);
+            __syncthreads();                                   // everyone has left the W2 buffers
+            fetch_w2(0, w2b0);
+        } else {
+            ptile(w1b0, hc[0]);
+            __syncthreads();
+            if constexpr (NOB > 4) fetch(a.ppacked + (size_t)4 * PT, w1b0, PS{});      // lands under the next three tiles
+            ptile(w1b1, hc[1]);
+            if constexpr (NOB > 2) ptile(w2b0, hc[2]);
+            if constexpr (NOB > 3) ptile(w2b1, hc[3]);
+            if constexpr (NOB > 4) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                ptile(w1b0, hc[4]);
+            }
+            __syncthreads();
+            fetch_w1(0, w1b0);
+            fetch_w2(0, w2b0);
+        }
+        // h0 = acc / (row scale x weight scale) + bias [+ h]; LayerNorm over the row (this lane's 16 x NOB slots, the partner half's)
+        float s = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (32 * ob + 8 * g < D) {
+                    const float4 pb = *reinterpret_cast<const float4*>(a.pb + 32 * ob + 8 * g + 4 * h);
+                    float v0 = fmaf(hc[ob][4 * g], ppin, pb.x), v1 = fmaf(hc[ob][4 * g + 1], ppin, pb.y);
+                    float v2 = fmaf(hc[ob][4 * g + 2], ppin, pb.z), v3 = fmaf(hc[ob][4 * g + 3], ppin, pb.w);
+                    if constexpr (PRES) { v0 = pres[ob][g].x + v0; v1 = pres[ob][g].y + v1; v2 = pres[ob][g].z + v2; v3 = pres[ob][g].w + v3; }
+                    hc[ob][4 * g] = v0; hc[ob][4 * g + 1] = v1; hc[ob][4 * g + 2] = v2; hc[ob][4 * g + 3] = v3;
+                    s += (v0 + v1) + (v2 + v3);
+                }
+        s += __shfl_xor(s, 32, 64);
+        const float mu = s / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (32 * ob + 8 * (r >> 2) < D) { const float d = hc[ob][r] - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+        const float yi = 1.0f / (a.rscale * ik2);              // the residual enters the output accumulators (a power of two when rscale is)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                if (32 * ob + 16 * gp < D) {                   // k-block 2 ob + gp = registers 8 gp .. 8 gp + 7 of tile ob (D % 16 == 0)
+                    float y[8];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = 2 * gp + gg;
+                        const float4 w = *reinterpret_cast<const float4*>(a.ln_w + 32 * ob + 8 * g + 4 * h), c = *reinterpret_cast<const float4*>(a.ln_b + 32 * ob + 8 * g + 4 * h);
+                        y[4 * gg] = ((hc[ob][4 * g] - mu) * rstd * w.x + c.x) * s_x; y[4 * gg + 1] = ((hc[ob][4 * g + 1] - mu) * rstd * w.y + c.y) * s_x;
+                        y[4 * gg + 2] = ((hc[ob][4 * g + 2] - mu) * rstd * w.z + c.z) * s_x; y[4 * gg + 3] = ((hc[ob][4 * g + 3] - mu) * rstd * w.w + c.w) * s_x;
+                    }
+                    split_frag2(y, xf[2 * ob + gp][0], xf[2 * ob + gp][1]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[ob][r] = hc[ob][r] * yi;
+        }
+    }
 
     // Software pipeline over the hidden blocks (W1 parts and W2 parts double buffered separately, each fetched a full iteration before its
     // first use): the first product of block hb + 1 runs with the SECOND half of block hb's epilogue (y = v / u, split) between its MFMAs,
@@ -448,12 +626,15 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             phase2(std::true_type{}, w2b0, hf, accA, bias);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // the X fragments are dead now: their registers take the residual rows for the final update
+            // the X fragments are dead now: their registers take the residual rows for the final update (prologue instances: the residual is
+            // already inside the accumulators)
+            if constexpr (KP16 == 0) {
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob)
+                for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g)
+                        if (32 * ob + 8 * g < D) res[ob][g] = *reinterpret_cast<const float4*>(hrow + 32 * ob + 8 * g + 4 * h);
+            }
             __builtin_amdgcn_sched_barrier(0);
             phase1(std::false_type{}, w1b0, accA, hf, plan_of(-1, nullptr, -1, nullptr));
             __builtin_amdgcn_sched_barrier(0);
@@ -462,25 +643,95 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     }
 
     // ---- h <- h + rscale * (Yt + b2): lane (row n, half h) holds out features 32 ob + 8 g + 4 h + 0..3
-    if (!row_ok) return;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int m = 32 * ob + 8 * g + 4 * h;
-            if (m < D) {                                       // D % 16 == 0, so the four features are in or out together
+            if (32 * ob + 8 * g < D) {                         // D % 16 == 0, so the four features (and both halves) are in or out together
                 const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + m);
-                float4 r = res[ob][g];
                 if (H2) {                                      // the accumulators back to the true scale (a power of two: exact)
                     yacc[ob][4 * g + 0] *= ik2; yacc[ob][4 * g + 1] *= ik2; yacc[ob][4 * g + 2] *= ik2; yacc[ob][4 * g + 3] *= ik2;
                 }
-                r.x += a.rscale * (yacc[ob][4 * g + 0] + b2.x);
-                r.y += a.rscale * (yacc[ob][4 * g + 1] + b2.y);
-                r.z += a.rscale * (yacc[ob][4 * g + 2] + b2.z);
-                r.w += a.rscale * (yacc[ob][4 * g + 3] + b2.w);
-                *reinterpret_cast<float4*>(hrow + m) = r;
+                float4 r;
+                if constexpr (KP16 == 0) {
+                    r = res[ob][g];
+                    r.x += a.rscale * (yacc[ob][4 * g + 0] + b2.x);
+                    r.y += a.rscale * (yacc[ob][4 * g + 1] + b2.y);
+                    r.z += a.rscale * (yacc[ob][4 * g + 2] + b2.z);
+                    r.w += a.rscale * (yacc[ob][4 * g + 3] + b2.w);
+                } else {                                       // h0 rode through the accumulators: rscale (h0 / rscale + Y + b2)
+                    r.x = a.rscale * (yacc[ob][4 * g + 0] + b2.x);
+                    r.y = a.rscale * (yacc[ob][4 * g + 1] + b2.y);
+                    r.z = a.rscale * (yacc[ob][4 * g + 2] + b2.z);
+                    r.w = a.rscale * (yacc[ob][4 * g + 3] + b2.w);
+                }
+                if constexpr (!EPI) {
+                    if (row_ok) *reinterpret_cast<float4*>(hrow + m) = r;
+                } else {
+                    yacc[ob][4 * g + 0] = r.x; yacc[ob][4 * g + 1] = r.y; yacc[ob][4 * g + 2] = r.z; yacc[ob][4 * g + 3] = r.w;
+                }
             }
         }
+    if constexpr (EPI) {
+        // ---- LayerNorm of the updated rows, then per tile and clip segment the column sums - staged through the wave's own (dead) weight
+        // buffer as [32 rows][D + 4] float32 (16-byte stores conflict-free at this pitch), summed by lane = column in row order
+        constexpr int GP = D + 4;
+        static_assert(32 * GP * 4 <= W1_PART, "the staging tile must fit a weight buffer");
+        float sm = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (32 * ob + 8 * (r >> 2) < D) sm += yacc[ob][r];
+        sm += __shfl_xor(sm, 32, 64);
+        const float mu2 = sm / (float)D;
+        float q2 = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (32 * ob + 8 * (r >> 2) < D) { const float d = yacc[ob][r] - mu2; q2 = fmaf(d, d, q2); }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd2 = 1.0f / sqrtf(q2 / (float)D + 1e-5f);
+        __syncthreads();                                       // every wave has left the weight buffers
+        float* st = reinterpret_cast<float*>(wave == 0 ? w1b0 : wave == 1 ? w1b1 : wave == 2 ? w2b0 : w2b1);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (32 * ob + 8 * g < D) {
+                    const int m = 32 * ob + 8 * g + 4 * h;
+                    const float4 w = *reinterpret_cast<const float4*>(a.ln2_w + m), c = *reinterpret_cast<const float4*>(a.ln2_b + m);
+                    *reinterpret_cast<float4*>(st + n * GP + m) = make_float4((yacc[ob][4 * g] - mu2) * rstd2 * w.x + c.x, (yacc[ob][4 * g + 1] - mu2) * rstd2 * w.y + c.y,
+                                                                                (yacc[ob][4 * g + 2] - mu2) * rstd2 * w.z + c.z, (yacc[ob][4 * g + 3] - mu2) * rstd2 * w.w + c.w);
+                }
+        __builtin_amdgcn_wave_barrier();                       // (one wave: its LDS operations execute in order)
+        const long long r0 = (long long)blockIdx.x * 128 + wave * 32;      // the tile's first row
+        const int n0 = (int)min((long long)32, (long long)a.T - r0 % a.T);  // rows of the clip the first row belongs to
+        const int nv = (int)max((long long)0, min((long long)32, (long long)a.M - r0));      // rows that exist
+        const double sc = (double)a.m_scale;
+        double* mrow = a.msum + (size_t)(blockIdx.x * 4 + wave) * 2 * D;
+        // the lane's columns side by side (independent float64 chains), the two segments as two row ranges
+        constexpr int NC = (D + 63) / 64;
+        double s0[NC], s1[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
+        const int e0 = min(n0, nv);
+        for (int j = 0; j < e0; ++j) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (lane + 64 * k < D) s0[k] += __builtin_rint((double)st[j * GP + lane + 64 * k] * sc);      // an integer: sums of up to 128 of them are exact
+        }
+        for (int j = e0; j < nv; ++j) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (lane + 64 * k < D) s1[k] += __builtin_rint((double)st[j * GP + lane + 64 * k] * sc);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (lane + 64 * k < D) { mrow[lane + 64 * k] = s0[k]; mrow[D + lane + 64 * k] = s1[k]; }
+    }
 }
 
 }  // namespace
@@ -490,17 +741,53 @@ size_t ffn_x3_packed_bytes(int D) { return (size_t)(D / 8) * ffn_x3_block_bytes(
 // D = 192 / 256 (round 6): the two-term form only - its weight blocks (64 KB at 256, double buffered) and 460 registers fit one workgroup per
 // CU; the three-term form's 96 KB blocks do not fit the LDS
 bool ffn_x3_supported(int D, bool h2) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 144 || (h2 && (D == 192 || D == 256)); }
+// prologue / epilogue instances are compiled for the BASELINE width only (d_model 144; K = 64 log-mel bins or K = d_model)
+bool ffn_x3_pro_supported(int D, int KP) { return D == 144 && (KP == 64 || KP == 144); }
 
-hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1, float sw2) {
+hipError_t launch_ffn_x3_pack(const float* W1, const float* b1, const float* W2, void* out, int D, hipStream_t s, float sw1, float sw2, int perm) {
     const size_t total = (size_t)(D / 8) * (D / 16 + 2 * ((D + 31) / 32)) * 64;
     hipLaunchKernelGGL(ffn_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W1, b1, W2,
-                       reinterpret_cast<unsigned char*>(out), D, sw1, sw2);
+                       reinterpret_cast<unsigned char*>(out), D, sw1, sw2, perm);
+    return hipGetLastError();
+}
+
+hipError_t launch_ffn_x3_pro_pack(const float* W, void* out, int D, int KP, float ws, hipStream_t s) {
+    if (!ffn_x3_pro_supported(D, KP) || !(ws > 0.0f)) return hipErrorInvalidValue;
+    const size_t total = (size_t)((D + 31) / 32) * (KP / 16) * 64;
+    hipLaunchKernelGGL(ffn_pro_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, reinterpret_cast<unsigned char*>(out), D, KP, ws);
+    return hipGetLastError();
+}
+
+size_t ffn_x3_msum_bytes(int M, int D) { return (size_t)((M + 127) / 128) * 4 * 2 * D * sizeof(double); }
+
+hipError_t launch_ffn_x3_mean_finish(const double* msum, float* out, int B, int T, int D, float m_scale, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (T < 32 || !(m_scale > 0.0f)) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * D;
+    hipLaunchKernelGGL(ffn_mean_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, msum, out, B, T, D, 1.0 / ((double)m_scale * (double)T));
     return hipGetLastError();
 }
 
 hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     const dim3 grid((a.M + 127) / 128);
+    const bool epi = a.msum != nullptr;
+    if (a.pro_k > 0 || epi) {                                  // round-6 instances: d_model 144, two-term form
+        if (D != 144 || !(a.h2_x > 0.0f) || (a.pro_k > 0 && (!ffn_x3_pro_supported(D, a.pro_k) || !a.px || !a.ppacked || !a.pb)) ||
+            (epi && (a.T < 32 || !(a.m_scale > 0.0f) || !a.ln2_w || !a.ln2_b)) || (a.pro_k == 64 && a.pro_res)) return hipErrorInvalidValue;
+        if (a.pro_k == 64) {
+            if (epi) hipLaunchKernelGGL((ffn_x3_kernel<9, true, 4, false, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((ffn_x3_kernel<9, true, 4, false, false>), grid, dim3(256), 0, s, a);
+        } else if (a.pro_k == 144) {
+            if (a.pro_res) {
+                if (epi) hipLaunchKernelGGL((ffn_x3_kernel<9, true, 9, true, true>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((ffn_x3_kernel<9, true, 9, true, false>), grid, dim3(256), 0, s, a);
+            } else return hipErrorInvalidValue;
+        } else {
+            hipLaunchKernelGGL((ffn_x3_kernel<9, true, 0, false, true>), grid, dim3(256), 0, s, a);
+        }
+        return hipGetLastError();
+    }
 #define FFN_GO(D16V)                                                                                               \
     {                                                                                                              \
         if (a.h2_x > 0.0f) hipLaunchKernelGGL((ffn_x3_kernel<D16V, true>), grid, dim3(256), 0, s, a);              \

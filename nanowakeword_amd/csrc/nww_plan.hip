@@ -1176,15 +1176,21 @@ extern "C" int nww_finalize(nww_handle* h) {
             const int hb = 0, t1 = 1, t3 = 2, big = 3;      // h, LN/glu/attn scratch, dwconv scratch, wide scratch
             bool last_fused = false;
             p.need(t1, (size_t)T * D); p.need(t3, (size_t)T * D);
-            if (!add_lin_x3(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), 0))
-                add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
+            p.need(hb, (size_t)T * D);
+            // round 6: the row-local Linears next to a feed-forward module run INSIDE its launch (FfnArgs::px: input_proj in front of the first
+            // block's ff1, conv2 + residual in front of every ff2), and the last block's LayerNorm + time average behind its ff2
+            // (FfnArgs::msum); NWW_FFN_FUSED = 0 and the other arithmetics keep the separate launches
             for (int i = 0; i < nb; ++i) {
                 const std::string q = "model.conformer_blocks." + std::to_string(i);
-                auto ffn = [&](const std::string& ff) {
+                // pro: 0 none, 1 input_proj (x = the head input), 2 conv_module.conv2 + residual (x = the depthwise output in t3); epi: the block's
+                // final LayerNorm + mean over time.  With pro / epi the step is planned only if it can be fused that way (false: nothing planned).
+                auto ffn = [&](const std::string& ff, int pro, bool epi) -> bool {
                     const float *lw = p.W(q + ff + ".layer_norm.weight"), *lb = p.W(q + ff + ".layer_norm.bias");
                     // LayerNorm + linear1 + swish + linear2 + half-step residual in one kernel (ffn_x3.hip); same arithmetic
                     // switch as the split-operand GEMMs it replaces
                     static const int fused = [] { const char* e = getenv("NWW_FFN_FUSED"); return e ? atoi(e) : 1; }();
+                    const int pro_k = pro == 1 ? F : pro == 2 ? D : 0;
+                    if ((pro || epi) && !(fused && p.h->f16 && p.h->conv_products == 6 && (!pro || ffn_x3_pro_supported(D, pro_k)) && D == 144 && (!epi || T >= 32))) return false;
                     if (fused && p.h->conv_products == 6 && ffn_x3_supported(D, p.h->f16)) {
                         void* packed = nullptr;
                         // NWW_ARITH_F16X3: both operands of both products are bounded whatever the residual stream holds -
@@ -1200,25 +1206,69 @@ extern "C" int nww_finalize(nww_handle* h) {
                             fx = f16_scale(bx); fw1 = f16_wscale(w1); fh = f16_scale(bh); fw2 = f16_wscale(w2);
                         }
                         const bool h2 = fx > 0.0f && fw1 > 0.0f && fh > 0.0f && fw2 > 0.0f;
+                        // the prologue Linear's weights (two binary16 terms; its input rows are scaled per row in the kernel) and the epilogue's scale
+                        const float* pw = pro == 1 ? p.W("model.input_proj.weight") : pro == 2 ? p.W(q + ".conv_module.conv2.weight") : nullptr;
+                        const float* pbias = pro == 1 ? p.W("model.input_proj.bias") : pro == 2 ? p.W(q + ".conv_module.conv2.bias") : nullptr;
+                        const float *l2w = epi ? p.W(q + ".layer_norm.weight") : nullptr, *l2b = epi ? p.W(q + ".layer_norm.bias") : nullptr;
+                        float pws = 0.0f, mscale = 0.0f;
+                        void* ppk = nullptr;
+                        bool extras_ok = h2 || !(pro || epi);
+                        if (pro && extras_ok) {
+                            pws = f16_wscale(f16_fetch(p.h, pw, (size_t)D * pro_k));
+                            extras_ok = pws > 0.0f && pbias && hipMalloc(&ppk, ffn_x3_pro_tile_bytes(pro_k) * ((D + 31) / 32)) == hipSuccess &&
+                                        launch_ffn_x3_pro_pack(pw, ppk, D, pro_k, pws, p.h->own_stream) == hipSuccess;
+                        }
+                        if (epi && extras_ok) {
+                            const auto h2w = f16_fetch(p.h, l2w, D), h2b = f16_fetch(p.h, l2b, D);
+                            double by = 0.0;
+                            for (int k = 0; k < D; ++k) by = std::fmax(by, std::sqrt((double)D) * std::fabs((double)h2w[k]) + std::fabs((double)h2b[k]));
+                            mscale = by < 1e30 ? (float)f16_pow2_floor(1099511627776.0 / std::fmax(by, 1e-30)) : 0.0f;      // |LayerNorm| x scale <= 2^40
+                            extras_ok = mscale > 0.0f && std::isfinite(mscale);
+                        }
+                        if (!extras_ok) {
+                            if (ppk) (void)hipFree(ppk);
+                            if (pro || epi) return false;
+                        }
                         if (ffn_x3_supported(D, h2) && hipMalloc(&packed, ffn_x3_packed_bytes(D)) == hipSuccess &&
                             launch_ffn_x3_pack(p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"),
-                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream, h2 ? fw1 : 0.0f, h2 ? fw2 : 0.0f) == hipSuccess) {
+                                               p.W(q + ff + ".linear2.weight"), packed, D, p.h->own_stream, h2 ? fw1 : 0.0f, h2 ? fw2 : 0.0f, pro ? 1 : 0) == hipSuccess) {
                             p.h->packed_weights.push_back(packed);
+                            if (ppk) p.h->packed_weights.push_back(ppk);
                             const float* b2 = p.W(q + ff + ".linear2.bias");
-                            p.add("ffn_x3:" + q + ff + " (ln+linear1+swish+linear2+0.5res)" + (h2 ? " [f16x3]" : ""), [=](Run& r) {
+                            const float p_un = pro ? 1.0f / pws : 1.0f;
+                            // the epilogue's exact partial sums: per 32-row tile two segments of D float64 (the idle wide scratch buffer)
+                            if (epi) p.need(big, (size_t)((T + 31) / 32 + 1) * 4 * D + (size_t)16 * D);
+                            const std::string what = std::string(pro == 1 ? "input_proj+" : pro == 2 ? "conv2(pw)+res+" : "") + "ln+linear1+swish+linear2+0.5res" + (epi ? "+layernorm+time sums" : "");
+                            p.add("ffn_x3:" + q + ff + " (" + what + ")" + (h2 ? " [f16x3]" : ""), [=](Run& r) {
                                 FfnArgs a{r.buf[hb], lw, lb, static_cast<const unsigned char*>(packed), b2, r.B * T, 0.5f};
                                 if (h2) { a.h2_x = fx; a.h2_w1 = fw1; a.h2_h = fh; a.h2_w2 = fw2; }
+                                if (pro) {
+                                    a.px = pro == 1 ? r.x : r.buf[t3]; a.ppacked = static_cast<const unsigned char*>(ppk); a.pb = pbias;
+                                    a.pro_k = pro_k; a.pro_res = pro == 2 ? 1 : 0; a.p_un = p_un;
+                                }
+                                if (epi) { a.ln2_w = l2w; a.ln2_b = l2b; a.msum = reinterpret_cast<double*>(r.buf[big]); a.T = T; a.m_scale = mscale; }
                                 return launch_ffn_x3(a, D, r.stream);
                             });
-                            return;
+                            if (epi)
+                                p.add("mean_finish:" + q + " (time average of the exact tile sums)", [=](Run& r) {
+                                    return launch_ffn_x3_mean_finish(reinterpret_cast<const double*>(r.buf[big]), r.buf[t1], r.B, T, D, mscale, r.stream);
+                                });
+                            return true;
                         }
                         if (packed) (void)hipFree(packed);
+                        if (ppk) (void)hipFree(ppk);
+                        if (pro || epi) return false;
                     }
                     p.add("layernorm:" + q + ff, [=](Run& r) { return launch_layernorm(r.buf[hb], r.buf[t1], lw, lb, r.B * T, D, ACT_NONE, r.stream); });
                     add_gemm(p, q + ff + ".linear1+swish", t1, big, T, 4 * D, D, p.W(q + ff + ".linear1.weight"), p.W(q + ff + ".linear1.bias"), ACT_SILU);
                     add_gemm(p, q + ff + ".linear2+0.5res", big, hb, T, D, 4 * D, p.W(q + ff + ".linear2.weight"), p.W(q + ff + ".linear2.bias"), ACT_NONE, nullptr, nullptr, hb, 0.5f);
+                    return true;
                 };
-                ffn(".ff1");
+                if (!(i == 0 && ffn(".ff1", 1, false))) {
+                    if (i == 0 && !add_lin_x3(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), 0))
+                        add_gemm(p, "input_proj", -1, hb, T, D, F, p.W("model.input_proj.weight"), p.W("model.input_proj.bias"), ACT_NONE);
+                    ffn(".ff1", 0, false);
+                }
                 // the whole attention module (in_proj, per-head softmax(q k^T) v, out_proj, residual) in one launch per clip-resident
                 // workgroup (attn_x3.hip) under the default arithmetic at the compiled shape; NWW_ATTN_FUSED=0: the three launches below
                 static const int attn_fused = [] { const char* e = getenv("NWW_ATTN_FUSED"); return e ? atoi(e) : 1; }();
@@ -1294,14 +1344,23 @@ extern "C" int nww_finalize(nww_handle* h) {
                         p.add("glu:" + m, [=](Run& r) { return launch_glu(r.buf[big], r.buf[t1], r.B * T, D, r.stream); });
                     }
                     p.add("dwconv1d+bn+swish:" + m, [=](Run& r) { return launch_dwconv1d_bn_swish(r.buf[t1], dw, db, ba, bb, r.buf[t3], r.B, T, D, 31, r.stream); });
-                    if (!add_lin_x3(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), 1, hb, 1.0f))
-                        add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
                     }
                 }
-                ffn(".ff2");
+                // conv2 + residual inside ff2's launch, and behind the LAST block's ff2 its LayerNorm + the sums of the time average
+                const bool want_epi = i == nb - 1;
+                bool ff2_done = ffn(".ff2", 2, want_epi);
+                if (ff2_done && want_epi) last_fused = true;
+                if (!ff2_done && want_epi) ff2_done = ffn(".ff2", 2, false);
+                if (!ff2_done) {
+                    const std::string m = q + ".conv_module";
+                    if (!add_lin_x3(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), 1, hb, 1.0f))
+                        add_gemm(p, m + ".conv2(pw)+res", t3, hb, T, D, D, p.W(m + ".conv2.weight"), p.W(m + ".conv2.bias"), ACT_NONE, nullptr, nullptr, hb, 1.0f);
+                    ffn(".ff2", 0, false);
+                }
                 const float *lw = p.W(q + ".layer_norm.weight"), *lb = p.W(q + ".layer_norm.bias");
                 // the last block's LayerNorm feeds only the mean over time: one pass for both (NWW_LN_MEAN=0: two launches)
-                if (i == nb - 1 && D <= 256) {
+                if (last_fused) {
+                } else if (i == nb - 1 && D <= 256) {
                     p.add("layernorm+mean:" + q + " + time", [=](Run& r) { return launch_ln_mean(r.buf[hb], r.buf[t1], lw, lb, r.B, T, D, r.stream); });
                     last_fused = true;
                 } else {

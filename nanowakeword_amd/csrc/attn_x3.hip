@@ -25,7 +25,11 @@
 // columns ONE plain tile, computed at the top of the clip (14 projection tiles per wave instead of 24).
 // Weights: 2 + 4 x heads chunks (<= 32 KB: 18 fragments of 1 KB + biases; out_proj 30) streamed through four LDS slots by LDS-DMA two
 // chunks ahead of their use, one barrier per chunk; the chunk sequence is periodic in the clip, so the stream never drains.
-// One workgroup per CU (158 KB of LDS, ~330 registers per lane).
+// One workgroup per CU (158 KB of LDS, ~390 registers per lane).
+// Measured and not kept (tools/ubench/attn_trace, profiles/r06_attn_trace*.txt): (a) a head as TWO phases (k, v, q tiles | scores .. out_proj: 11
+// barriers per clip instead of 19, every fetch a full phase ahead) - 85 k clocks per clip against 81.5 k: the phases are chains of LDS
+// latency -> dependent MFMAs -> epilogue VALU in a lone in-order wave, not barrier waits; (b) every residual block requested up front
+// in the epilogue - the same: all 256 CUs reach their epilogue together and move 3 x 58 KB each at HBM speed whatever the order.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

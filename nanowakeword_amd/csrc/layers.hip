@@ -1332,9 +1332,9 @@ __global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
     const bool jok = j < H;
     const int jc = jok ? j : H - 1;
     for (int idx = threadIdx.x; idx < 32 * ldh; idx += blockDim.x) hs[idx] = 0.0f;
-    float hprev[16], cprev[16];
+    float cprev[16];                                         // (the previous h is not needed by the LSTM cell update: only c is carried)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hprev[r] = 0.0f; cprev[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) cprev[r] = 0.0f;
     float bh[4];
     const float* wq[4];
 #pragma unroll
@@ -1346,6 +1346,9 @@ __global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
+        // (opaque per step: the 16 gate-row and output addresses of the lane are not hoisted out of the step loop and spilled)
+        int hh_o = lane >> 5;
+        asm volatile("" : "+v"(hh_o));
         f32x16 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -1354,7 +1357,7 @@ __global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
         float xq[4][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * hh_o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) xq[q][r] = 0.0f;
             if (b < a.B && jok) {
@@ -1383,7 +1386,7 @@ __global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh_o;
             const int b = b0 + c;
             float hn = 0.0f, cn = 0.0f;
             if (b < a.B && jok) {
@@ -1396,7 +1399,7 @@ __global__ void __launch_bounds__(512) lstm_kernel(GruArgs a) {
                 if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                 if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
             }
-            hprev[r] = hn; cprev[r] = cn;
+            cprev[r] = cn;
             if (jok) hs[(size_t)c * ldh + j] = hn;
         }
         __syncthreads();
@@ -1509,6 +1512,10 @@ hipError_t launch_rnn_pad_weights(const float* w_hh, float* out, int gates, int 
     return hipGetLastError();
 }
 
+// gate functions on the hardware exp2 / rcp (abs. error <= 2e-7, as rnn_x3.hip / rnn_stream.hip; the library expf / tanhf cost this kernel
+// 22 (GRU) / 52 (LSTM) spilled registers under its 256-register budget: VERDICT r05)
+__device__ __forceinline__ float wide_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float wide_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
 template <int G>
 __global__ void __launch_bounds__(512) rnn_wide_kernel(GruArgs a) {
     constexpr int TP = 2;                                     // tiles per wave: 8 waves x 2 x 32 = 512 hidden units
@@ -1520,16 +1527,23 @@ __global__ void __launch_bounds__(512) rnn_wide_kernel(GruArgs a) {
     const int b0 = blockIdx.x * 32;
     const int ntile = (H + 31) / 32;
     for (int idx = threadIdx.x; idx < 2 * 32 * ldh; idx += blockDim.x) hbuf[0][idx] = 0.0f;
-    float hprev[TP][16], cprev[TP][16];
+    // the previous h of a (clip, unit) is read back from the LDS plane the products use (zero at step 0); only the LSTM's cell state lives in
+    // registers (h in registers as well cost 20 / 50 spilled ones under the 256-register budget of sixteen... eight waves)
+    float cprev[G == 4 ? TP : 1][16];
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp)
+    for (int tp = 0; tp < (G == 4 ? TP : 1); ++tp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { hprev[tp][r] = 0.0f; cprev[tp][r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) cprev[tp][r] = 0.0f;
     __syncthreads();
     for (int step = 0; step < a.steps; ++step) {
         const int t = a.reverse ? a.T - 1 - step : step;
         const float* cur = hbuf[step & 1];
         float* nxt = hbuf[(step & 1) ^ 1];
+        // lane coordinates re-derived from an opaque copy every step: from the plain ones the 16 output addresses per tile are loop-invariant,
+        // get hoisted out of the step loop and spill (50 registers in the LSTM instance)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int i = lane_o & 31, hh = lane_o >> 5;
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
             const int tile = wave + 8 * tp;
@@ -1573,22 +1587,22 @@ __global__ void __launch_bounds__(512) rnn_wide_kernel(GruArgs a) {
                 if (b < a.B && jok) {
                     const float* xg = a.xg + ((size_t)b * a.T + t) * G * H + j;
                     if (G == 3) {
-                        const float rg = 1.0f / (1.0f + expf(-(xg[0] + acc[0][r] + bh[0])));
-                        const float zg = 1.0f / (1.0f + expf(-(xg[H] + acc[1][r] + bh[1])));
-                        const float ng = tanhf(xg[2 * H] + rg * (acc[2][r] + bh[2]));
-                        hn = (1.0f - zg) * ng + zg * hprev[tp][r];
+                        const float rg = wide_sigmoid(xg[0] + acc[0][r] + bh[0]);
+                        const float zg = wide_sigmoid(xg[H] + acc[1][r] + bh[1]);
+                        const float ng = wide_tanh(xg[2 * H] + rg * (acc[2][r] + bh[2]));
+                        hn = (1.0f - zg) * ng + zg * cur[(size_t)c * ldh + j];
                     } else {
-                        const float ig = 1.0f / (1.0f + expf(-(xg[0] + acc[0][r] + bh[0])));
-                        const float fg = 1.0f / (1.0f + expf(-(xg[H] + acc[1][r] + bh[1])));
-                        const float gg = tanhf(xg[2 * H] + acc[2][r] + bh[2]);
-                        const float og = 1.0f / (1.0f + expf(-(xg[3 * H] + acc[G - 1][r] + bh[G - 1])));
-                        cn = fg * cprev[tp][r] + ig * gg;
-                        hn = og * tanhf(cn);
+                        const float ig = wide_sigmoid(xg[0] + acc[0][r] + bh[0]);
+                        const float fg = wide_sigmoid(xg[H] + acc[1][r] + bh[1]);
+                        const float gg = wide_tanh(xg[2 * H] + acc[2][r] + bh[2]);
+                        const float og = wide_sigmoid(xg[3 * H] + acc[G - 1][r] + bh[G - 1]);
+                        cn = fg * cprev[G == 4 ? tp : 0][r] + ig * gg;
+                        hn = og * wide_tanh(cn);
                     }
                     if (a.seq_out) a.seq_out[((size_t)b * a.T + t) * a.ld_seq + a.col_off + j] = hn;
                     if (a.last_out && step == a.steps - 1) a.last_out[(size_t)b * a.ld_last + a.col_off + j] = hn;
                 }
-                hprev[tp][r] = hn; cprev[tp][r] = cn;
+                if (G == 4) cprev[G == 4 ? tp : 0][r] = cn;
                 if (jok) nxt[(size_t)c * ldh + j] = hn;
             }
         }

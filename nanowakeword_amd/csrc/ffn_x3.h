@@ -24,10 +24,10 @@ struct FfnArgs {
     int pro_k = 0, pro_res = 0;      // KP (64 or D); add the rows of h (conv2 + residual)
     float p_un = 1.0f;               // 1 / scale of the packed prologue weights
     // ---- round 6: LayerNorm + mean over time BEHIND the module (the block's final LayerNorm feeding only the time average of the last block):
-    // rows are not written; per 32-row tile and clip segment the LayerNorm-ed rows are summed EXACTLY (integers of 2^-40 of the plan-time
-    // bound, in float64: order-independent, so a clip's mean does not depend on where the clip sits in the batch) into msum [tiles][2][D]
+    // rows are not written; per 32-row tile and clip segment the LayerNorm-ed rows are summed EXACTLY (as two planes of integers, 2^-36 of the
+    // plan-time bound: order-independent, so a clip's mean does not depend on where the clip sits in the batch) into msum [tiles][2][2][D]
     const float* ln2_w = nullptr; const float* ln2_b = nullptr;
-    double* msum = nullptr; int T = 0; float m_scale = 0.0f;
+    float* msum = nullptr; int T = 0; float m_scale = 0.0f;
 };
 
 // One packed hidden block = a W1 part (D/16 x 3 fragments of 1 KB) and a W2 part (ceil(D/32) x 2 x 3 fragments, then the
@@ -48,5 +48,5 @@ bool ffn_x3_pro_supported(int D, int KP);
 hipError_t launch_ffn_x3_pro_pack(const float* W, void* out, int D, int KP, float ws, hipStream_t s);
 // finish of the epilogue instances: out [B][D] = (sum over the clip's tile segments of msum) / (m_scale T)
 size_t ffn_x3_msum_bytes(int M, int D);
-hipError_t launch_ffn_x3_mean_finish(const double* msum, float* out, int B, int T, int D, float m_scale, hipStream_t s);
+hipError_t launch_ffn_x3_mean_finish(const float* msum, float* out, int B, int T, int D, float m_scale, hipStream_t s);
 hipError_t launch_ffn_x3(const FfnArgs& a, int D, hipStream_t s);

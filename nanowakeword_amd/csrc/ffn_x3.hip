@@ -160,20 +160,21 @@ __global__ void __launch_bounds__(256) ffn_pro_pack_kernel(const float* __restri
 }
 
 // out [b][c] = (sum of the clip's tile segments) / (scale T): tile t covers rows 32 t .. 32 t + 31, segment 0 = its rows of the clip its
-// first row belongs to, segment 1 = its rows of the next clip (T >= 32: a tile touches at most two clips).  The addends are integers in
-// float64, so the order of the sum does not matter.
-__global__ void __launch_bounds__(256) ffn_mean_finish_kernel(const double* __restrict__ msum, float* __restrict__ out, int B, int T, int D, double inv) {
+// first row belongs to, segment 1 = its rows of the next clip (T >= 32: a tile touches at most two clips).  msum [tile][segment][plane hi /
+// lo][D]: the addends are integers (below 2^24 each), so the order of the float64 sums does not matter.
+__global__ void __launch_bounds__(256) ffn_mean_finish_kernel(const float* __restrict__ msum, float* __restrict__ out, int B, int T, int D, double inv) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)B * D) return;
     const int c = (int)(idx % D);
     const long long b = (long long)(idx / D);
     const long long t0 = (b * T) / 32, t1 = (b * T + T - 1) / 32;
-    double s = 0.0;
+    double hi = 0.0, lo = 0.0;                                 // integers: exact in any order
     for (long long t = t0; t <= t1; ++t) {
         const int seg = ((32 * t) / T == b) ? 0 : 1;
-        s += msum[((size_t)t * 2 + seg) * D + c];
+        const float* m = msum + ((size_t)t * 2 + seg) * 2 * D;
+        hi += (double)m[c]; lo += (double)m[D + c];
     }
-    out[idx] = (float)(s * inv);
+    out[idx] = (float)((hi * 262144.0 + lo) * inv);
 }
 
 // (Measured and not kept for the two-term form: 256 rows per workgroup on eight waves, two per SIMD, each running product -
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
     bf16x8 xf[D16][NT];
     f32x16 yacc[NOB];
     if constexpr (KP16 == 0) {
+    FFN_STAMP(30, 0)
     fetch_w1(0, w1b0);
     fetch_w2(0, w2b0);
 #pragma unroll
@@ -298,6 +300,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             fetch(a.ppacked, w1b0, PS{}); fetch(a.ppacked + (size_t)PT, w1b1, PS{});
             fetch(a.ppacked + (size_t)2 * PT, w2b0, PS{}); fetch(a.ppacked + (size_t)3 * PT, w2b1, PS{});
         }
+        FFN_STAMP(30, 0)
         const float* prow = a.px + (size_t)(row_ok ? row : a.M - 1) * KP;
         bf16x8 pf[KP16][2];
         float ppin;
@@ -350,8 +353,10 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 acc = ffn_mma<true>(wh, pf[kb][0], acc);
             }
         };
+        FFN_STAMP(30, 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        FFN_STAMP(30, 2)
         if constexpr (SMALL) {
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) ptile((ob < NPB ? w2b0 : w2b1) + (ob % NPB) * PT, hc[ob]);
@@ -373,6 +378,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
             fetch_w1(0, w1b0);
             fetch_w2(0, w2b0);
         }
+        FFN_STAMP(30, 3)
         // h0 = acc / (row scale x weight scale) + bias [+ h]; LayerNorm over the row (this lane's 16 x NOB slots, the partner half's)
         float s = 0.0f;
 #pragma unroll
@@ -417,6 +423,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) yacc[ob][r] = hc[ob][r] * yi;
         }
+        FFN_STAMP(30, 4)
     }
 
     // Software pipeline over the hidden blocks (W1 parts and W2 parts double buffered separately, each fetched a full iteration before its
@@ -642,6 +649,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
         }
     }
 
+    FFN_STAMP(31, 0)
     // ---- h <- h + rscale * (Yt + b2): lane (row n, half h) holds out features 32 ob + 8 g + 4 h + 0..3
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
@@ -673,6 +681,7 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 }
             }
         }
+    FFN_STAMP(31, 1)
     if constexpr (EPI) {
         // ---- LayerNorm of the updated rows, then per tile and clip segment the column sums - staged through the wave's own (dead) weight
         // buffer as [32 rows][D + 4] float32 (16-byte stores conflict-free at this pitch), summed by lane = column in row order
@@ -694,43 +703,70 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 if (32 * ob + 8 * (r >> 2) < D) { const float d = yacc[ob][r] - mu2; q2 = fmaf(d, d, q2); }
         q2 += __shfl_xor(q2, 32, 64);
         const float rstd2 = 1.0f / sqrtf(q2 / (float)D + 1e-5f);
+        FFN_STAMP(31, 3)
         __syncthreads();                                       // every wave has left the weight buffers
+        FFN_STAMP(31, 4)
         float* st = reinterpret_cast<float*>(wave == 0 ? w1b0 : wave == 1 ? w1b1 : wave == 2 ? w2b0 : w2b1);
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (32 * ob + 8 * g < D) {
-                    const int m = 32 * ob + 8 * g + 4 * h;
-                    const float4 w = *reinterpret_cast<const float4*>(a.ln2_w + m), c = *reinterpret_cast<const float4*>(a.ln2_b + m);
-                    *reinterpret_cast<float4*>(st + n * GP + m) = make_float4((yacc[ob][4 * g] - mu2) * rstd2 * w.x + c.x, (yacc[ob][4 * g + 1] - mu2) * rstd2 * w.y + c.y,
-                                                                                (yacc[ob][4 * g + 2] - mu2) * rstd2 * w.z + c.z, (yacc[ob][4 * g + 3] - mu2) * rstd2 * w.w + c.w);
-                }
-        __builtin_amdgcn_wave_barrier();                       // (one wave: its LDS operations execute in order)
+        // Exact sums in float32: y x scale (|.| <= 2^36) = hi 2^18 + lo, hi = rint(y scale 2^-18) (|hi| <= 2^18), lo = rint of the exact remainder
+        // x 2^18 (|lo| <= 2^17) - integers whose sums over a tile's 32 rows stay below 2^24, i.e. exact in float32 whatever the order.  The lane
+        // converts its own elements once; the hi plane and then the lo plane are staged and summed by lane = column.  (First versions: float64
+        // rint / add per element in the column loop 12 k clocks per tile, int32 the same - the conversions, not the adds: tools/ubench/ffn_trace.)
+        const float sc1 = a.m_scale * (1.0f / 262144.0f);
         const long long r0 = (long long)blockIdx.x * 128 + wave * 32;      // the tile's first row
         const int n0 = (int)min((long long)32, (long long)a.T - r0 % a.T);  // rows of the clip the first row belongs to
         const int nv = (int)max((long long)0, min((long long)32, (long long)a.M - r0));      // rows that exist
-        const double sc = (double)a.m_scale;
-        double* mrow = a.msum + (size_t)(blockIdx.x * 4 + wave) * 2 * D;
-        // the lane's columns side by side (independent float64 chains), the two segments as two row ranges
-        constexpr int NC = (D + 63) / 64;
-        double s0[NC], s1[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) { s0[k] = 0.0; s1[k] = 0.0; }
         const int e0 = min(n0, nv);
-        for (int j = 0; j < e0; ++j) {
+        constexpr int NC = (D + 63) / 64;
+        float sums[2][2][NC];                                  // [plane hi / lo][segment][column]
 #pragma unroll
-            for (int k = 0; k < NC; ++k)
-                if (lane + 64 * k < D) s0[k] += __builtin_rint((double)st[j * GP + lane + 64 * k] * sc);      // an integer: sums of up to 128 of them are exact
-        }
-        for (int j = e0; j < nv; ++j) {
+        for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int k = 0; k < NC; ++k)
-                if (lane + 64 * k < D) s1[k] += __builtin_rint((double)st[j * GP + lane + 64 * k] * sc);
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (32 * ob + 8 * g < D) {
+                        const int m = 32 * ob + 8 * g + 4 * h;
+                        float o[4];
+                        if (pl == 0) {
+                            const float4 w = *reinterpret_cast<const float4*>(a.ln2_w + m), c = *reinterpret_cast<const float4*>(a.ln2_b + m);
+                            const float wv[4] = {w.x, w.y, w.z, w.w}, cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float t = ((yacc[ob][4 * g + q] - mu2) * rstd2 * wv[q] + cv[q]) * sc1, hf = __builtin_rintf(t);
+                                o[q] = hf;
+                                yacc[ob][4 * g + q] = __builtin_rintf((t - hf) * 262144.0f);      // t - hf is exact; kept for the second plane
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o[q] = yacc[ob][4 * g + q];
+                        }
+                        *reinterpret_cast<float4*>(st + n * GP + m) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+            __builtin_amdgcn_wave_barrier();                   // (one wave: its LDS operations execute in order)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { sums[pl][0][k] = 0.0f; sums[pl][1][k] = 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const bool in0 = j < e0, in1 = j >= e0 && j < nv;      // (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const float v = (lane + 64 * k < D) ? st[j * GP + lane + 64 * k] : 0.0f;
+                    sums[pl][0][k] += in0 ? v : 0.0f;
+                    sums[pl][1][k] += in1 ? v : 0.0f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        FFN_STAMP(31, 6)
+        // (the two planes stay float32 here: a handful of float64 conversions per lane cost this epilogue another 6 k clocks; the finish kernel combines them)
+        float* mrow = a.msum + (size_t)(blockIdx.x * 4 + wave) * 4 * D;      // [segment][plane][D]
 #pragma unroll
         for (int k = 0; k < NC; ++k)
-            if (lane + 64 * k < D) { mrow[lane + 64 * k] = s0[k]; mrow[D + lane + 64 * k] = s1[k]; }
+            if (lane + 64 * k < D) {
+                mrow[lane + 64 * k] = sums[0][0][k]; mrow[D + lane + 64 * k] = sums[1][0][k];
+                mrow[2 * D + lane + 64 * k] = sums[0][1][k]; mrow[3 * D + lane + 64 * k] = sums[1][1][k];
+            }
+        FFN_STAMP(31, 2)
     }
 }
 
@@ -758,9 +794,9 @@ hipError_t launch_ffn_x3_pro_pack(const float* W, void* out, int D, int KP, floa
     return hipGetLastError();
 }
 
-size_t ffn_x3_msum_bytes(int M, int D) { return (size_t)((M + 127) / 128) * 4 * 2 * D * sizeof(double); }
+size_t ffn_x3_msum_bytes(int M, int D) { return (size_t)((M + 127) / 128) * 4 * 4 * D * sizeof(float); }
 
-hipError_t launch_ffn_x3_mean_finish(const double* msum, float* out, int B, int T, int D, float m_scale, hipStream_t s) {
+hipError_t launch_ffn_x3_mean_finish(const float* msum, float* out, int B, int T, int D, float m_scale, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (T < 32 || !(m_scale > 0.0f)) return hipErrorInvalidValue;
     const size_t total = (size_t)B * D;

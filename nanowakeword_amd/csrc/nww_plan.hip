@@ -1222,7 +1222,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                             const auto h2w = f16_fetch(p.h, l2w, D), h2b = f16_fetch(p.h, l2b, D);
                             double by = 0.0;
                             for (int k = 0; k < D; ++k) by = std::fmax(by, std::sqrt((double)D) * std::fabs((double)h2w[k]) + std::fabs((double)h2b[k]));
-                            mscale = by < 1e30 ? (float)f16_pow2_floor(1099511627776.0 / std::fmax(by, 1e-30)) : 0.0f;      // |LayerNorm| x scale <= 2^40
+                            mscale = by < 1e30 ? (float)f16_pow2_floor(68719476736.0 / std::fmax(by, 1e-30)) : 0.0f;      // |LayerNorm| x scale <= 2^36
                             extras_ok = mscale > 0.0f && std::isfinite(mscale);
                         }
                         if (!extras_ok) {
@@ -1236,7 +1236,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                             if (ppk) p.h->packed_weights.push_back(ppk);
                             const float* b2 = p.W(q + ff + ".linear2.bias");
                             const float p_un = pro ? 1.0f / pws : 1.0f;
-                            // the epilogue's exact partial sums: per 32-row tile two segments of D float64 (the idle wide scratch buffer)
+                            // the epilogue's exact partial sums: per 32-row tile two segments x two planes of D floats (the idle wide scratch buffer)
                             if (epi) p.need(big, (size_t)((T + 31) / 32 + 1) * 4 * D + (size_t)16 * D);
                             const std::string what = std::string(pro == 1 ? "input_proj+" : pro == 2 ? "conv2(pw)+res+" : "") + "ln+linear1+swish+linear2+0.5res" + (epi ? "+layernorm+time sums" : "");
                             p.add("ffn_x3:" + q + ff + " (" + what + ")" + (h2 ? " [f16x3]" : ""), [=](Run& r) {
@@ -1246,12 +1246,12 @@ extern "C" int nww_finalize(nww_handle* h) {
                                     a.px = pro == 1 ? r.x : r.buf[t3]; a.ppacked = static_cast<const unsigned char*>(ppk); a.pb = pbias;
                                     a.pro_k = pro_k; a.pro_res = pro == 2 ? 1 : 0; a.p_un = p_un;
                                 }
-                                if (epi) { a.ln2_w = l2w; a.ln2_b = l2b; a.msum = reinterpret_cast<double*>(r.buf[big]); a.T = T; a.m_scale = mscale; }
+                                if (epi) { a.ln2_w = l2w; a.ln2_b = l2b; a.msum = r.buf[big]; a.T = T; a.m_scale = mscale; }
                                 return launch_ffn_x3(a, D, r.stream);
                             });
                             if (epi)
                                 p.add("mean_finish:" + q + " (time average of the exact tile sums)", [=](Run& r) {
-                                    return launch_ffn_x3_mean_finish(reinterpret_cast<const double*>(r.buf[big]), r.buf[t1], r.B, T, D, mscale, r.stream);
+                                    return launch_ffn_x3_mean_finish(r.buf[big], r.buf[t1], r.B, T, D, mscale, r.stream);
                                 });
                             return true;
                         }

@@ -2,12 +2,12 @@
 // waves around every second hidden block of the main loop - block top | fetches issued | first product + epilogue done | second product issued |
 // fetches landed (vmcnt 0) | behind the barrier - plus plain launch timing.  D = 144 (the default Conformer width), two-term form.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DNWW_TRACE -I nanowakeword_amd/csrc -I include tools/ubench/ffn_trace.hip -o tools/ubench/ffn_trace
-// run:   tools/ubench/ffn_trace [M=206848]
+// run:   tools/ubench/ffn_trace [M=206848] [mode: 0 plain, 1 + input_proj (K = 64) in front, 2 + conv2 (K = 144) + residual in front, 3 = 2 + LayerNorm + time sums behind]
 #include "../../nanowakeword_amd/csrc/ffn_x3.hip"
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 206848, D = 144;
+    const int M = argc > 1 ? atoi(argv[1]) : 206848, D = 144, mode = argc > 2 ? atoi(argv[2]) : 0;
     std::vector<float> h((size_t)M * D), w1((size_t)4 * D * D), w2((size_t)4 * D * D), b1(4 * D), b2(D), lw(D, 1.0f), lb(D, 0.0f);
     uint32_t st = 1;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -23,9 +23,21 @@ int main(int argc, char** argv) {
     hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice); hipMemcpy(db1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(db2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dlw, lw.data(), D * 4, hipMemcpyHostToDevice); hipMemcpy(dlb, lb.data(), D * 4, hipMemcpyHostToDevice);
     hipStream_t s; hipStreamCreate(&s);
-    launch_ffn_x3_pack(dw1, db1, dw2, pk, D, s, 32768.0f, 32768.0f);
+    launch_ffn_x3_pack(dw1, db1, dw2, pk, D, s, 32768.0f, 32768.0f, mode ? 1 : 0);
     FfnArgs a{dh, dlw, dlb, static_cast<const unsigned char*>(pk), db2, M, 0.5f};
     a.h2_x = 512.0f; a.h2_w1 = 32768.0f; a.h2_h = 64.0f; a.h2_w2 = 32768.0f;
+    if (mode) {
+        const int KP = mode == 1 ? 64 : 144;
+        std::vector<float> px((size_t)M * KP), pw((size_t)D * KP);
+        for (auto& v : px) v = rnd() * 4.0f;
+        for (auto& v : pw) v = rnd() * 0.2f;
+        float *dpx, *dpw, *dms; void* ppk;
+        hipMalloc(&dpx, px.size() * 4); hipMalloc(&dpw, pw.size() * 4); hipMalloc(&ppk, ffn_x3_pro_tile_bytes(KP) * 5); hipMalloc(&dms, ffn_x3_msum_bytes(M, D));
+        hipMemcpy(dpx, px.data(), px.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dpw, pw.data(), pw.size() * 4, hipMemcpyHostToDevice);
+        launch_ffn_x3_pro_pack(dpw, ppk, D, KP, 32768.0f, s);
+        a.px = dpx; a.ppacked = (const unsigned char*)ppk; a.pb = db2; a.pro_k = KP; a.pro_res = mode >= 2; a.p_un = 1.0f / 32768.0f;
+        if (mode == 3) { a.ln2_w = dlw; a.ln2_b = dlb; a.msum = dms; a.T = 101; a.m_scale = 68719476736.0f / 64.0f; }
+    }
     for (int i = 0; i < 3; ++i) { hipMemcpyAsync(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice, s); launch_ffn_x3(a, D, s); }
     hipStreamSynchronize(s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -47,6 +59,14 @@ int main(int argc, char** argv) {
         }
         printf("  wave %d:", wv);
         for (int k = 0; k < 6; ++k) printf(" %7.1f", acc[k] / n);
+        printf("\n");
+    }
+    printf("prologue of workgroup 0 (clocks since the kernel's first stamp): rows split, fetches issued | landed + barrier | products done | LayerNorm + fragments | ... | main loop done | update done | sums done\n");
+    for (int wv = 0; wv < 4; ++wv) {
+        const unsigned long long* p0 = &tr[(wv * 32 + 30) * 8];
+        const unsigned long long* p1 = &tr[(wv * 32 + 31) * 8];
+        printf("  wave %d: %7llu %7llu %7llu %7llu | %8llu %8llu %8llu", wv, p0[1] - p0[0], p0[2] - p0[0], p0[3] - p0[0], p0[4] - p0[0], p1[0] - p0[0], p1[1] - p0[0], p1[2] > p0[0] ? p1[2] - p0[0] : 0ULL);
+        if (p1[2] > p0[0]) printf("   (behind the update: stats %llu | barrier %llu | staged %llu | summed %llu | stored %llu)", p1[3] - p1[1], p1[4] - p1[1], p1[5] - p1[1], p1[6] - p1[1], p1[2] - p1[1]);
         printf("\n");
     }
     return 0;

@@ -682,13 +682,13 @@ def main():
             peak_r2 = (f1 + f2) / (f1 / PEAK_F32_TFLOPS + f2 / (PEAK_BF16_TFLOPS / P))
             roofline["frac_round2_definition"] = round(achieved / peak_r2, 4)
             roofline["note"] = ("peaks assume the 2.4 GHz boost clock; with all 256 CUs busy this kernel runs power-limited at "
-                                "1.9-2.0 GHz (tools/ubench/trunk_trace.hip, DESIGN.md 4.2b)")
+                                "1.9-2.0 GHz (tools/ubench/trunk_trace.hip, DESIGN.md 4.10)")
             # back-to-back bf16 MFMAs with toggling operands on all 256 CUs sustain 5.63e10 wave-instructions per second of the
-            # nominal 7.68e10 (1.85 GHz at the package's power limit; tools/ubench/power_mix.hip mode 4, DESIGN 4.2b)
+            # nominal 7.68e10 (1.85 GHz at the package's power limit; tools/ubench/power_mix.hip mode 4, DESIGN 4.10)
             roofline["frac_of_sustained_matrix_rate"] = round(achieved / peak / (5.63 / 7.68), 4)
             # how busy the two pipes the kernel is limited by actually are, from the committed PMC pass of this kernel at this batch
             # (profiles/traffic.json) and the live launch time: with the two-term arithmetic the matrix pipe is no longer the only
-            # limiter - the launch takes about the SUM of its matrix time and its VALU time (DESIGN.md 4.2c)
+            # limiter - the launch takes about the SUM of its matrix time and its VALU time (DESIGN.md 2)
             try:
                 ent = json.load(open(tp)).get(name) or {}
                 if ent.get("batch") == B and ent.get("sq_insts_mfma"):
@@ -732,7 +732,7 @@ def main():
                        "conv_arith": {"f32": "conv2 on v_mfma_f32_32x32x2_f32",
                                       "bf16x9": "float32 operands split exactly into 3 bf16 terms, all 9 partial products on v_mfma_f32_32x32x16_bf16, f32 accumulate",
                                       "bf16x6": "float32 operands split exactly into 3 bf16 terms, the 6 partial products >= 2^-23 of a product on v_mfma_f32_32x32x16_bf16, f32 accumulate (float32-grade: DESIGN.md 4.2)",
-                                      "f16x3": "float32 operands, scaled by plan-time powers of two, split into 2 binary16 terms (22-23 of 24 significant bits), the 3 partial products >= 2^-22 of a product on v_mfma_f32_32x32x16_f16, f32 accumulate (float32-MFMA accuracy against float64: DESIGN.md 4.2c)"}[arith],
+                                      "f16x3": "float32 operands, scaled by plan-time powers of two, split into 2 binary16 terms (22-23 of 24 significant bits), the 3 partial products >= 2^-22 of a product on v_mfma_f32_32x32x16_f16, f32 accumulate (float32-MFMA accuracy against float64: DESIGN.md 2)"}[arith],
                        "parallelism": f"batch-split x{world}" + (f" + RCCL all-gather of logits ({gather_via}" + (", on a side stream, two steps in flight)" if gather_via == "capi" else ")") if world > 1 else "")},
             "max_abs_dlogit": max_dlogit,      # the timed logits of the first 16 clips against the oracle (north_star: <= 1e-4)
             "max_abs_dlogit_note": "16 clips of the timed batch, PCM -> logit, against oracle/ (numpy float32 restatement of the reference); checker only, outside the timed region",
@@ -746,9 +746,11 @@ def main():
         extras = world == 1 and not a.no_extras
         if extras:
             # the same step over three rotating copies of the batch (393 MB > the Infinity Cache): PCM really comes from HBM
-            for _ in range(6):
-                step(True)
-            torch.cuda.synchronize(dev)
+            t_pre = time.perf_counter()                         # (the clocks fell while the checker ran on the CPU: the same ramp as in front of the headline loop)
+            while time.perf_counter() - t_pre < max(a.prewarm_seconds, 0.5):
+                for _ in range(12):
+                    step(True)
+                torch.cuda.synchronize(dev)
             t0r = time.perf_counter()
             for _ in range(max(a.steps, 60)):
                 step(True)

@@ -37,7 +37,7 @@ def _newer(target: str, deps) -> bool:
 # gain) and cost a v_mov per operand to build the register pairs - measured on the 25-point DFT body: 532 VALU /
 # 120 VGPRs with it, 432 VALU / 62 VGPRs without.  Disabled for the VALU-bound files; NWW_SLP="all" / "none"
 # overrides for A/B builds (together with NWW_LIB_PATH to keep two libraries side by side).
-# Round 3: a packed f32 instruction is also starved by any matrix-pipe wave on its SIMD (DESIGN 4.2a iii); A/B over every file
+# Round 3: a packed f32 instruction is also starved by any matrix-pipe wave on its SIMD; A/B over every file
 # (NWW_SLP=none against the default, tools/bench_configs.py): BcResNet front 0.534 -> 0.515, its depthwise kernels 0.118 /
 # 0.102 -> 0.114 / 0.094, dual_x3 0.172 / 0.242 -> 0.163 / 0.236, ffn_x3 -1 %; mha_mfma 0.318 -> 0.366 and conv3_x3 +1 % (they keep SLP).
 NO_SLP = {"frontend2.hip", "trunk_b.hip", "dual_x3.hip", "bc_chain.hip", "layers.hip", "ffn_x3.hip"}

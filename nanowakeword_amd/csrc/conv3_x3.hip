@@ -7,7 +7,7 @@
 // v_mfma_f32_32x32x16_bf16 with float32 accumulation (products < 2^-23 of the result are dropped).  The float32-MFMA
 // kernel this replaces (conv3x3_mfma_kernel, trunk.hip) spends 144 x 64 = 9216 matrix-pipe clocks per 32 pixel x 32
 // channel tile, this one 108 x 32 = 3456 - and on gfx950 the float32 MFMA runs at the VALU rate and blocks the VALU
-// while it runs (DESIGN.md 4.2a), the bf16 one does neither.
+// while it runs (DESIGN.md 4.10), the bf16 one does neither.
 //
 // One workgroup (8 waves) = one (clip, 32-channel output group); a workgroup keeps its group for its whole life, so
 // the group's weights are split and laid out as MFMA B fragments in LDS once:

@@ -145,7 +145,7 @@ template <int CB, int NST, int ACT, bool H2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(184))) gemm_x3_kernel(GemmArgs g) {
     constexpr int NT = X3A<H2>::NT, X3_ROW = X3A<H2>::ROW, PB = 2 * NT;   // terms, LDS row bytes, 16-byte pieces of a row's 16-k block
     // accumulators in AGPRs: two workgroups share a CU, and one's bf16 MFMAs run beside the other's split/stage VALU
-    // work only in the AGPR form (DESIGN.md 4.2a; tools/ubench/mfma_valu_overlap.hip).  The empty asm flips hipcc's
+    // work only in the AGPR form (DESIGN.md 4.10; tools/ubench/mfma_valu_overlap.hip).  The empty asm flips hipcc's
     // choice; the plain launch bound keeps the register file unsplit, amdgpu_num_vgpr caps the VGPR side so that
     // VGPRs + accumulator AGPRs <= 256 (two waves per SIMD).
     { float agpr_hint = 0.0f; asm volatile("; mfma accumulators in AGPRs" : "+a"(agpr_hint)); }

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
         }
         // The next weight block's LDS-DMA (issued before this block's products) and the residual loads must have landed before
         // the barrier behind this block - waited for HERE, before the stores: vmcnt counts stores too, and waiting for it after
-        // them made every block sit out the write latency of its own outputs (out_proj 0.117 -> see DESIGN 7)
+        // them made every block sit out the write latency of its own outputs (out_proj 0.117 -> see docs/DESIGN_rounds1-5.md 7)
         LIN_STAMP(blk, 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LIN_STAMP(blk, 3)

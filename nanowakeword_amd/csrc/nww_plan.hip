@@ -733,7 +733,7 @@ extern "C" int nww_finalize(nww_handle* h) {
         if (!e2.empty()) return fail(h, NWW_ERR_INVALID, "frontend mel plan: %s", e2.c_str());
         HIP_TRY(h, hipMalloc(&h->d_melplan, sizeof(Fe2MelPlan)));
         HIP_TRY(h, hipMemcpy(h->d_melplan, plan.data(), sizeof(Fe2MelPlan), hipMemcpyHostToDevice));
-        // (the DFT on the matrix pipe - frontend3 - was built in round 5, parity-green and slower: tools/ubench/fe3/, DESIGN 4.1b)
+        // (the DFT on the matrix pipe - frontend3 - was built in round 5, parity-green and slower: tools/ubench/fe3/, DESIGN 4.1)
     }
     // ---- plan
     PlanCtx p{h};
@@ -1335,7 +1335,7 @@ extern "C" int nww_finalize(nww_handle* h) {
                     const float *dw = p.W(m + ".depthwise_conv.weight"), *db = p.W(m + ".depthwise_conv.bias");
                     const float *ba = p.W(m + ".batch_norm.alpha"), *bb = p.W(m + ".batch_norm.beta");
                     // (the whole module as ONE clip-resident launch was built and measured: bit-identical, 0.27 ms against 0.25 for the three launches
-                    // below - tools/ubench/convmod_x3.hip, DESIGN 4.9)
+                    // below - tools/ubench/convmod_x3.hip, DESIGN 4.4)
                     {
                     // LayerNorm + pointwise conv1 + GLU in one launch (lin_x3.hip), else the three separate ones
                     if (!add_lin_x3(p, m + ".layer_norm+conv1(pw)+glu", hb, t1, T, D, D, p.W(m + ".conv1.weight"), p.W(m + ".conv1.bias"), 2, 99, 1.f, lw, lb)) {

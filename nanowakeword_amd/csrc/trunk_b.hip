@@ -71,6 +71,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef TB_ABL
 #define TB_ABL 0      // ablation mask of tools/ubench/trunk_trace.hip builds: 1 conv2 without per-tap LDS reads, 2 no conv2 epilogue,
 #endif                // 4 no conv1, 8 no conv2, 16 no conv1 epilogue (pool / split / A1 stores), 32 no input staging, 64 no input loads either
+#ifdef NWW_TRACE      // tools/ubench/front_trace.hip: s_memtime of workgroup 0's eight waves at the phase boundaries of bc_front_b_kernel's strips
+__device__ unsigned long long g_front_trace[8 * 16 * 8];
+#define BF_STAMP(it, k) if (blockIdx.x == 0 && lane == 0 && (it) < 16) g_front_trace[(wave * 16 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define BF_STAMP(it, k)
+#endif
+
 namespace {
 constexpr int C1 = 16, C2 = 32;
 constexpr int NW = 8;                   // waves per workgroup
@@ -880,6 +887,9 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     const int i = lane & 31, hi = lane >> 5;
 
     for (int k = tid; k < NT * plane_b / 4; k += NTHR) reinterpret_cast<uint32_t*>(In3)[k] = 0u;      // halo columns stay zero
+    // P's pixel slots W1 .. W1p - 1 (never written) and the row behind the strip's max_conv rows stay zero: the depthwise reads them as
+    // its out-of-plane columns / rows
+    for (int k = tid; k < (gg.max_conv + 1) * W1p * 8; k += NTHR) reinterpret_cast<float4*>(P)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = tid; k < 288; k += NTHR) Wd[k] = a.dw_wt[k];
     if (tid < 4) Zp[tid] = 0.0f;
     if (tid < 32) {
@@ -915,7 +925,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx4 < n4) {
                 const int lr = (4 * idx4) / W, x = 4 * idx4 - lr * W, y = y0 + lr;
-                if (y >= 0 && y < H) pre[q] = *reinterpret_cast<const float4*>(xin + (size_t)y * W + x);
+                if (y >= 0 && y < H) pre[q] = *reinterpret_cast<const float4*>(xin + (y * W + x));      // (a clip's plane: 32-bit offsets)
             }
         }
     };
@@ -962,9 +972,11 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         strip_rows(sidx, oy0, oy1, r_lo, r_hi);
         const int y0 = 2 * r_lo - 1, n = (2 * (r_hi - r_lo + 1) + 2) * W;
         const float* xin = a.in + (size_t)b * H * W;
-        for (int idx = tid; idx < n; idx += NTHR) {
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));                          // (nothing of this loop hoisted out of the clip loop: the fast path has no registers for it)
+        for (int idx = t0; idx < n; idx += NTHR) {
             const int lr = idx / W, x = idx - lr * W, y = y0 + lr;
-            const float v = (y >= 0 && y < H) ? xin[(size_t)y * W + x] : 0.0f;
+            const float v = (y >= 0 && y < H) ? xin[y * W + x] : 0.0f;
             unsigned char* d = In3 + (lr * Wp0 + x + 1) * 2;
             if constexpr (F16) {
                 uint32_t hh, ll;
@@ -987,17 +999,26 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     const int Wg2 = (Wo + 1) >> 1, dw_rpp = (NTHR >> 3) / max(Wg2, 1);
     const bool dw_fast = F16 && sw == 2 && dw_rpp >= 1;      // (the three-term instances have no registers to spare for it)
     const int dw_xg = dslot % max(Wg2, 1), dw_ry = dslot / max(Wg2, 1);
-    int dxoff[5];
-    auto calc_dxoff = [&]() {
-#pragma unroll
-        for (int cx = 0; cx < 5; ++cx) {
-            const int xx = 4 * dw_xg - 1 + cx;
-            dxoff[cx] = (xx >= 0 && xx < W1) ? bf_pslot(xx) * 32 + 4 * (cq ^ bf_pswz(xx)) : -1;
-        }
-    };
-    if constexpr (F16) calc_dxoff();
+    // byte offsets inside a P row of the lane's quad of its five columns 4 xg - 1 .. 4 xg + 3: columns 4 xg / 4 xg + 2 sit at colE / colE + 128,
+    // 4 xg + 1 / 4 xg + 3 at colO / colO + 128 (bf_pslot, bf_pswz), column 4 xg - 1 at colL - for xg = 0 it lies outside the plane and the
+    // lane reads the zero row instead (colL = 0 there).  Columns >= W1 are zero slots of P.
+    const int dw_z = 2 * (dw_xg & 1);
+    const int colE0 = 4 * dw_xg * 128 + 16 * (cq ^ dw_z), colO0 = (4 * dw_xg + 2) * 128 + 16 * (cq ^ dw_z ^ 1);
+    const int colL0 = dw_xg > 0 ? (4 * dw_xg - 1) * 128 + 16 * (cq ^ (1 | (2 * ((dw_xg - 1) & 1)))) : 0;
+    const int prow_b = W1p * 128;                               // bytes per P row
+    const unsigned char* const Pb = reinterpret_cast<const unsigned char*>(P);
+    const unsigned char* const Zrow = Pb + (size_t)gg.max_conv * prow_b;
+    // convolution tasks with one 32-pixel group per row (W1 <= 32): the lane's operand / result addresses are a lane constant plus a wave-uniform
+    // row term
+    const bool conv1g = ngx == 1;
+    const int cv_xc = min(i, W1 - 1);
+    const int cv_in0 = 2 * hi * pitch0 + 4 * cv_xc;
+    const int cv_out0 = bf_pslot(cv_xc) * 128 + 16 * ((4 * set + 2 * hi) ^ bf_pswz(cv_xc));
 
     int b = blockIdx.x, sidx = 0;
+#ifdef NWW_TRACE
+    int trace_it = 0;
+#endif
     if (b < a.B) {
         if (vec_in) { float4 p0[NPRE]; fetch(b, 0, p0); put(0, p0); }
         else stage_sync(b, 0);
@@ -1008,15 +1029,22 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         if (ns >= nstrips) { ns = 0; nb = b + gridDim.x; }
         const bool has_next = nb < a.B;
         float4 pre[NPRE];
+        BF_STAMP(trace_it, 0)
         if (has_next && vec_in) fetch(nb, ns, pre);
+        BF_STAMP(trace_it, 1)
         int oy0, oy1, r_lo, r_hi;
         strip_rows(sidx, oy0, oy1, r_lo, r_hi);
+        // the lane constants pass through an opaque copy per strip: left loop-invariant, every address derived from them (one per LDS access of
+        // the two phases) is hoisted out of the clip loop and spilled - 59 registers' worth
+        int cv_in = cv_in0, cv_out = cv_out0, colE = colE0, colO = colO0, colL = colL0, cqv = cq, xgv = dw_xg;
+        asm volatile("" : "+v"(cv_in), "+v"(cv_out), "+v"(colE), "+v"(colO), "+v"(colL), "+v"(cqv), "+v"(xgv));
+        const int cv_out1 = cv_out ^ 16;                          // ((q0 + 1) ^ sz = (q0 ^ sz) ^ 1: q0 is even)
         // ---- conv + BN + act + pool of rows r_lo .. r_hi -> P
         const int ntask = (r_hi - r_lo + 1) * ngx * 2;
         for (int t = wave; t < ntask; t += NW) {
-            const int g = t >> 1, Rl = g / ngx, gx = g - Rl * ngx;
+            const int g = t >> 1, Rl = conv1g ? g : g / ngx, gx = conv1g ? 0 : g - Rl * ngx;
             const int xc = min(32 * gx + i, W1 - 1);
-            const unsigned char* base = In3 + (2 * Rl + 2 * hi) * pitch0 + 4 * xc;
+            const unsigned char* base = conv1g ? In3 + cv_in + 2 * Rl * pitch0 : In3 + (2 * Rl + 2 * hi) * pitch0 + 4 * xc;
             bf16x8 cf[3];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -1024,6 +1052,9 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(base + tt * plane_b + pitch0);
                 cf[tt] = frag4(p[0], p[1], q[0], q[1]);
             }
+            // the wave's bias / folded-BN rows travel under the MFMAs (requested behind them they put an LDS round trip into every task)
+            const float4* bp = reinterpret_cast<const float4*>(BNp + 16 * set + 8 * hi);
+            const float4 b0v = bp[0], b1v = bp[1], a0v = bp[8], a1v = bp[9], e0v = bp[16], e1v = bp[17];
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -1035,48 +1066,65 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const float4* bp = reinterpret_cast<const float4*>(BNp + 16 * set + 8 * hi);
-            const float4 b0v = bp[0], b1v = bp[1], a0v = bp[8], a1v = bp[9], e0v = bp[16], e1v = bp[17];
             const float bs[8] = {b0v.x, b0v.y, b0v.z, b0v.w, b1v.x, b1v.y, b1v.z, b1v.w};
             const float al[8] = {a0v.x, a0v.y, a0v.z, a0v.w, a1v.x, a1v.y, a1v.z, a1v.w};
             const float be[8] = {e0v.x, e0v.y, e0v.z, e0v.w, e1v.x, e1v.y, e1v.z, e1v.w};
             float m[8];
+            if (bn_pos) {                                         // (one wave-uniform branch per task instead of one per channel)
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc)
-                m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc], 1.0f, bn_pos);
+                for (int cc = 0; cc < 8; ++cc)
+                    m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc], 1.0f, true);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc)
+                    m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc], 1.0f, false);
+            }
             const int x = 32 * gx + i;
-            if (x < W1) {
-                float* dst = P + ((size_t)Rl * W1p + bf_pslot(x)) * 32;
+            int o0 = cv_out, o1 = cv_out1;                        // byte offsets of the lane's two quads in its P row
+            if (!conv1g) {
                 const int q0 = 4 * set + 2 * hi, sz = bf_pswz(x);
-                *reinterpret_cast<float4*>(dst + 4 * (q0 ^ sz)) = make_float4(m[0], m[1], m[2], m[3]);
-                *reinterpret_cast<float4*>(dst + 4 * ((q0 + 1) ^ sz)) = make_float4(m[4], m[5], m[6], m[7]);
+                o0 = bf_pslot(x) * 128 + 16 * (q0 ^ sz); o1 = o0 ^ 16;
+            }
+            if (x < W1) {
+                unsigned char* const prow = reinterpret_cast<unsigned char*>(P) + Rl * prow_b;
+                *reinterpret_cast<float4*>(__builtin_assume_aligned(prow + o0, 16)) = make_float4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<float4*>(__builtin_assume_aligned(prow + o1, 16)) = make_float4(m[4], m[5], m[6], m[7]);
             }
         }
+        BF_STAMP(trace_it, 2)
         __syncthreads();
+        BF_STAMP(trace_it, 3)
         // the planes are free: the next strip's rows land while this strip's depthwise runs
         if (has_next) {
             if (vec_in) put(ns, pre);
             else stage_sync(nb, ns);
         }
+        BF_STAMP(trace_it, 4)
         // ---- depthwise 3x3 of the strip's rows out of P (taps in dwconv3x3_nhwc_kernel's order and fmaf chain)
         if (F16 && dw_fast) {
             if (dw_ry < dw_rpp) {
                 for (int oyl = dw_ry; oyl < oy1 - oy0; oyl += dw_rpp) {
                     const int oy = oy0 + oyl;
                     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, centre[2] = {acc[0], acc[0]};
-#pragma unroll 1
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int yy = oy * sh - 1 + dy;
-                        const bool oky = yy >= 0 && yy < H1;
-                        const float* prow = P + (yy - r_lo) * W1p * 32;
-                        float4 v[5];
+                    // rows oy sh - 1 .. + 1 of the plane (the middle one always exists), an out-of-plane row = the zero row
+                    const int yy0 = oy * sh - 1;
+                    const unsigned char* const r1 = Pb + (yy0 + 1 - r_lo) * prow_b;
+                    const unsigned char* const rb[3] = {yy0 >= 0 ? r1 - prow_b : Zrow, r1, yy0 + 2 < H1 ? r1 + prow_b : Zrow};
 #pragma unroll
-                        for (int cx = 0; cx < 5; ++cx)
-                            v[cx] = *reinterpret_cast<const float4*>((oky && dxoff[cx] >= 0) ? prow + dxoff[cx] : Zp);
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const unsigned char* const pe = rb[dy] + colE;
+                        const unsigned char* const po = rb[dy] + colO;
+                        const unsigned char* const pl = (xgv > 0 ? rb[dy] : Zrow) + colL;
+                        float4 v[5];
+                        v[0] = *reinterpret_cast<const float4*>(pl);
+                        v[1] = *reinterpret_cast<const float4*>(pe);
+                        v[2] = *reinterpret_cast<const float4*>(po);
+                        v[3] = *reinterpret_cast<const float4*>(pe + 128);
+                        v[4] = *reinterpret_cast<const float4*>(po + 128);
                         if (dy == 1) { centre[0] = v[1]; centre[1] = v[3]; }
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
-                            const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cq);
+                            const float4 w = *reinterpret_cast<const float4*>(Wd + (dy * 3 + dx) * 32 + 4 * cqv);
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const float4 pv = v[2 * j + dx];
@@ -1084,12 +1132,17 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                                 acc[j].z = fmaf(pv.z, w.z, acc[j].z); acc[j].w = fmaf(pv.w, w.w, acc[j].w);
                             }
                         }
+                        // a row at a time: left alone, hipcc issues all 24 loads first and sinks the arithmetic into the stores' branches - 96
+                        // registers of operands
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[j].x), "+v"(acc[j].y), "+v"(acc[j].z), "+v"(acc[j].w));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int ox = 2 * dw_xg + j;
+                        const int ox = 2 * xgv + j;
                         if (ox < Wo) {
-                            const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cq;
+                            const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cqv;
                             if (a.bf16_out) {                     // wave-uniform: 16-bit activations (split_h2.h)
                                 const int k16 = a.bf16_out;
                                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_out) + oi) =
@@ -1141,7 +1194,12 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                 *reinterpret_cast<float4*>(a.xs_out + oi) = centre;
             }
         }
+        BF_STAMP(trace_it, 5)
         __syncthreads();
+        BF_STAMP(trace_it, 6)
+#ifdef NWW_TRACE
+        ++trace_it;
+#endif
         b = nb; sidx = ns;
     }
 }
@@ -1308,7 +1366,7 @@ hipError_t launch_bc_front_b_pack_f16(const float* w1, unsigned char* packed, fl
 // (the strip height follows the three-term form's LDS need in every arithmetic: how a clip is cut does not depend on the switch)
 static size_t bc_front_b_lds(int W, int sh, int rows_dw) {
     const BfGeom g = bf_geom(W, sh, rows_dw);
-    return (size_t)BF_HEAD + 3 * (size_t)g.plane_b + (size_t)g.max_conv * ((W / 2 + 3) & ~3) * 32 * sizeof(float) + 16;
+    return (size_t)BF_HEAD + 3 * (size_t)g.plane_b + (size_t)(g.max_conv + 1) * ((W / 2 + 3) & ~3) * 32 * sizeof(float) + 16;      // (+ 1: P's zero row)
 }
 // depthwise rows per strip such that two workgroups share a CU (80 KB each); 0 = does not fit
 int bc_front_b_rows(int H, int W, int sh) {

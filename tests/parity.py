@@ -2,7 +2,7 @@
 
 Float tolerances follow BASELINE.json's north_star: frame counts bit-exact, log-mel and logits
 within 1e-4 (float32).  Two facts measured against the reference itself (tools/make_goldens.py,
-see DESIGN.md "Conditioning") shape how 1e-4 is applied to the frontend:
+see DESIGN.md 2) shape how 1e-4 is applied to the frontend:
 
  * The reference evaluates each 400-tap DFT sum in float32, so every mel bin of a frame carries
    an ABSOLUTE error of ~1.5e-6 x that frame's peak mel power (reference vs float64 evaluation

@@ -186,7 +186,7 @@ def test_spec_and_macs():
 
 
 def test_f16x3_split_arithmetic_claims():
-    """The claims csrc/split_h2.h and DESIGN 4.2c make about the two-term binary16 split, checked in numpy (no GPU): for v inside
+    """The claims csrc/split_h2.h and DESIGN 2 make about the two-term binary16 split, checked in numpy (no GPU): for v inside
     the binary16 range, hi = RN16(v), lo = RN16(v - hi): (i) v - hi is exact in float32; (ii) |v - (hi + lo)| <= 2^-23 |v| as long as
     lo keeps all its bits (|v| >= 2^-2; below that the error is an absolute 2^-25), and exactly 0 for at least a third of the values; (iii) every partial product of two terms is
     exact in float32 (11 x 11 significant bits); (iv) the dropped lo*lo is < 2^-22 of the product; (v) scaling by a power of two

@@ -5,7 +5,7 @@ Emulates `act_dtype = bf16` of the BcResNet head in the oracle: every tensor the
 d3, h3) rounded to bf16, one at a time and together, on the 16 golden clips; then the two remedies that were proposed or obvious:
   * subtracting the all-floor (-100 dB) response from the front kernel's outputs before rounding,
   * position-keyed ordered dither instead of round-to-nearest (de-correlates the rounding error across pixels).
-Findings (round 4): the activations are NOT large (<= 144 over all clips) - on constant input every pixel of a
+Findings (round 4, docs/DESIGN_rounds1-5.md section 7): the activations are NOT large (<= 144 over all clips) - on constant input every pixel of a
 channel carries the SAME rounding error, which survives the global average pool instead of averaging out.  The error is spread over
 xs1 / h1 / h2 / d3 (0.05 / 0.08 / 0.10 / 0.04 of the 0.35), so a wider format for one tensor does not help; centring makes broadband
 clips worse (0.05); dither brings silence from 0.35 to 0.05-0.07 but not under 2e-2.

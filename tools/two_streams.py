@@ -2,7 +2,7 @@
 """Does overlapping the step's kernels across two batches help?  Two handles on two streams, each running the headline
 step (B = 4096 per call) back to back, against one handle doing the same number of steps alone.  The frontend draws
 1150 W (issue-bound), the head sits at the 1400 W cap: if the runtime interleaves them the package could stay at the cap
-all the time (DESIGN.md 4.2b)."""
+all the time (DESIGN.md 4.10)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """(round 6) Formerly tests/test_gpu_frontend3.py: parity checks of the matrix-pipe frontend experiment.  The kernel no longer ships in
-libnwwhip.so (it is slower than the FFT kernel: DESIGN 4.1b); these checks ran green against the round-5 library with NWW_FE3=1 and are
+libnwwhip.so (it is slower than the FFT kernel: DESIGN 4.1); these checks ran green against the round-5 library with NWW_FE3=1 and are
 kept for the record - they need a library build that links tools/ubench/fe3/frontend3.hip and honours NWW_FE3.
 """
 """The matrix-pipe frontend (frontend3.hip; opt-in NWW_FE3 = 1): the 400-point DFT as a prime-factor 25 x 16 pair of dense products

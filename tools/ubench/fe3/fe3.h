@@ -3,7 +3,7 @@
 //
 // Replaces, per 400-sample frame, the dense windowed DFT the reference's CPU interpreter executes as two conv1d's
 // (nanowakeword/_export/onnx.py:42-63 bases, :66-83 forward) by a PRIME-FACTOR 25 x 16 pair of small dense products on
-// v_mfma_f32_16x16x32_f16, in the two-term binary16 arithmetic of DESIGN 4.2c:
+// v_mfma_f32_16x16x32_f16, in the two-term binary16 arithmetic of DESIGN 2:
 //   sample n = 16 j + c of the frame  (c = n mod 16 "class", j = 0..24);  bin k <-> (k1, k2) = (k mod 16, k mod 25)
 //   n1 = 9 n mod 16, n2 = 11 n mod 25  =>  exp(-2 pi i n k / 400) = W16^(n1 k1) W25^(n2 k2)      (no twiddles between the stages)
 //   stage 1, per class c:  Z_c[k2] = sum_j x[16 j + c] w[16 j + c] W25^(n2 k2),  k2 = 0..12 (real input: the rest are conjugates)

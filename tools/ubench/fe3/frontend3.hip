@@ -14,7 +14,7 @@
 //                 (16 registers), re^2 + im^2 of the lane's four bins -> power rows (bin maps in registers)
 //   P3  mel + dB  wave w owns frames 4 w .. 4 w + 3: lane = filter, taps in registers (frontend2's S4), v_log_f32, 16-byte copy-out
 // Three workgroup barriers per item, 52 KB of LDS per workgroup.  HBM traffic per clip: 2 N bytes read + 4 n_mels T written.
-// MEASURED (DESIGN 4.1b): 0.21 ms per 4096 clips against frontend2's 0.155 - the kernel is OPT-IN (NWW_FE3 = 1).  Its 37 M VALU
+// MEASURED (DESIGN 4.1): 0.21 ms per 4096 clips against frontend2's 0.155 - the kernel is OPT-IN (NWW_FE3 = 1).  Its 37 M VALU
 // instructions per launch are half of frontend2's 78 M, but the dataflow moves ~200 KB per 16-frame item through LDS (planes 12 + 32,
 // Z 27 + 27, powers 13 + 82 re-read lane = filter, dB stage 8), and at the 64 (stores) to 128 (reads) bytes per clock the LDS pipe
 // sustains that is 2 500-3 500 clocks per item whatever the occupancy: 2 waves per SIMD (this default) and 4 (-DFE3_NW=16) run the same.
@@ -83,7 +83,7 @@ unsigned long long* g_fe3_trace = nullptr;
 //   4 waves x 1 item (default): four classes per wave, 224 registers, two workgroups per CU - 0.213-0.222 ms per 4096 clips
 //   16 waves x 2 items (-DFE3_NW=16): ONE class per wave - its stage-1 matrices are 16 registers instead of 64, the resident set ~60 -
 //      so a wave fits 128 registers and the CU holds 16 waves = FOUR per SIMD (one 1024-thread workgroup, 104 KB of LDS): 0.224 ms,
-//      THE SAME: occupancy is not what bounds this kernel, the LDS pipe is (~200 KB per item through 64-128 B per clock: DESIGN 4.1b)
+//      THE SAME: occupancy is not what bounds this kernel, the LDS pipe is (~200 KB per item through 64-128 B per clock: DESIGN 4.1)
 //   8 x 1: spills 27-83 registers at 128, 0.25 ms
 #ifndef FE3_NW
 #define FE3_NW 4

@@ -158,7 +158,8 @@ __device__ __forceinline__ void x3_mfma(const bf16x8* x, const bf16x8* y, f32x16
 //   ReLU with BN:    al s / k, be s                        (nothing else changes)
 //   other:           al / k (1 / k without BN), be, post = s   (the activation sees the true value)
 // pos (wave-uniform, BN only): every folded-BN factor of the layer is >= 0 (checked at plan time) - the window's maximum alone decides
-template <int ACT, bool BN, bool SC = false>
+// NB: the layer has no bias (bias = 0 exactly): the add is left out
+template <int ACT, bool BN, bool SC = false, bool NB = false>
 __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v3, float bias, float nbias, float al, float be, float post = 1.0f,
                                            bool pos = false) {
     if (ACT == ACT_RELU && !BN) {
@@ -176,11 +177,11 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
         float t, mx, mn;
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(v3));
-        if (pos) return fmaxf((mx + bias) * al + be, 0.0f);
+        if (pos) return fmaxf((NB ? mx : mx + bias) * al + be, 0.0f);
         asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
         asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(v3));
         const float e = al < 0.0f ? mn : mx;
-        return fmaxf((e + bias) * al + be, 0.0f);
+        return fmaxf((NB ? e : e + bias) * al + be, 0.0f);
     }
     // GELU / SiLU fall to their single minimum (x = -0.75 / -1.28) and rise after it, and bias + folded BN is monotone: over the
     // window, act(bn(v)) is largest at the window's LARGEST or SMALLEST v - two activations per pooled value instead of four
@@ -190,7 +191,7 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
     asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(t), "v"(v3));
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v0), "v"(v1), "v"(v2));
     asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(v3));
-    float a = mx + bias, b = mn + bias;
+    float a = NB ? mx : mx + bias, b = NB ? mn : mn + bias;
     if (BN) { a = a * al + be; b = b * al + be; }
     const float m = fmaxf(tb_act<ACT>(a), tb_act<ACT>(b));
     return SC ? m * post : m;
@@ -993,7 +994,7 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         }
     };
     const int cq = tid & 7, dslot = tid >> 3;                  // depthwise: four channels 4 cq .., NTHR / 8 output slots
-    const bool bn_pos = __builtin_amdgcn_readfirstlane(a.bn_pos) != 0;
+    const bool bn_pos = __builtin_amdgcn_readfirstlane(a.bn_pos) != 0, has_bias = a.bias != nullptr;
     // depthwise, stride 2 along x (the BcResNet geometry): a thread owns TWO outputs along x of one row for the whole launch - its five
     // input columns' offsets in P (slot, swizzle) are computed once here, out-of-plane columns marked -1
     const int Wg2 = (Wo + 1) >> 1, dw_rpp = (NTHR >> 3) / max(Wg2, 1);
@@ -1006,6 +1007,9 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
     const int colE0 = 4 * dw_xg * 128 + 16 * (cq ^ dw_z), colO0 = (4 * dw_xg + 2) * 128 + 16 * (cq ^ dw_z ^ 1);
     const int colL0 = dw_xg > 0 ? (4 * dw_xg - 1) * 128 + 16 * (cq ^ (1 | (2 * ((dw_xg - 1) & 1)))) : 0;
     const int prow_b = W1p * 128;                               // bytes per P row
+    const int dw_row0 = dw_ry * sh * prow_b;                    // the lane's row of a depthwise pass, in bytes of P
+    const int dw_out0 = (dw_ry * Wo + 2 * dw_xg) * 32 + 4 * cq; // its first output inside the pass's rows
+    const int oy_last2 = (H1 - 2) / max(sh, 1);                 // the last depthwise row whose third input row (oy sh + 1) lies in the plane
     const unsigned char* const Pb = reinterpret_cast<const unsigned char*>(P);
     const unsigned char* const Zrow = Pb + (size_t)gg.max_conv * prow_b;
     // convolution tasks with one 32-pixel group per row (W1 <= 32): the lane's operand / result addresses are a lane constant plus a wave-uniform
@@ -1036,8 +1040,8 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         strip_rows(sidx, oy0, oy1, r_lo, r_hi);
         // the lane constants pass through an opaque copy per strip: left loop-invariant, every address derived from them (one per LDS access of
         // the two phases) is hoisted out of the clip loop and spilled - 59 registers' worth
-        int cv_in = cv_in0, cv_out = cv_out0, colE = colE0, colO = colO0, colL = colL0, cqv = cq, xgv = dw_xg;
-        asm volatile("" : "+v"(cv_in), "+v"(cv_out), "+v"(colE), "+v"(colO), "+v"(colL), "+v"(cqv), "+v"(xgv));
+        int cv_in = cv_in0, cv_out = cv_out0, colE = colE0, colO = colO0, colL = colL0, cqv = cq, xgv = dw_xg, rowv = dw_row0, outv = dw_out0;
+        asm volatile("" : "+v"(cv_in), "+v"(cv_out), "+v"(colE), "+v"(colO), "+v"(colL), "+v"(cqv), "+v"(xgv), "+v"(rowv), "+v"(outv));
         const int cv_out1 = cv_out ^ 16;                          // ((q0 + 1) ^ sz = (q0 ^ sz) ^ 1: q0 is even)
         // ---- conv + BN + act + pool of rows r_lo .. r_hi -> P
         const int ntask = (r_hi - r_lo + 1) * ngx * 2;
@@ -1052,9 +1056,12 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(base + tt * plane_b + pitch0);
                 cf[tt] = frag4(p[0], p[1], q[0], q[1]);
             }
-            // the wave's bias / folded-BN rows travel under the MFMAs (requested behind them they put an LDS round trip into every task)
+            // the wave's folded-BN rows (and bias rows, if the layer has a bias - BcResNet's init conv has none) travel under the MFMAs:
+            // requested behind them they put an LDS round trip into every task
             const float4* bp = reinterpret_cast<const float4*>(BNp + 16 * set + 8 * hi);
-            const float4 b0v = bp[0], b1v = bp[1], a0v = bp[8], a1v = bp[9], e0v = bp[16], e1v = bp[17];
+            float4 b0v = make_float4(0.f, 0.f, 0.f, 0.f), b1v = b0v;
+            if (has_bias) { b0v = bp[0]; b1v = bp[1]; }
+            const float4 a0v = bp[8], a1v = bp[9], e0v = bp[16], e1v = bp[17];
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -1070,7 +1077,11 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
             const float al[8] = {a0v.x, a0v.y, a0v.z, a0v.w, a1v.x, a1v.y, a1v.z, a1v.w};
             const float be[8] = {e0v.x, e0v.y, e0v.z, e0v.w, e1v.x, e1v.y, e1v.z, e1v.w};
             float m[8];
-            if (bn_pos) {                                         // (one wave-uniform branch per task instead of one per channel)
+            if (BN && bn_pos && !has_bias) {                      // (one wave-uniform branch per task instead of one per channel)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc)
+                    m[cc] = pool_quad<ACT, BN, false, true>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], 0.0f, 0.0f, al[cc], be[cc], 1.0f, true);
+            } else if (bn_pos) {
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc)
                     m[cc] = pool_quad<ACT, BN>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1], bs[cc], -bs[cc], al[cc], be[cc], 1.0f, true);
@@ -1103,13 +1114,14 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
         // ---- depthwise 3x3 of the strip's rows out of P (taps in dwconv3x3_nhwc_kernel's order and fmaf chain)
         if (F16 && dw_fast) {
             if (dw_ry < dw_rpp) {
-                for (int oyl = dw_ry; oyl < oy1 - oy0; oyl += dw_rpp) {
+                // every lane term of the addresses is a launch constant (rowv, outv); what changes with the strip / the pass is wave-uniform
+                int oyb = oy0;                                    // the pass's first row
+                for (int oyl = dw_ry; oyl < oy1 - oy0; oyl += dw_rpp, oyb += dw_rpp) {
                     const int oy = oy0 + oyl;
                     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, centre[2] = {acc[0], acc[0]};
                     // rows oy sh - 1 .. + 1 of the plane (the middle one always exists), an out-of-plane row = the zero row
-                    const int yy0 = oy * sh - 1;
-                    const unsigned char* const r1 = Pb + (yy0 + 1 - r_lo) * prow_b;
-                    const unsigned char* const rb[3] = {yy0 >= 0 ? r1 - prow_b : Zrow, r1, yy0 + 2 < H1 ? r1 + prow_b : Zrow};
+                    const unsigned char* const r1 = Pb + (oyb * sh - r_lo) * prow_b + rowv;
+                    const unsigned char* const rb[3] = {oy > 0 ? r1 - prow_b : Zrow, r1, oy <= oy_last2 ? r1 + prow_b : Zrow};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const unsigned char* const pe = rb[dy] + colE;
@@ -1142,16 +1154,18 @@ __global__ void __launch_bounds__(512, 4) bc_front_b_kernel(Conv1DwArgs a) {
                     for (int j = 0; j < 2; ++j) {
                         const int ox = 2 * xgv + j;
                         if (ox < Wo) {
-                            const size_t oi = ((size_t)b * Ho * Wo + (size_t)oy * Wo + ox) * 32 + 4 * cqv;
+                            // the clip's plane (wave-uniform, 64 bits) + the lane's 32-bit offset inside it
+                            const size_t ob = (size_t)b * Ho * Wo * 32 + (size_t)(oyb * Wo * 32 + 32 * j);
+                            const unsigned ol = (unsigned)outv;
                             if (a.bf16_out) {                     // wave-uniform: 16-bit activations (split_h2.h)
                                 const int k16 = a.bf16_out;
-                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_out) + oi) =
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.d_out) + ob + ol) =
                                     make_uint2(nww_pk_act16(k16, acc[j].x, acc[j].y, a.d_scale), nww_pk_act16(k16, acc[j].z, acc[j].w, a.d_scale));
-                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.xs_out) + oi) =
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.xs_out) + ob + ol) =
                                     make_uint2(nww_pk_act16(k16, centre[j].x, centre[j].y, a.xs_scale), nww_pk_act16(k16, centre[j].z, centre[j].w, a.xs_scale));
                             } else {
-                                *reinterpret_cast<float4*>(a.d_out + oi) = acc[j];
-                                *reinterpret_cast<float4*>(a.xs_out + oi) = centre[j];
+                                *reinterpret_cast<float4*>(a.d_out + ob + ol) = acc[j];
+                                *reinterpret_cast<float4*>(a.xs_out + ob + ol) = centre[j];
                             }
                         }
                     }

@@ -22,9 +22,11 @@ def run(n_cases=40, seed=0, log=print, kinds=("conformer", "crnn", "bcresnet", "
         kind = rng.choice(list(kinds))
         act = str(rng.choice(["relu", "gelu", "silu"]))
         if kind == "conformer":
-            d, nh = [(32, 2), (32, 8), (64, 4), (96, 4), (96, 2), (128, 4), (144, 4), (144, 8), (80, 4)][rng.integers(0, 9)]
+            # (144, 4) three times: the default width, whose attention is one clip-resident kernel for 64 < T <= 128 (round 6); 192 / 256: the
+            # fused kernels' wide instances; two blocks: the feed-forward launch with and without the Linears / the time sums folded into it
+            d, nh = [(32, 2), (32, 8), (64, 4), (96, 4), (96, 2), (128, 4), (144, 4), (144, 4), (144, 4), (144, 8), (80, 4), (192, 4), (256, 4), (256, 8)][rng.integers(0, 14)]
             cfg = HeadConfig("conformer", (int(rng.integers(3, 140)), int(rng.choice([32, 40, 64]))), embedding_dim=16,
-                             conformer_d_model=d, conformer_n_head=nh, activation=act)
+                             conformer_d_model=d, conformer_n_head=nh, activation=act, n_blocks=int(rng.choice([1, 1, 2])))
         elif kind == "crnn":
             # conv stacks the fused trunk takes and does not take, 64+ channel stages (k-split passes), clips up to 2.6 s (row strips), recurrent
             # widths between the register-resident ones (zero-padded instances) and above them
@@ -43,7 +45,7 @@ def run(n_cases=40, seed=0, log=print, kinds=("conformer", "crnn", "bcresnet", "
                              layer_dim=int(rng.choice([20, 32, 48, 64, 96, 100, 128, 160])), n_blocks=int(rng.integers(1, 3)))
         else:
             cfg = HeadConfig("e2e_dnn", (int(rng.choice([32, 40, 64])), int(rng.integers(32, 130))), embedding_dim=16, activation=act)
-        B = int(rng.choice([1, 2, 5, 17, 33, 130]))
+        B = int(rng.choice([1, 2, 5, 17, 33, 130, 300]))
         try:
             sd = synth_state_dict(cfg)
             m = HipModel(cfg, FrontendConfig(n_mels=min(cfg.input_shape[1], 128) if kind != "e2e_dnn" else cfg.input_shape[0]), state_dict=sd,

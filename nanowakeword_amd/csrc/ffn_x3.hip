@@ -499,7 +499,12 @@ __global__ void __launch_bounds__(256) ffn_x3_kernel(FfnArgs a) {
                 if (m < NT && kb + 1 < D16) nw[m] = *reinterpret_cast<const bf16x8*>(w1p + ((kb + 1) * NT + m) * 1024);
                 acc = ffn_mma<H2>(cw[PW[m]], xf[kb][PX[m]], acc);
                 asm volatile("" : "+a"(acc));
-                const int j0 = q * (NF1 + NF2) / NSLOT, j1 = (q + 1) * (NF1 + NF2) / NSLOT;      // the fetches of the blocks ahead, spread over the slots
+                // the fetches of the blocks ahead: one per slot from the block's first MFMA on.  (Spread evenly over all 27 slots, as in
+                // round 5, the last piece left ~1600 clocks before the block's end and the wave then waited ~300 for it at vmcnt(0): one per slot
+                // -2.5 % plain / with the K = 64 prologue, -4.5 % with the K = 144 prologue + epilogue; tools/ubench/ffn_trace without -DNWW_TRACE -
+                // with the stamps' own stores in vmcnt the trace cannot see this wait.)
+                constexpr int FS = (NF1 + NF2 + 1) < NSLOT ? (NF1 + NF2 + 1) : NSLOT;
+                const int j0 = (q < FS ? q : FS) * (NF1 + NF2) / FS, j1 = (q + 1 < FS ? q + 1 : FS) * (NF1 + NF2) / FS;
                 for (int j = j0; j < j1; ++j) {
                     if (j < NF1) { if (fp.s1) fetch_step(fp.s1, fp.d1, j); }
                     else if (fp.s2) fetch_step(fp.s2, fp.d2, j - NF1);

@@ -47,6 +47,16 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("ffn_x3 D=%d M=%d: %.4f ms per launch (%s)\n", D, M, ms, hipGetErrorString(hipGetLastError()));
+#ifndef NWW_TRACE      // built without -DNWW_TRACE: timing only (20 launches back to back)
+    {
+        hipEventRecord(e0, s);
+        for (int i = 0; i < 20; ++i) launch_ffn_x3(a, D, s);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("ffn_x3 D=%d M=%d mode %d: %.4f ms per launch over 20 launches, no stamps\n", D, M, mode, ms / 20);
+        return 0;
+    }
+#else
     std::vector<unsigned long long> tr(4 * 32 * 8);
     hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_ffn_trace), tr.size() * 8);
     printf("clocks since the block's top (even blocks 2..14 averaged): fetches issued | product 1 + epilogue | product 2 issued | vmcnt(0) | behind barrier | next stamped top (2 blocks later)\n");
@@ -70,4 +80,5 @@ int main(int argc, char** argv) {
         printf("\n");
     }
     return 0;
+#endif
 }

@@ -220,6 +220,8 @@ __global__ void __launch_bounds__(64 * NWV, 2) lin_x3_kernel(LinArgs a) {
     // pieces of 64 different rows (64 cache lines per instruction - tools/ubench/lin_trace: issuing a block's four stores took 2450 of its 7700
     // clocks, the residual's loads likewise); transposed, lane l of store j owns 16 bytes of row 8 j + l / 8 and eight lanes cover a row's 128
     // contiguous bytes.  Same arithmetic per element: bit-identical results.
+    // (GLU, measured in round 6: its product a sigmoid(b) formed in the accumulator layout, then through the same transpose - 0.1014 ms against
+    // 0.101-0.104 direct, 230 registers instead of 174; four-wave workgroups of 128 rows for a finer tail - 0.120: not kept)
     constexpr bool TR = EPI != 2;
     constexpr int TP = 36;                                     // floats per row of the transpose tile (16-byte writes of 16 lanes: conflict-free)
     __shared__ __attribute__((aligned(16))) float tbuf[TR ? NWV * 32 * TP : 4];

@@ -14,6 +14,7 @@ struct AttnArgs {
     float cK, cV;                    // powers of two that bring the raw k / v accumulators into the binary16 range (plan-time bounds)
     float o_un;                      // 1 / (scale of the packed out_proj weights x in_proj weight scale x cV)
     float qscale;                    // 1 / sqrt(head dim)
+    int stagger = 0;                 // set by the launcher: start-up delay step in shader clocks (workgroups start in eight phases)
 };
 
 bool attn_x3_supported(int T, int D, int n_head);

@@ -190,6 +190,16 @@ __global__ void __launch_bounds__(256) attn_x3_kernel(AttnArgs a) {
     };
     using StepsIn = std::integral_constant<int, S_IN>;
     using StepsO = std::integral_constant<int, S_O>;
+    // Start-up stagger (many clips per workgroup only): every workgroup runs the same phases on the same amount of data, so all CUs reach
+    // their memory phase - the epilogue's residual rows in, updated rows out, the next clip's rows in: 3 x 58 KB - TOGETHER and share the HBM
+    // for it; started in eight phases 2000 clocks apart they stay apart for the whole launch.  Measured at B = 2048 (tools/ubench/attn_trace):
+    // epilogue 16.6-17.4 k -> 11.7-12.1 k clocks, clip 81.7 k -> 77.3 k, launch 0.340 -> 0.326 ms; 1000 / 4000 / 8000 clocks per phase:
+    // 0.335 / 0.336 / 0.351 (the delay itself: seven steps at most, once).
+    if (a.stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long d = (unsigned long long)(((int)blockIdx.x >> 3) & 7) * (unsigned)a.stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
     if ((int)blockIdx.x < a.B) {
         fetch(a.packed, slot1, StepsIn{});
         fetch(a.packed + ATT_CH_IN, slot2, StepsIn{});
@@ -583,12 +593,14 @@ hipError_t launch_attn_x3_pack(const float* in_w, const float* in_b, const float
     return hipGetLastError();
 }
 
-hipError_t launch_attn_x3(const AttnArgs& a, int D, int n_head, hipStream_t s) {
-    if (a.B <= 0) return hipSuccess;
-    if (!attn_x3_supported(a.T, D, n_head)) return hipErrorInvalidValue;
-    if (((reinterpret_cast<uintptr_t>(a.h) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.bc)) & 15) != 0) return hipErrorInvalidValue;
+hipError_t launch_attn_x3(const AttnArgs& a0, int D, int n_head, hipStream_t s) {
+    if (a0.B <= 0) return hipSuccess;
+    if (!attn_x3_supported(a0.T, D, n_head)) return hipErrorInvalidValue;
+    if (((reinterpret_cast<uintptr_t>(a0.h) | reinterpret_cast<uintptr_t>(a0.out) | reinterpret_cast<uintptr_t>(a0.bc)) & 15) != 0) return hipErrorInvalidValue;
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const dim3 grid(a.B < cus ? a.B : cus);
+    const dim3 grid(a0.B < cus ? a0.B : cus);
+    AttnArgs a = a0;
+    a.stagger = a0.B >= 4 * cus ? 2000 : 0;                    // (fewer clips per workgroup: the delay would not pay back)
     const int nt16 = (a.T + 15) / 16;
     if (nt16 == 7) hipLaunchKernelGGL((attn_x3_kernel<9, 4, 36, 7>), grid, dim3(256), 0, s, a);          // T = 97 .. 112: 1 s clips at the 10 ms hop
     else if (nt16 == 8) hipLaunchKernelGGL((attn_x3_kernel<9, 4, 36, 8>), grid, dim3(256), 0, s, a);

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) rnn_stream_pack_kernel(const float* __res
 template <int G, int HP, int RING, int RS_MT>
 __global__ void __launch_bounds__(64 * (HP / 32)) rnn_stream_kernel(GruArgs a) {
     constexpr int KS = HP / 32, NWV = HP / 32;
-    constexpr int LDP = HP + 8;                               // binary16 per LDS row: +16 bytes keeps the 16-byte fragment reads conflict-free
+    constexpr int LDP = HP + 16;                              // binary16 per LDS row: + 32 bytes - conflict-free fragment reads for the real ds_read_b128 lane groups (rnn_x3.hip)
     constexpr int UPK = G * RS_NB;                            // units per k-block and wave
     constexpr int NU = KS * UPK;                              // units per step and wave
     static_assert(NU % RING == 0, "the ring closes on the step");
@@ -296,7 +296,7 @@ hipError_t launch_rnn_stream(const GruArgs& a, int gates, hipStream_t s) {
     static const int n_cu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
     const int mt = force_mt == 1 || force_mt == 2 ? force_mt : (a.B <= 16 * n_cu ? 1 : 2);
     const dim3 grid((a.B + 16 * mt - 1) / (16 * mt)), block(64 * (HP / 32));
-    const size_t lds = (size_t)2 * 2 * 16 * mt * (HP + 8) * sizeof(uint16_t);      // two sets of two term planes
+    const size_t lds = (size_t)2 * 2 * 16 * mt * (HP + 16) * sizeof(uint16_t);     // two sets of two term planes
 #ifdef NWW_ABLATION
     GruArgs ad = a;
     { const char* e = getenv("NWW_RNN_DBG"); ad.dbg = e ? atoi(e) : 0; }

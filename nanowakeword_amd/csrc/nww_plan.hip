@@ -387,6 +387,14 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
         p.h->packed_weights.push_back(packed);
         if (f16 && out_range) *out_range = F16Range{bound2, typ2};
         const int products = f16 ? 3 : x3;
+        // BN + ReLU stems (CRNN, E2E): all folded-BN factors of both layers non-negative (gamma > 0, the usual case) -> the pooled value is
+        // the window's maximum pushed through BN + ReLU (trunk_b.hip: POS instance)
+        int bn_pos = 0;
+        if (f16 && al1 && al2 && act == ACT_RELU) {
+            bn_pos = 1;
+            for (float v : f16_fetch(p.h, al1, C1)) if (!(v >= 0.0f)) bn_pos = 0;
+            for (float v : f16_fetch(p.h, al2, C2)) if (!(v >= 0.0f)) bn_pos = 0;
+        }
         if (in_id == -1 && !p.h->e2e_transposed) p.h->x_stride_ok = true;                   // this step reads the head input with any clip stride
         if (f16 && in_id == -1) p.h->clamps_features = true;
         p.add("trunk_x3:" + name + (f16 ? " [f16x3]" : ""), [=](Run& r) {
@@ -394,6 +402,7 @@ bool add_trunk(PlanCtx& p, const std::string& name, int in_id, int out_id, int C
             if (out_blocked && *out_blocked) a.out_blocked = C2 * (H / 4) * (W / 4) / 32;     // decided by the consumer (add_gemm) at plan time
             a.wpack = static_cast<const unsigned char*>(packed);
             if (f16) { a.f16_in = f_in; a.f16_k1 = f_in * f_w1; a.f16_s1 = f_s1; a.f16_k2 = f_s1 * f_w2; a.f16_so = 1.0f; a.f16_clamp = (float)in_bound; }
+            a.bn_pos = bn_pos;
             if (in_id == -1) a.in_clip_stride = r.x_stride;
             if (r.stream_mode) {                        // streaming hop: pooled rows into the per-stream rings, all of them or the invalidated ones
                 a.out = r.a2_ring; a.out_ring_rows = r.a2_rows; a.out_row0 = r.a2_row0;

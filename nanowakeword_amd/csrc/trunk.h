@@ -10,6 +10,7 @@ struct TrunkArgs {
     float* out;                                        // [B][C2][H/4][W/4]
     int B, H, W, act;
     int dbg = 0;                                       // ablation only: bit0 skip conv1, bit1 skip conv2
+    int bn_pos = 0;                                    // trunk_b, two-term form: every folded-BN factor al1 / al2 is >= 0 (plan-time check)
     int strips = 1;                                    // row strips per clip (set by launch_cnn_trunk)
     // > 0: write the output as the split-operand GEMM's A tiles instead of [B][C2][H/4][W/4]: 128-clip row blocks x
     // out_blocked k-tiles of 32 features, each (row block, k-tile) a contiguous [128][32] float tile (gemm_x3.hip)

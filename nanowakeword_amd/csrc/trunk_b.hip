@@ -200,7 +200,7 @@ __device__ __forceinline__ float pool_quad(float v0, float v1, float v2, float v
 // conv2 of one tile: 32 pixels (2 rows x 16 columns) x 32 output channels, 9 taps x (K = 16 input channels = one MFMA
 // per product).  The lane's pixel contributes three 16-byte fragments per tap (8 channels of one term).  pa: the
 // lane's pixel of the tile, dst: where its four pooled columns of output channel i go, nv: how many of them exist.
-template <int ACT, int PRODUCTS, bool BN>
+template <int ACT, int PRODUCTS, bool BN, bool POS = false>
 __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, const bf16x8 (&bw)[TbA<PRODUCTS>::NWA], const unsigned char* wl,
                                            float bias2, float nbias2, float al2, float be2, float post2, float* dst, int nv) {
     using AR = TbA<PRODUCTS>;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
     float own[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)                      // pooled column 8X + 2k + hi
-        own[k] = pool_quad<ACT, BN, AR::F16>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2);
+        own[k] = pool_quad<ACT, BN, AR::F16>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2, POS);
     // half 0 keeps columns 0..3 of the 8-column segment, half 1 keeps 4..7: v_permlane32_swap hands the upper half of
     // its first operand to the lower half of the second and vice versa - after it both halves hold (x, y) and (z, w)
     const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
@@ -257,7 +257,7 @@ __device__ __forceinline__ void conv2_tile(const unsigned char* pa, int rowB, co
 // per wave for 864 clocks of MFMAs (tools/ubench/trunk_trace.hip).  The fragments travel THREE taps ahead in a ring of
 // registers instead, across the tile boundary too: the last three taps of a tile request the first three of the wave's next
 // tile (pa_next; null behind the last tile).  ring: taps 0..2 of this tile on entry, of the next tile on exit.
-template <int ACT, bool BN>
+template <int ACT, bool BN, bool POS = false>
 __device__ __forceinline__ void conv2_tile_h2(const unsigned char* pa, const unsigned char* pa_next, int rowB, const bf16x8 (&bw)[18],
                                               bf16x8 (&ring)[3][2], float bias2, float nbias2, float al2, float be2, float post2,
                                               float* dst, int nv) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void conv2_tile_h2(const unsigned char* pa, const uns
     float own[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        own[k] = pool_quad<ACT, BN, true>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2);
+        own[k] = pool_quad<ACT, BN, true>(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3], bias2, nbias2, al2, be2, post2, POS);
     const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
     const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[1]), __float_as_uint(own[3]), false, false);
     float4 o;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void conv2_tile_h2(const unsigned char* pa, const uns
 // Two tiles of one wave in flight: a wave with one accumulator chain leaves the matrix pipe to its partner (or idle) through its own
 // epilogue and prologue - a lone wave takes 2.0 k clocks per tile for 864 clocks of MFMAs, and the SIMD's two waves own 3 + 4 tiles.
 // Per tap the fragments of both tiles are fetched one tap ahead (six MFMAs cover the LDS round trip) and share the weight fragments.
-template <int ACT, bool BN>
+template <int ACT, bool BN, bool POS = false>
 __device__ __forceinline__ void conv2_pair_h2(const unsigned char* pa0, const unsigned char* pa1, int rowB, const bf16x8 (&bw)[18],
                                               float bias2, float nbias2, float al2, float be2, float post2,
                                               float* dst0, int nv0, float* dst1, int nv1) {
@@ -339,7 +339,7 @@ __device__ __forceinline__ void conv2_pair_h2(const unsigned char* pa0, const un
         float own[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            own[k] = pool_quad<ACT, BN, true>(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3], bias2, nbias2, al2, be2, post2);
+            own[k] = pool_quad<ACT, BN, true>(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3], bias2, nbias2, al2, be2, post2, POS);
         const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[0]), __float_as_uint(own[2]), false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[1]), __float_as_uint(own[3]), false, false);
         float4 o;
@@ -448,7 +448,9 @@ __global__ void __launch_bounds__(64) trunk_b_pack_f16_kernel(const float* __res
 // With the roles swapped - conv1 on waves 0-3, the OLDER half that the SIMD's issue arbitration favours - 0.230 against 0.223, and
 // s_setprio 2 on the conv1 waves changes nothing: one after the other or side by side, the launch takes about the SUM of its matrix
 // time (0.10 ms at the clock it runs at) and its VALU time (0.09 ms).
-template <int ACT, int PRODUCTS, bool BN>
+// POS (BN + ReLU, two-term instances): every folded-BN factor of both layers is >= 0 (TrunkArgs::bn_pos, checked at plan time) - the pooled
+// value is the window's maximum pushed through BN + ReLU, five operations instead of nine (pool_quad)
+template <int ACT, int PRODUCTS, bool BN, bool POS = false>
 __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
     using AR = TbA<PRODUCTS>;
     constexpr bool F16 = AR::F16;
@@ -650,7 +652,7 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
                 for (int e = 0; e < 2; ++e) {
                     const int cc = 2 * c2 + e;
                     m2[e] = pool_quad<ACT, BN, F16>(acc0[2 * cc], acc0[2 * cc + 1], acc1[2 * cc], acc1[2 * cc + 1],
-                                                    b1v[cc], nb1v[cc], al1v[cc], be1v[cc], post1);
+                                                    b1v[cc], nb1v[cc], al1v[cc], be1v[cc], post1, POS);
                 }
                 if (F16) {
                     nww_split2h(m2[0], m2[1], ph[c2], pm[c2]);
@@ -715,7 +717,7 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
             for (; n + 1 < cnt; n += 2) {
                 int R1 = R, X1 = X;
                 step(R1, X1);
-                conv2_pair_h2<ACT, BN>(tile_pa(R, X), tile_pa(R1, X1), rowB, bw, bias2, -bias2, al2, be2, post2,
+                conv2_pair_h2<ACT, BN, POS>(tile_pa(R, X), tile_pa(R1, X1), rowB, bw, bias2, -bias2, al2, be2, post2,
                                        tile_dst(R, X), tile_nv(X), tile_dst(R1, X1), tile_nv(X1));
                 if (n < 4) TB_STAMP(2 + n / 2);
                 R = R1; X = X1;
@@ -729,11 +731,11 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
                     ring[t][0] = *reinterpret_cast<const bf16x8*>(pa + t * PS);
                     ring[t][1] = *reinterpret_cast<const bf16x8*>(pa + t * PS + 32);
                 }
-                conv2_tile_h2<ACT, BN>(pa, nullptr, rowB, bw, ring, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
+                conv2_tile_h2<ACT, BN, POS>(pa, nullptr, rowB, bw, ring, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
             }
         } else {
             for (int n = 0; n < cnt; ++n) {
-                conv2_tile<ACT, PRODUCTS, BN>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
+                conv2_tile<ACT, PRODUCTS, BN, POS>(tile_pa(R, X), rowB, bw, wl, bias2, -bias2, al2, be2, post2, tile_dst(R, X), tile_nv(X));
                 if (n < 4) TB_STAMP(2 + n);
                 step(R, X);
             }
@@ -792,8 +794,8 @@ __device__ __forceinline__ void cnn_trunk_b_body(const TrunkArgs& a) {
 }
 template <int ACT, int PRODUCTS, bool BN>
 __global__ void __launch_bounds__(512, 2) cnn_trunk_b_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, PRODUCTS, BN>(a); }
-template <int ACT, bool BN>
-__global__ void __launch_bounds__(512, 2) cnn_trunk_h2_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, 3, BN>(a); }
+template <int ACT, bool BN, bool POS = false>
+__global__ void __launch_bounds__(512, 2) cnn_trunk_h2_kernel(TrunkArgs a) { cnn_trunk_b_body<ACT, 3, BN, POS>(a); }
 
 
 
@@ -1263,9 +1265,10 @@ bool trunk_b_rows_fit(int H, int W, int r2a, int r2b) {
         const bool bn_ = (aa).al1 != nullptr || (aa).al2 != nullptr;                                                   \
         hipError_t e_ = hipErrorInvalidValue;                                                                          \
         int key_ = ((aa).act == ACT_RELU ? 0 : (aa).act == ACT_GELU ? 1 : (aa).act == ACT_SILU ? 2 : 3) * 4 + (products == 6 ? 0 : 2) + (bn_ ? 1 : 0); \
-        if (products == 3) key_ = (aa).act == ACT_RELU ? (bn_ ? 13 : 12) : (aa).act == ACT_GELU ? 14 : (aa).act == ACT_SILU ? 15 : 99; \
+        if (products == 3) key_ = (aa).act == ACT_RELU ? (bn_ ? ((aa).bn_pos ? 16 : 13) : 12) : (aa).act == ACT_GELU ? 14 : (aa).act == ACT_SILU ? 15 : 99; \
         switch (key_) {                                                                                                \
             TB_CASE_H2(12, ACT_RELU, false) TB_CASE_H2(13, ACT_RELU, true) TB_CASE_H2(14, ACT_GELU, true) TB_CASE_H2(15, ACT_SILU, true) \
+            TB_CASE_H2P(16, ACT_RELU)                                                                                  \
             TB_CASE(0, ACT_RELU, 6, false) TB_CASE(1, ACT_RELU, 6, true) TB_CASE(2, ACT_RELU, 9, false) TB_CASE(3, ACT_RELU, 9, true)   \
             TB_CASE(4, ACT_GELU, 6, false) TB_CASE(5, ACT_GELU, 6, true) TB_CASE(6, ACT_GELU, 9, false) TB_CASE(7, ACT_GELU, 9, true)   \
             TB_CASE(8, ACT_SILU, 6, false) TB_CASE(9, ACT_SILU, 6, true) TB_CASE(10, ACT_SILU, 9, false) TB_CASE(11, ACT_SILU, 9, true) \
@@ -1277,6 +1280,11 @@ bool trunk_b_rows_fit(int H, int W, int r2a, int r2b) {
     case K:                                                                                                            \
         e_ = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_h2_kernel<ACTV, BNV>), lds);                        \
         if (e_ == hipSuccess) hipLaunchKernelGGL((cnn_trunk_h2_kernel<ACTV, BNV>), dim3(grid), dim3(NTHR), lds, s, aa); \
+        break;
+#define TB_CASE_H2P(K, ACTV)                                                                                           \
+    case K:                                                                                                            \
+        e_ = nww_allow_lds(reinterpret_cast<const void*>(cnn_trunk_h2_kernel<ACTV, true, true>), lds);                 \
+        if (e_ == hipSuccess) hipLaunchKernelGGL((cnn_trunk_h2_kernel<ACTV, true, true>), dim3(grid), dim3(NTHR), lds, s, aa); \
         break;
 #define TB_CASE(K, ACTV, PRODV, BNV)                                                                                   \
     case K:                                                                                                            \
